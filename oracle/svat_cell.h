@@ -1,0 +1,109 @@
+/*
+ * oracle/svat_cell.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Field list of the CPU restatement ("oracle") of RoGeR's SVAT time step.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything under oracle/.  The product (roger_amd/csrc) never includes this.
+ *
+ * One `oc_cell` holds every per-cell variable the reference step touches
+ * (reference: roger/variables.py VARIABLES, roger/core/<module>.py).  Variables that
+ * carry a trailing `timesteps=2` dimension in the reference (tau=1, taum1=0,
+ * roger/variables.py:200-214) are declared with OC_F2/OC_I2 and stored as
+ * NAME (tau) and NAME_m1 (taum1).
+ */
+#ifndef ORACLE_SVAT_CELL_H
+#define ORACLE_SVAT_CELL_H
+
+#include <stdint.h>
+
+/* X(kind, name): kind is F (double), F2 (double, two time levels), I (int32) */
+#define OC_FIELDS(X)                                                            \
+    X(I, maskCatch) X(I, maskRiver) X(I, maskLake) X(I, lu_id) X(I, no_wf)      \
+    /* forcing at the current step */                                           \
+    X(F2, prec) X(F2, ta) X(F, pet) X(F, pet_res)                               \
+    /* surface parameters */                                                    \
+    X(F, S_int_top_tot) X(F, S_int_ground_tot) X(F, S_dep_tot) X(F, c_int)      \
+    X(F2, ground_cover) X(F, lai) X(F, throughfall_coeff_top)                   \
+    X(F, throughfall_coeff_ground) X(F, basal_transp_coeff)                     \
+    X(F, basal_evap_coeff) X(F, swe_top_tot) X(F, sealing) X(F2, z_root)        \
+    X(F, c_root)                                                                \
+    /* soil parameters */                                                       \
+    X(F, z_soil) X(F, dmpv) X(F, lmpv) X(F, theta_ac) X(F, theta_ufc)           \
+    X(F, theta_pwp) X(F, theta_sat) X(F, theta_fc) X(F, ks) X(F, kf)            \
+    X(F, ks_ss) X(F, lambda_bc) X(F, m_bc) X(F, ha) X(F, n_salv) X(F, wfs)      \
+    X(F, z_evap) X(F, rew) X(F, tew) X(F, mp_drain_area) X(F, theta_27)         \
+    X(F, theta_4) X(F, theta_6) X(F, sand) X(F, clay) X(F, z_sc_max)            \
+    X(F, S_ac_rz) X(F, S_ufc_rz) X(F, S_pwp_rz) X(F, S_fc_rz) X(F, S_sat_rz)    \
+    X(F, S_ac_ss) X(F, S_ufc_ss) X(F, S_pwp_ss) X(F, S_fc_ss) X(F, S_sat_ss)    \
+    X(F, S_ac_s) X(F, S_ufc_s) X(F, S_pwp_s) X(F, S_fc_s) X(F, S_sat_s)         \
+    X(F2, z_gw) X(F, theta_irr) X(F, theta_fp_rz) X(F, theta_lp_rz)             \
+    X(F, theta_fp_ss) X(F, theta_lp_ss)                                         \
+    /* surface storages */                                                      \
+    X(F2, S_int_top) X(F2, S_int_ground) X(F2, S_dep) X(F2, S_snow) X(F2, swe)  \
+    X(F2, swe_top) X(F2, swe_ground) X(F2, S_sur) X(F2, z0)                     \
+    /* interception fluxes */                                                   \
+    X(F, rain_top) X(F, int_rain_top) X(F, rain_ground) X(F, int_rain_ground)   \
+    X(F, snow_top) X(F, int_snow_top) X(F, snow_ground) X(F, int_snow_ground)   \
+    X(F, int_top) X(F, int_ground) X(F, int_prec) X(F, prec_event_csum)         \
+    /* evapotranspiration */                                                    \
+    X(F, evap_int_top) X(F, evap_int_ground) X(F, evap_int) X(F, evap_dep)      \
+    X(F, evap_sur) X(F, k_stress_evap) X(F, evap_coeff) X(F, pevap_soil)        \
+    X(F, evap_soil) X(F, k_stress_transp) X(F, transp_coeff) X(F, pt)           \
+    X(F, ptransp) X(F, ptransp_res) X(F, transp) X(F, de) X(F, aet_soil)        \
+    X(F, aet)                                                                   \
+    /* snow */                                                                  \
+    X(F, snow_melt_top) X(F, snow_melt_drip) X(F, snow_melt_ground)             \
+    X(F, snow_melt) X(F, q_snow)                                                \
+    /* infiltration */                                                          \
+    X(F, pi_gr) X(F, pi_m) X(F, t_sat) X(F, Fs) X(F, Fs_t0) X(F, t_event_csum)  \
+    X(F, theta_d) X(F, theta_d_t0) X(F, theta_d_t1) X(F, theta_d_rel)           \
+    X(F, theta_d_rel_t0) X(F, theta_d_fp) X(F, inf_mat_pot) X(F, inf_mat)       \
+    X(F, inf_mat_event_csum) X(F, inf_mat_pot_event_csum) X(F2, z_wf)           \
+    X(F2, z_wf_t0) X(F2, z_wf_t1) X(F, z_wf_fc) X(F, lmpv_non_sat) X(F2, y_mp)  \
+    X(F, inf_mp) X(F, inf_mp_event_csum) X(F, inf_mp_rz) X(F, inf_mp_ss)        \
+    X(F, inf_ss) X(F, inf_mat_rz) X(F, z_sc) X(F, z_sc_non_sat) X(F2, y_sc)     \
+    X(F, inf_sc) X(F, inf_sc_event_csum) X(F, inf_sc_rz) X(F, inf_rz) X(F, inf) \
+    X(F, q_hof) X(F, q_sof) X(F, q_sur)                                         \
+    /* soil storages */                                                         \
+    X(F, S_fp_rz) X(F, S_lp_rz) X(F, S_fp_ss) X(F, S_lp_ss) X(F, S_fp_s)        \
+    X(F, S_lp_s) X(F2, S_rz) X(F2, S_ss) X(F2, S_s) X(F2, S) X(F, dS)           \
+    X(F, dS_rz) X(F, dS_ss) X(F, dS_s) X(F2, theta_rz) X(F2, theta_ss)          \
+    X(F2, theta) X(F2, k_rz) X(F2, k_ss) X(F2, k) X(F2, h_rz) X(F2, h_ss)       \
+    X(F2, h) X(F, irr_demand)                                                   \
+    /* subsurface */                                                            \
+    X(F2, z_sat) X(F, S_zsat) X(F, S_zsat_rz) X(F, S_zsat_ss) X(F, q_pot_rz)    \
+    X(F, q_rz) X(F, q_pot_ss) X(F, q_ss) X(F, cpr_rz)                           \
+    /* numerics */                                                              \
+    X(F, dS_num_error) X(F, dS_rz_num_error) X(F, dS_ss_num_error)
+
+typedef struct oc_cell {
+#define OC_DECL_F(n) double n;
+#define OC_DECL_F2(n) double n; double n##_m1;
+#define OC_DECL_I(n) int32_t n;
+#define OC_DECL(kind, n) OC_DECL_##kind(n)
+    OC_FIELDS(OC_DECL)
+#undef OC_DECL
+#undef OC_DECL_F
+#undef OC_DECL_F2
+#undef OC_DECL_I
+} oc_cell;
+
+/* global (per-domain) scalars of the reference: roger/variables.py:189-330 */
+typedef struct oc_scalars {
+    int64_t itt, time, dt_secs, itt_day, itt_forc, time_event0, event_id_counter;
+    int64_t event_id[2]; /* [0]=taum1, [1]=tau */
+    int64_t year[2], month[2], doy[2];
+    double dt;
+    /* outputs of the global checks, for tests */
+    int64_t sanity_ok;
+} oc_scalars;
+
+/* model settings used on the path: roger/settings.py:52-122 */
+typedef struct oc_settings {
+    double pi, r_mp, l_sc, sf, ta_fm, rmax, transp_water_stress, atol, rtol;
+    double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
+    double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
+    int64_t end_event, hpi;
+} oc_settings;
+
+#endif

@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the SVAT hot path from the reference NumPy backend.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What it does: imports the reference (`roger`, NumPy backend, float64, diskless),
+drives an in-memory `SVATSetup` subclass (heterogeneous per-cell parameters,
+synthetic forcing from roger_amd/forcing.py) through `setup()` and N calls of
+`step()`, and records
+
+  * the complete per-cell state after setup (the oracle's / HIP path's start
+    state, *including* all derived parameters, so setup-time kernels can be
+    checked separately from the step),
+  * the state after `soil.calculate_parameters` inputs only (raw user
+    parameters) for the setup-kernel tests,
+  * per-step global scalars (dt, dt_secs, itt_day, event ids, ...),
+  * full-state snapshots at selected steps, and per-routine snapshots for the
+    first steps of each dt class.
+
+Only *data* (inputs and expected outputs) is written; no reference code is
+stored.  Two third-party modules the reference imports but this image lacks are
+replaced by inert stand-ins that carry no arithmetic: `loguru` (logger that
+swallows every call) and `h5netcdf` (never touched in diskless mode).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+def _install_standins():
+    class _Null:
+        def __getattr__(self, name):
+            def f(*a, **k):
+                return self
+
+            return f
+
+    lg = types.ModuleType("loguru")
+    lg.logger = _Null()
+    sys.modules["loguru"] = lg
+    sys.modules["h5netcdf"] = types.ModuleType("h5netcdf")
+
+
+def import_reference():
+    _install_standins()
+    sys.path.insert(0, "/root/reference")
+    from roger import runtime_settings
+
+    runtime_settings.update(backend="numpy", float_type="float64", diskless_mode=True)
+    import roger  # noqa: F401
+
+    return roger
+
+
+# ---------------------------------------------------------------------------
+# scenarios
+# ---------------------------------------------------------------------------
+def hetero_params(nx, ny, seed=42):
+    """Per-cell parameters covering the land uses / soils the kernels branch on."""
+    rng = np.random.default_rng(seed)
+    n = nx * ny
+    lu_pool = np.array([8, 5, 10, 13, 0, 98, 11, 12, 6, 7, 9, 15, 8, 10, 5, 8])
+    lu = lu_pool[np.arange(n) % lu_pool.size]
+    z_soil = rng.uniform(400, 2000, n).round(0)
+    lmpv = np.minimum(rng.choice([0.0, 200.0, 500.0, 900.0, 1500.0], n), z_soil * 0.95).round(0)
+    p = dict(
+        lu_id=lu,
+        z_soil=z_soil,
+        dmpv=rng.choice([0.0, 25.0, 50.0, 100.0], n),
+        lmpv=lmpv,
+        theta_ac=rng.uniform(0.05, 0.2, n),
+        theta_ufc=rng.uniform(0.08, 0.25, n),
+        theta_pwp=rng.uniform(0.05, 0.3, n),
+        ks=rng.uniform(0.5, 50, n),
+        kf=np.full(n, 2500.0),
+        sealing=np.where(lu == 0, rng.uniform(0.2, 0.8, n), 0.0),
+        S_dep_tot=np.zeros(n),
+    )
+    th_sat = p["theta_ac"] + p["theta_ufc"] + p["theta_pwp"]
+    p["theta_rz0"] = p["theta_pwp"] + rng.uniform(0.1, 0.95, n) * (th_sat - p["theta_pwp"])
+    p["theta_ss0"] = p["theta_pwp"] + rng.uniform(0.1, 0.95, n) * (th_sat - p["theta_pwp"])
+    # a few tie / edge cells
+    p["theta_rz0"][0] = p["theta_pwp"][0] + p["theta_ufc"][0]  # exactly field capacity
+    p["dmpv"][1] = 0.0
+    p["lmpv"][2] = 0.0
+    return {k: v.reshape(nx, ny) for k, v in p.items()}
+
+
+def uniform_params(nx, ny):
+    """benchmarks/SVAT_benchmark.py:92-103,117-121"""
+    f = lambda v: np.full((nx, ny), v)  # noqa: E731
+    return dict(
+        lu_id=f(8), z_soil=f(2000.0), dmpv=f(50.0), lmpv=f(50.0), theta_ac=f(0.1), theta_ufc=f(0.1),
+        theta_pwp=f(0.2), ks=f(5.0), kf=f(2500.0), sealing=f(0.0), S_dep_tot=f(0.0),
+        theta_rz0=f(0.3), theta_ss0=f(0.3),
+    )
+
+
+def make_model(roger, params, forcing, ndays):
+    from roger import roger_routine
+    from roger.models.svat import SVATSetup
+    from roger.core.operators import numpy as npx, update, at
+
+    nx, ny = params["lu_id"].shape
+    F = forcing
+
+    class GoldenSVAT(SVATSetup):
+        @roger_routine
+        def set_settings(self, state):
+            s = state.settings
+            s.identifier = "GoldenSVAT"
+            s.nx, s.ny = nx, ny
+            s.runlen = 24 * 60 * 60 * ndays
+            s.nitt_forc = len(F["PREC"])
+            s.dx = 1
+            s.dy = 1
+            s.x_origin = 0.0
+            s.y_origin = 0.0
+            s.time_origin = "2018-01-01 00:00:00"
+            s.enable_groundwater_boundary = False
+            s.enable_macropore_lower_boundary_condition = False
+            s.enable_adaptive_time_stepping = True
+
+        @roger_routine
+        def set_parameters_setup(self, state):
+            vs = state.variables
+            for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf",
+                      "sealing", "S_dep_tot"):
+                setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], params[k]))
+
+        @roger_routine
+        def set_initial_conditions(self, state):
+            vs = state.variables
+            vs.theta_rz = update(vs.theta_rz, at[2:-2, 2:-2, : vs.taup1], params["theta_rz0"][:, :, None])
+            vs.theta_ss = update(vs.theta_ss, at[2:-2, 2:-2, : vs.taup1], params["theta_ss0"][:, :, None])
+
+        @roger_routine
+        def set_forcing_setup(self, state):
+            vs = state.variables
+            for k in ("PREC", "TA", "PET"):
+                setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
+
+        @roger_routine
+        def set_forcing(self, state):
+            # same slicing as benchmarks/SVAT_benchmark.py:151-171, data held in memory
+            vs = state.variables
+            if vs.time % (24 * 60 * 60) == 0:
+                vs.itt_day = 0
+                vs.year = update(vs.year, at[1], F["YEAR"][vs.itt_forc])
+                vs.month = update(vs.month, at[1], F["MONTH"][vs.itt_forc])
+                vs.doy = update(vs.doy, at[1], F["DOY"][vs.itt_forc])
+                sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
+                vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
+                vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
+                vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
+                vs.itt_forc = vs.itt_forc + 6 * 24
+
+    return GoldenSVAT()
+
+
+# ---------------------------------------------------------------------------
+# recording
+# ---------------------------------------------------------------------------
+def plane_names():
+    """(plane name, reference variable, level) for every oracle plane."""
+    import ctypes
+
+    lib = ctypes.CDLL(os.path.join(REPO, "oracle", "libsvat_oracle.so"))
+    lib.oc_plane_name.restype = ctypes.c_char_p
+    out = []
+    for i in range(lib.oc_nplanes()):
+        nm = lib.oc_plane_name(i).decode()
+        if nm.endswith("_m1"):
+            out.append((nm, nm[:-3], 0))
+        else:
+            out.append((nm, nm, 1))
+    return out
+
+
+SCALARS = ("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")
+SCALARS2 = ("event_id", "year", "month", "doy")
+
+
+def snapshot(vs, planes):
+    """Interior (ghost-free), flattened copy of every oracle plane -> (nplanes, n) float64."""
+    cols = []
+    for _, var, lvl in planes:
+        a = np.asarray(getattr(vs, var))
+        a = a[2:-2, 2:-2, lvl] if a.ndim == 3 else a[2:-2, 2:-2]
+        cols.append(np.asarray(a, dtype=np.float64).ravel())
+    return np.stack(cols)
+
+
+def scalars(vs):
+    row = [float(np.asarray(getattr(vs, k))) for k in SCALARS]
+    for k in SCALARS2:
+        a = np.asarray(getattr(vs, k))
+        row += [float(a[0]), float(a[1])]
+    return np.array(row)
+
+
+ROUTINES = (
+    ("adaptive_time_stepping", "adaptive_time_stepping"),
+    ("interception", "calculate_interception"),
+    ("evapotranspiration", "calculate_evapotranspiration"),
+    ("snow", "calculate_snow"),
+    ("infiltration", "calculate_infiltration"),
+    ("subsurface_runoff", "calculate_subsurface_runoff"),
+    ("capillary_rise", "calculate_capillary_rise"),
+    ("soil", "calculate_soil"),  # last of the four storage routines
+    ("numerics", "calc_storage"),
+)
+
+
+def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine_steps, outdir):
+    import importlib
+
+    model = make_model(roger, params, forcing, ndays)
+    planes = plane_names()
+    rec = {}
+    routine_log = {}
+    state_holder = {}
+
+    # wrap the per-routine entry points so that the state after each one can be recorded
+    originals = []
+    for mod_name, fn_name in ROUTINES:
+        mod = importlib.import_module(f"roger.core.{mod_name}")
+        orig = getattr(mod, fn_name)
+
+        def make_wrapper(orig, tag):
+            def wrapper(state, *a, **k):
+                out = orig(state, *a, **k)
+                step_no = state_holder.get("step")
+                if step_no in routine_steps:
+                    routine_log[f"r{step_no:05d}_{tag}"] = snapshot(state.variables, planes)
+                    routine_log[f"r{step_no:05d}_{tag}_scal"] = scalars(state.variables)
+                return out
+
+            return wrapper
+
+        setattr(mod, fn_name, make_wrapper(orig, fn_name))
+        originals.append((mod, fn_name, orig))
+
+    # capture the raw user parameters before the derived-parameter kernels run
+    from roger.core import soil as _soil
+
+    orig_calc_params = _soil.calculate_parameters
+
+    def calc_params_wrapper(state):
+        rec["pre_params"] = snapshot(state.variables, planes)
+        return orig_calc_params(state)
+
+    _soil.calculate_parameters = calc_params_wrapper
+    from roger.core import surface as _surface
+
+    orig_surf_params = _surface.calculate_parameters
+
+    def surf_params_wrapper(state):
+        rec["pre_surface"] = snapshot(state.variables, planes)
+        return orig_surf_params(state)
+
+    _surface.calculate_parameters = surf_params_wrapper
+    orig_calc_ic = _soil.calculate_initial_conditions
+
+    def calc_ic_wrapper(state):
+        # state after set_initial_conditions + surface.calculate_initial_conditions input
+        rec["pre_ic"] = snapshot(state.variables, planes)
+        return orig_calc_ic(state)
+
+    _soil.calculate_initial_conditions = calc_ic_wrapper
+    try:
+        model.setup()
+        vs = model.state.variables
+        rec["plane_names"] = np.array([p[0] for p in planes])
+        rec["nx_ny"] = np.array(params["lu_id"].shape)
+        rec["state0"] = snapshot(vs, planes)
+        rec["scal0"] = scalars(vs)
+        rec["lut_ilu"] = np.asarray(vs.lut_ilu, dtype=np.float64)
+        rec["lut_gc"] = np.asarray(vs.lut_gc, dtype=np.float64)
+        rec["lut_gcm"] = np.asarray(vs.lut_gcm, dtype=np.float64)
+        rec["lut_rdlu"] = np.asarray(vs.lut_rdlu, dtype=np.float64)
+        for k, v in forcing.items():
+            rec[f"forc_{k}"] = v
+        scal_rows = []
+        snaps = {}
+        step = 0
+        runlen = model.state.settings.runlen
+        while vs.time < runlen and step < max_steps:
+            step += 1
+            state_holder["step"] = step
+            model.step(model.state)
+            scal_rows.append(scalars(vs))
+            if step % snap_every == 0 or step <= 3:
+                snaps[f"s{step:05d}"] = snapshot(vs, planes)
+        snaps[f"s{step:05d}"] = snapshot(vs, planes)
+        rec["scal"] = np.stack(scal_rows)
+        rec["nsteps"] = np.array(step)
+        rec.update(snaps)
+        rec.update(routine_log)
+        path = os.path.join(outdir, f"{name}.npz")
+        np.savez_compressed(path, **rec)
+        dts = rec["scal"][:, SCALARS.index("dt")]
+        print(f"{name}: {step} steps (daily {np.sum(dts == 24)}, hourly {np.sum(dts == 1)}, "
+              f"10min {np.sum(dts < 1)}), {len(snaps)} snapshots, {len(routine_log) // 2} routine snapshots, "
+              f"max dS_num_error {float(np.max(np.asarray(vs.dS_num_error))):.3e} -> {path} "
+              f"({os.path.getsize(path) / 1e6:.2f} MB)")
+    finally:
+        for mod, fn_name, orig in originals:
+            setattr(mod, fn_name, orig)
+        _soil.calculate_parameters = orig_calc_params
+        _surface.calculate_parameters = orig_surf_params
+        _soil.calculate_initial_conditions = orig_calc_ic
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    roger = import_reference()
+    from roger_amd.forcing import combo_forcing, toy_forcing
+
+    cases = {
+        # name: (params, forcing, ndays, max_steps, snap_every, routine_steps)
+        "svat_hetero_combo": (hetero_params(4, 4), combo_forcing(ndays=24), 24, 100000, 40,
+                              set(range(1, 4)) | {30, 31, 60, 61, 200, 201, 400, 401}),
+        "svat_uniform_rain": (uniform_params(3, 2), toy_forcing("rain", ndays=6), 6, 100000, 10, {1, 2, 14, 15}),
+        "svat_hetero_heavyrain": (hetero_params(3, 3, seed=7), toy_forcing("heavyrain", ndays=4), 4, 100000, 25,
+                                  {1, 2, 3, 20, 21}),
+        "svat_hetero_snowrain": (hetero_params(3, 3, seed=11), toy_forcing("snow+rain", ndays=8), 8, 100000, 20,
+                                 {1, 2, 3, 10, 11}),
+    }
+    for name, (params, forcing, ndays, max_steps, snap_every, rsteps) in cases.items():
+        if args.only and args.only != name:
+            continue
+        run_case(roger, name, params, forcing, ndays, max_steps, snap_every, rsteps, args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Helpers shared by the oracle (CPU) and HIP (GPU) parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo")
+
+# Tolerance of the oracle against the reference NumPy backend, and of the HIP path against the
+# oracle.  fp64 throughout; differences come only from libm `pow/log/exp` implementations
+# (NumPy ships SVML AVX512 `pow`, glibc and ROCm's ocml differ from it in the last ulp) and are
+# amplified by catastrophic cancellation in the storage differences (dS*, *_num_error), hence
+# the absolute term.
+RTOL = 1e-10
+ATOL = 1e-10
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    names = [str(x) for x in g["plane_names"]]
+    forcing = {k[5:]: g[k] for k in g.files if k.startswith("forc_")}
+    return g, names, forcing
+
+
+def compare(got, ref, names, rtol=RTOL, atol=ATOL, what=""):
+    """Assert two (nplanes, n) snapshots agree; NaN == NaN, inf == inf."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+        close = np.abs(got - ref) <= atol + rtol * np.abs(ref)
+    ok = same | close
+    if not ok.all():
+        bad = np.argwhere(~ok)
+        lines = []
+        for p, i in bad[:12]:
+            lines.append(f"  {names[p]}[{i}]: got {got[p, i]!r} ref {ref[p, i]!r}")
+        raise AssertionError(f"{what}: {len(bad)} mismatching values\n" + "\n".join(lines))
