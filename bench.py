@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the SVAT hot path: cell-timesteps/s on the SVAT_benchmark grid.
+
+    python bench.py --gpus N --steps K --warmup W [--size NX NY]
+
+One "step" is one model time step (adaptive dt: 24 h / 1 h / 10 min) of every column of the grid:
+the device-side user hooks, the predicate kernels and the fused per-column kernel.  The workload
+is BASELINE.json configs[1]: SVAT_benchmark, nx*ny = 10^6 uniform benchmark parameters
+(benchmarks/SVAT_benchmark.py:92-103,117-121), float64, synthetic forcing (seeded
+roger_amd.forcing.combo_forcing; the reference's forcing.nc is not shipped).  All state is resident
+in HBM before the timed region.  For N > 1 every rank owns one nx*ny slab of a grid split along x
+(weak scaling); the only data-path communication is the 2 x 64-value predicate all-reduce per step.
+
+Prints one JSON line on rank 0 (see the bench contract).  The `roofline` entry prices the fused
+kernel `k_step` at 2779 algorithmic bytes per cell-step against the
+8 TB/s HBM peak, with the kernel duration measured by HIP events on the kernel's stream inside
+the timed region.  The `cpu_baseline` entry times the oracle (a scalar C port of the reference's
+NumPy step, 1 thread) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md section 8(d)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(n_cells, steps, forcing):
+    """Oracle (oracle/svat_oracle.c) on the host: same parameters, same forcing, same steps."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import numpy as np
+
+    import oracle_binding as ob
+    from roger_amd import lookuptables as lut
+    from roger_amd.svat import BENCHMARK_PARAMS
+
+    st = ob.OracleState(n_cells)
+    st.set_luts(lut.ARR_ILU, lut.ARR_GC, lut.ARR_GCM, lut.ARR_RDLU)
+    P = st.planes
+    P["maskCatch"][:] = 1
+    for nm, v in (("ta", 15.0), ("ta_m1", 15.0), ("z_gw", 1000.0), ("z_gw_m1", 1000.0), ("c_int", 1.0), ("c_root", 1.0)):
+        P[nm][:] = v
+    for k, v in BENCHMARK_PARAMS.items():
+        if k not in ("theta_rz", "theta_ss"):
+            P[k][:] = v
+    st.scal.dt, st.scal.dt_secs, st.scal.event_id_counter = 1.0, 3600, 1
+    for k, v in (("year", 1900), ("month", 1), ("doy", 1)):
+        getattr(st.scal, k)[0] = getattr(st.scal, k)[1] = v
+    st.topo()
+    st.params_surface()
+    st.params_soil()
+    for lvl in ("", "_m1"):
+        P["theta_rz" + lvl][:] = BENCHMARK_PARAMS["theta_rz"]
+        P["theta_ss" + lvl][:] = BENCHMARK_PARAMS["theta_ss"]
+    st.initial_conditions()
+    drv = ob.ForcingDriver(forcing)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pd, td, ed, monthly = drv.before_step(st)
+        st.step(pd, td, ed, monthly)
+    dt = time.perf_counter() - t0
+    return n_cells * steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=2, default=(1000, 1000), metavar=("NX", "NY"))
+    ap.add_argument("--params", choices=("uniform", "hetero"), default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=100000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hip backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from roger_amd.distributed import HipPhases, PhasedStepper
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.svat import create_svat, hetero_params
+
+    nx, ny = args.size
+    n_local = nx * ny
+    params = hetero_params(n_local, seed=42 + rank) if args.params == "hetero" else None
+    ctx = create_svat(nx, ny, params=params, device=local_rank)
+    total_steps = args.steps + args.warmup
+    forcing = combo_forcing(ndays=max(30, total_steps // 20 + 5))
+    ctx.set_forcing_series(forcing)
+    stepper = PhasedStepper(HipPhases(ctx, device))
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    stepper.run(args.warmup)
+    s0 = ctx.get_scalars()
+    ctx.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    stepper.run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.timing_summary()
+    ctx.enable_timing(False)
+    s1 = ctx.get_scalars()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if s1.sanity_ok != 1 or s1.itt - s0.itt != args.steps:
+        raise SystemExit(f"bench: step bookkeeping failed (sanity_ok={s1.sanity_ok}, itt {s0.itt}->{s1.itt})")
+
+    if rank == 0:
+        value = world * n_local * args.steps / elapsed
+        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = ALGO_BYTES_PER_CELL_STEP * n_local / k_avg_s / 1e9
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf))
+                if int(rec.get("n_cells", -1)) == n_local:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "cell-timesteps/sec on SVAT_benchmark grid",
+            "value": value,
+            "unit": "cell-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SVAT_benchmark synthetic grid nx*ny={n_local} per GPU ({nx}x{ny}), {args.params} "
+                            "benchmark parameters, combo forcing (seed 42), adaptive dt",
+                "cells_per_gpu": n_local,
+                "simulated_seconds": int(s1.time - s0.time),
+                "decomposition": f"({world},1) along x, predicate all-reduce only",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_step",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * n_local,
+                "avg_kernel_ms": k_avg_s * 1e3,
+                "launches_timed": launches,
+            },
+        }
+        if not args.no_cpu_baseline:
+            cpu_steps = min(args.steps + args.warmup, 60)
+            v, secs = cpu_baseline(args.cpu_cells, cpu_steps, forcing)
+            out["cpu_baseline"] = {
+                "value": v,
+                "unit": "cell-timesteps/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"oracle/svat_oracle.c, {args.cpu_cells} cells x first {cpu_steps} steps of the same "
+                          f"forcing, {secs:.1f} s on one host core",
+            }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

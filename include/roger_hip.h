@@ -1,0 +1,182 @@
+/*
+ * include/roger_hip.h -- C ABI of the MI355X-native ("hip") backend for RoGeR's per-cell
+ * SVAT time step.
+ *
+ * The reference (Hydrology-IFH/roger) has no native code; its "FFI" for this path is the
+ * Python operator surface: `@roger_routine` functions that mutate `state.variables` and
+ * `@roger_kernel` functions that return a `KernelOutput` (roger/routines.py:118,239).  Each
+ * entry point below replaces the body of one such routine; the citation names the reference
+ * routine it stands in for.  All pointers are plain host or device pointers, all sizes are
+ * explicit, no C++ or torch types cross the boundary.  Every call returns 0 on success or a
+ * negative rh_status; `rh_last_error` gives the text.  A context is bound to one HIP device
+ * and one stream and is not thread-safe (the reference driver is single-threaded,
+ * roger/roger.py:523-580).  Calls are asynchronous on the context's stream; `rh_sync` and the
+ * download calls fence (the counterpart of `flush()`, roger/core/operators.py:137-145).
+ */
+#ifndef ROGER_HIP_H
+#define ROGER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_ABI_VERSION 1
+#define RH_SLOTS_PER_DAY 144 /* roger/variables.py:109 "timesteps_day": 6 * 24 */
+
+typedef enum rh_status {
+    RH_OK = 0,
+    RH_ERR_ARG = -1,     /* bad argument (unknown field, size mismatch, null pointer) */
+    RH_ERR_HIP = -2,     /* a HIP runtime call failed */
+    RH_ERR_STATE = -3,   /* call order violated (e.g. step before forcing was set) */
+    RH_ERR_NODEVICE = -4 /* no usable gfx950 device */
+} rh_status;
+
+/* Plane ids: one per (variable, time level); see rh_fields.def. */
+typedef enum rh_plane {
+#define RH_FIELD_1(name) RH_P_##name,
+#define RH_FIELD_2(name) RH_P_##name, RH_P_##name##_m1,
+#define RH_FIELD(name, type, levels) RH_FIELD_##levels(name)
+#include "rh_fields.def"
+#undef RH_FIELD
+#undef RH_FIELD_1
+#undef RH_FIELD_2
+    RH_NPLANES
+} rh_plane;
+
+/* Model settings used on the path (roger/settings.py:52-122), with the reference defaults
+ * filled in by rh_default_config. */
+typedef struct rh_config {
+    int64_t nx, ny;   /* local interior grid of this rank (reference arrays carry +4 ghosts per
+                         axis, roger/variables.py:170-173; the arena stores the interior only) */
+    int32_t device;   /* HIP device ordinal */
+    int32_t reserved;
+    double pi, r_mp, l_sc, sf, ta_fm, rmax, transp_water_stress, atol, rtol;
+    double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
+    double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
+    int64_t end_event, hpi;
+} rh_config;
+
+/* Per-domain scalars of the reference (roger/variables.py:189-330).  event_id/year/month/doy
+ * are [taum1, tau] as in the reference. */
+typedef struct rh_scalars {
+    int64_t itt, time, dt_secs, itt_day, itt_forc, time_event0, event_id_counter;
+    int64_t event_id[2], year[2], month[2], doy[2];
+    double dt;
+    int64_t sanity_ok; /* numerics.sanity_check of the last step (roger/core/numerics.py:728) */
+} rh_scalars;
+
+typedef struct rh_ctx rh_ctx;
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+void rh_default_config(rh_config *cfg);
+/* Replaces RogerState.initialize_variables (roger/state.py:369-374): allocates one device arena
+ * with RH_NPLANES planes of nx*ny cells, zero-filled, then sets the non-zero `initial=` values of
+ * the registry (maskCatch=1, ta=15, z_gw=1000, c_int=1, c_root=1; roger/variables.py). */
+int rh_create(const rh_config *cfg, rh_ctx **out);
+void rh_destroy(rh_ctx *ctx);
+const char *rh_last_error(const rh_ctx *ctx); /* ctx may be NULL for rh_create failures */
+int rh_abi_version(void);
+
+/* Use an externally created HIP stream (e.g. torch's current stream) for all launches. */
+int rh_set_stream(rh_ctx *ctx, void *hip_stream);
+int rh_sync(rh_ctx *ctx);
+
+/* ---- field registry ---------------------------------------------------------------------- */
+int rh_num_planes(void);
+const char *rh_plane_name(int plane); /* "<variable>" for tau, "<variable>_m1" for taum1 */
+int rh_plane_is_int(int plane);       /* 1: int32 plane, 0: float64 plane */
+int rh_plane_index(const char *name); /* -1 if unknown */
+int64_t rh_num_cells(const rh_ctx *ctx);
+
+/* Host <-> device copies of one plane (n_cells elements of the plane's type, C order over
+ * (x, y) interior).  Counterpart of assigning / reading `vs.<name>` in a setup script. */
+int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes);
+int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes);
+/* Device address of a plane, for zero-copy wrapping by the host package. */
+void *rh_plane_device_ptr(rh_ctx *ctx, int plane);
+
+int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s);
+int rh_get_scalars(rh_ctx *ctx, rh_scalars *s); /* synchronises */
+
+/* Look-up tables (roger/lookuptables.py; vs.lut_ilu (25,13), vs.lut_gc (25,13), vs.lut_gcm
+ * (25,2), vs.lut_rdlu (25,7)), row-major float64. */
+int rh_set_luts(rh_ctx *ctx, const double *ilu, const double *gc, const double *gcm, const double *rdlu);
+
+/* Forcing of the current day: what `set_forcing` assigns to vs.prec_day / vs.ta_day /
+ * vs.pet_day (benchmarks/SVAT_benchmark.py:151-171).  per_cell == 0: three vectors of 144
+ * values shared by all cells (the broadcast the benchmark performs); per_cell != 0: three
+ * (n_cells, 144) arrays. Host pointers; copied asynchronously. */
+int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day, const double *pet_day,
+                       int per_cell);
+
+/* The whole 10-minute forcing series plus calendar, resident on the device: what
+ * `set_forcing_setup` assigns to vs.PREC / vs.TA / vs.PET / vs.YEAR / vs.MONTH / vs.DOY
+ * (benchmarks/SVAT_benchmark.py:136-149).  With it the per-step user hooks `set_forcing` and
+ * `set_parameters` (SVAT_benchmark.py:105-110,151-171) run on the device (rh_hooks_phase), and
+ * rh_run_steps advances the model without any host synchronisation. */
+int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, const double *pet, const int64_t *year,
+                          const int64_t *month, const int64_t *doy, int64_t nitt_forc);
+
+/* ---- setup-time kernels ------------------------------------------------------------------ */
+int rh_topo(rh_ctx *ctx);               /* surface.calc_topo_kernel, roger/core/surface.py:40-71 */
+int rh_params_surface(rh_ctx *ctx);     /* calc_parameters_surface_kernel, surface.py:74-343 */
+int rh_params_soil(rh_ctx *ctx);        /* soil.calculate_parameters, roger/core/soil.py:143-557,727-739 */
+int rh_initial_conditions(rh_ctx *ctx); /* surface/soil.calculate_initial_conditions, surface.py:398-427, soil.py:742-1010 */
+
+/* ---- one entry point per routine of RogerSetup.step (roger/roger.py:396-457,485) ---------- */
+int rh_adaptive_dt(rh_ctx *ctx);        /* adaptive_time_stepping, core/adaptive_time_stepping.py:22-437 */
+int rh_interception(rh_ctx *ctx);       /* calculate_interception, core/interception.py:347-356 */
+int rh_evapotranspiration(rh_ctx *ctx); /* calculate_evapotranspiration, core/evapotranspiration.py:603-616 */
+int rh_snow(rh_ctx *ctx);               /* calculate_snow, core/snow.py:294-304 */
+int rh_infiltration(rh_ctx *ctx);       /* calculate_infiltration, core/infiltration.py:2148-2193 */
+int rh_subsurface_runoff(rh_ctx *ctx);  /* calculate_subsurface_runoff (SVAT branch), core/subsurface_runoff.py:1473-1479 */
+int rh_capillary_rise(rh_ctx *ctx);     /* calculate_capillary_rise, core/capillary_rise.py:346-358 */
+int rh_storage(rh_ctx *ctx);            /* calculate_surface/root_zone/subsoil/soil + numerics.calc_storage */
+int rh_num_error(rh_ctx *ctx);          /* numerics.sanity_check + calculate_num_error, core/numerics.py:716-1011 */
+int rh_after_timestep(rh_ctx *ctx);     /* after_timestep_kernel, roger/models/svat/svat.py:187-384 */
+
+/* ---- the fused step ------------------------------------------------------------------------
+ * One whole time step in the order of RogerSetup.step, without the user hooks: adaptive dt ->
+ * [monthly surface parameters] -> interception -> evapotranspiration -> snow -> infiltration ->
+ * subsurface runoff -> capillary rise -> storages -> itt/time increment -> sanity/num error ->
+ * after_timestep.  The global predicates (`.any()/.all()` in adaptive_time_stepping.py:38-81,
+ * 192-201 and infiltration.py:2155-2167) are reduced on the device; the scalars never leave it.
+ *
+ * The step is split in three phases so that a multi-GPU host can all-reduce the predicate words
+ * between them (bitwise OR over ranks; see rh_predicate_words):
+ *   phase 1: reduce the start-of-step predicates          -> words[0]
+ *   phase 2: select prec/ta, reduce the event predicates  -> words[1]
+ *   phase 3: scalar bookkeeping + the fused per-cell kernel
+ * rh_svat_step runs the three back to back (single GPU). `monthly` != 0 runs the surface
+ * parameter kernel first, as `set_parameters` does on a month change (svat.py:115-120). */
+int rh_step_phase1(rh_ctx *ctx);
+int rh_step_phase2(rh_ctx *ctx);
+int rh_step_phase3(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-side month-change flag */
+int rh_svat_step(rh_ctx *ctx, int monthly);
+/* Device-side `set_forcing` + `set_parameters` hooks (needs rh_set_forcing_series); runs before
+ * phase 1. */
+int rh_hooks_phase(rh_ctx *ctx);
+/* nsteps whole time steps, hooks included, enqueued back to back on the stream. */
+int rh_run_steps(rh_ctx *ctx, int64_t nsteps);
+/* Device address of the 64-bit predicate words (uint64_t[4]); combine over ranks with OR. */
+void *rh_predicate_words(rh_ctx *ctx);
+/* RCCL has no bitwise reduction: spread predicate word `word` into 64 int32 0/1 values at the
+ * device address `dev_dst64` (then all-reduce them with MAX), and fold 64 such values back.
+ * Stream-ordered, no synchronisation. */
+int rh_predicates_expand(rh_ctx *ctx, int word, int32_t *dev_dst64);
+int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64);
+
+/* HIP-event timing of the fused per-cell kernel.  rh_enable_timing(ctx, 1) starts a new
+ * measurement: every following step records an event pair around the kernel on the context's
+ * stream (no synchronisation).  rh_timing_summary synchronises and returns the summed kernel
+ * time and the number of timed launches since then. */
+int rh_enable_timing(rh_ctx *ctx, int on);
+int rh_timing_summary(rh_ctx *ctx, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROGER_HIP_H */

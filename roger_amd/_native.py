@@ -1,0 +1,242 @@
+"""ctypes binding of libroger_hip.so (the C ABI declared in include/roger_hip.h).
+
+This module is the only place the host package touches the native library.  There is no CPU
+fallback: if the library or a GPU is missing, creating a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libroger_hip.so")
+
+
+class RhConfig(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("device", C.c_int32), ("reserved", C.c_int32)] + [
+        (k, C.c_double) for k in (
+            "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min",
+            "clay_max", "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max",
+            "a_bc", "b_bc")
+    ] + [("end_event", C.c_int64), ("hpi", C.c_int64)]
+
+
+class RhScalars(C.Structure):
+    _fields_ = [
+        ("itt", C.c_int64), ("time", C.c_int64), ("dt_secs", C.c_int64), ("itt_day", C.c_int64),
+        ("itt_forc", C.c_int64), ("time_event0", C.c_int64), ("event_id_counter", C.c_int64),
+        ("event_id", C.c_int64 * 2), ("year", C.c_int64 * 2), ("month", C.c_int64 * 2), ("doy", C.c_int64 * 2),
+        ("dt", C.c_double), ("sanity_ok", C.c_int64),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_ENTRY_POINTS = (
+    "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
+    "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
+    "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase",
+)
+
+
+def load():
+    """Load the shared library and declare every symbol of roger_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} not found: build it with `python -m roger_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    lib.rh_abi_version.restype = i32
+    lib.rh_default_config.argtypes = [C.POINTER(RhConfig)]
+    lib.rh_default_config.restype = None
+    lib.rh_create.argtypes = [C.POINTER(RhConfig), C.POINTER(vp)]
+    lib.rh_destroy.argtypes = [vp]
+    lib.rh_destroy.restype = None
+    lib.rh_last_error.argtypes = [vp]
+    lib.rh_last_error.restype = C.c_char_p
+    lib.rh_set_stream.argtypes = [vp, vp]
+    lib.rh_num_planes.restype = i32
+    lib.rh_plane_name.argtypes = [i32]
+    lib.rh_plane_name.restype = C.c_char_p
+    lib.rh_plane_is_int.argtypes = [i32]
+    lib.rh_plane_index.argtypes = [C.c_char_p]
+    lib.rh_num_cells.argtypes = [vp]
+    lib.rh_num_cells.restype = i64
+    lib.rh_upload.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rh_download.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rh_plane_device_ptr.argtypes = [vp, i32]
+    lib.rh_plane_device_ptr.restype = vp
+    lib.rh_set_scalars.argtypes = [vp, C.POINTER(RhScalars)]
+    lib.rh_get_scalars.argtypes = [vp, C.POINTER(RhScalars)]
+    lib.rh_set_luts.argtypes = [vp, vp, vp, vp, vp]
+    lib.rh_set_forcing_day.argtypes = [vp, vp, vp, vp, i32]
+    for name in _ENTRY_POINTS:
+        getattr(lib, name).argtypes = [vp]
+    lib.rh_step_phase3.argtypes = [vp, i32]
+    lib.rh_svat_step.argtypes = [vp, i32]
+    lib.rh_run_steps.argtypes = [vp, i64]
+    lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
+    lib.rh_predicates_expand.argtypes = [vp, i32, vp]
+    lib.rh_predicates_compress.argtypes = [vp, i32, vp]
+    lib.rh_predicate_words.argtypes = [vp]
+    lib.rh_predicate_words.restype = vp
+    lib.rh_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.rh_enable_timing.argtypes = [vp, i32]
+    _lib = lib
+    return lib
+
+
+DECLARED_SYMBOLS = (
+    "rh_default_config", "rh_create", "rh_destroy", "rh_last_error", "rh_abi_version", "rh_set_stream", "rh_sync",
+    "rh_num_planes", "rh_plane_name", "rh_plane_is_int", "rh_plane_index", "rh_num_cells", "rh_upload",
+    "rh_download", "rh_plane_device_ptr", "rh_set_scalars", "rh_get_scalars", "rh_set_luts", "rh_set_forcing_day",
+    "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
+    "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
+    "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
+    "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress",
+)
+
+
+def plane_table():
+    lib = load()
+    n = lib.rh_num_planes()
+    return [(lib.rh_plane_name(i).decode(), bool(lib.rh_plane_is_int(i))) for i in range(n)]
+
+
+class Context:
+    """One device arena + stream (rh_ctx).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, nx, ny, device=0, **settings):
+        lib = load()
+        cfg = RhConfig()
+        lib.rh_default_config(C.byref(cfg))
+        cfg.nx, cfg.ny, cfg.device = int(nx), int(ny), int(device)
+        for k, v in settings.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(f"unknown setting {k}")
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.rh_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise NativeError(f"rh_create failed ({rc}): {lib.rh_last_error(None).decode()}")
+        self._h = h
+        self._lib = lib
+        self.nx, self.ny, self.n = int(nx), int(ny), int(nx) * int(ny)
+        self.planes = plane_table()
+        self.index = {nm: i for i, (nm, _) in enumerate(self.planes)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self._lib.rh_last_error(self._h).decode()}")
+
+    # -- planes -----------------------------------------------------------------------------
+    def dtype_of(self, name):
+        return np.int32 if self.planes[self.index[name]][1] else np.float64
+
+    def upload(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=self.dtype_of(name)).reshape(-1)
+        if a.size != self.n:
+            raise ValueError(f"{name}: expected {self.n} values, got {a.size}")
+        self._check(self._lib.rh_upload(self._h, self.index[name], a.ctypes.data_as(C.c_void_p), a.nbytes),
+                    f"rh_upload({name})")
+
+    def download(self, name):
+        out = np.empty(self.n, dtype=self.dtype_of(name))
+        self._check(self._lib.rh_download(self._h, self.index[name], out.ctypes.data_as(C.c_void_p), out.nbytes),
+                    f"rh_download({name})")
+        return out
+
+    def device_ptr(self, name):
+        return self._lib.rh_plane_device_ptr(self._h, self.index[name])
+
+    # -- scalars / tables / forcing -----------------------------------------------------------
+    def set_scalars(self, s):
+        self._check(self._lib.rh_set_scalars(self._h, C.byref(s)), "rh_set_scalars")
+
+    def get_scalars(self):
+        s = RhScalars()
+        self._check(self._lib.rh_get_scalars(self._h, C.byref(s)), "rh_get_scalars")
+        return s
+
+    def set_luts(self, ilu, gc, gcm, rdlu):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (ilu, gc, gcm, rdlu)]
+        for a, shape in zip(arrs, ((25, 13), (25, 13), (25, 2), (25, 7))):
+            if a.shape != shape:
+                raise ValueError(f"look-up table has shape {a.shape}, expected {shape}")
+        self._check(self._lib.rh_set_luts(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), "rh_set_luts")
+
+    def set_forcing_day(self, prec_day, ta_day, pet_day):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (prec_day, ta_day, pet_day)]
+        per_cell = arrs[0].ndim > 1
+        want = (self.n, 144) if per_cell else (144,)
+        for a in arrs:
+            if a.reshape(want).shape != want:
+                raise ValueError("forcing must be (144,) or (n_cells, 144)")
+        self._check(self._lib.rh_set_forcing_day(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                                 int(per_cell)), "rh_set_forcing_day")
+
+    def set_forcing_series(self, F):
+        """F: dict with PREC, TA, PET (float64) and YEAR, MONTH, DOY (int64) 10-minute vectors."""
+        f = [np.ascontiguousarray(F[k], dtype=np.float64) for k in ("PREC", "TA", "PET")]
+        c = [np.ascontiguousarray(F[k], dtype=np.int64) for k in ("YEAR", "MONTH", "DOY")]
+        n = f[0].size
+        if any(a.size != n for a in f + c):
+            raise ValueError("forcing vectors differ in length")
+        self._check(self._lib.rh_set_forcing_series(self._h, *[a.ctypes.data_as(C.c_void_p) for a in f + c], n),
+                    "rh_set_forcing_series")
+
+    def run_steps(self, nsteps):
+        self._check(self._lib.rh_run_steps(self._h, int(nsteps)), "rh_run_steps")
+
+    # -- routines -----------------------------------------------------------------------------
+    def call(self, entry):
+        self._check(getattr(self._lib, entry)(self._h), entry)
+
+    def step(self, monthly=False):
+        self._check(self._lib.rh_svat_step(self._h, int(bool(monthly))), "rh_svat_step")
+
+    def step_phase3(self, monthly=False):
+        self._check(self._lib.rh_step_phase3(self._h, int(bool(monthly))), "rh_step_phase3")
+
+    def sync(self):
+        self.call("rh_sync")
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.rh_set_stream(self._h, C.c_void_p(stream_handle)), "rh_set_stream")
+
+    def predicates_expand(self, word, dev_ptr):
+        self._check(self._lib.rh_predicates_expand(self._h, int(word), C.c_void_p(dev_ptr)), "rh_predicates_expand")
+
+    def predicates_compress(self, word, dev_ptr):
+        self._check(self._lib.rh_predicates_compress(self._h, int(word), C.c_void_p(dev_ptr)),
+                    "rh_predicates_compress")
+
+    def predicate_words_ptr(self):
+        return self._lib.rh_predicate_words(self._h)
+
+    def enable_timing(self, on=True):
+        self._check(self._lib.rh_enable_timing(self._h, int(on)), "rh_enable_timing")
+
+    def last_step_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.rh_last_step_kernel_ms(self._h, C.byref(ms)), "rh_timing_summary")
+        return float(ms.value)

@@ -1,0 +1,91 @@
+// rh_col.h -- one soil column ("cell") in registers, and the SoA device arena it is loaded from.
+//
+// Data layout in HBM: one arena per GPU, RH_NPLANES planes, each plane n_cells contiguous
+// elements (float64 or int32) in C order over the rank's interior (x, y) grid, plane p at
+// base + p * stride (stride a multiple of 256 B).  Lane l of a wavefront owns cell
+// blockIdx*256 + l, so every plane access is one fully coalesced 512-byte (float64) request per
+// wave-instruction; nothing is re-read within a kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "roger_hip.h"
+
+#define RH_DEV __device__ __forceinline__
+
+struct Col {
+#define RH_DECL_F64_1(name) double name;
+#define RH_DECL_F64_2(name) double name, name##_m1;
+#define RH_DECL_I32_1(name) int name;
+#define RH_DECL_I32_2(name) int name, name##_m1;
+#define RH_FIELD(name, type, levels) RH_DECL_##type##_##levels(name)
+#include "rh_fields.def"
+#undef RH_FIELD
+#undef RH_DECL_F64_1
+#undef RH_DECL_F64_2
+#undef RH_DECL_I32_1
+#undef RH_DECL_I32_2
+};
+
+struct Arena {
+    char *base;
+    size_t stride;  // bytes between planes
+    int64_t n;      // cells
+};
+
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, double &dst) {
+    dst = reinterpret_cast<const double *>(a.base + (size_t)plane * a.stride)[i];
+}
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, int &dst) {
+    dst = reinterpret_cast<const int *>(a.base + (size_t)plane * a.stride)[i];
+}
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, double v) {
+    reinterpret_cast<double *>(a.base + (size_t)plane * a.stride)[i] = v;
+}
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, int v) {
+    reinterpret_cast<int *>(a.base + (size_t)plane * a.stride)[i] = v;
+}
+
+// Settings that the kernels read (subset of rh_config, device copy).
+struct Consts {
+    double pi, r_mp, l_sc, sf, ta_fm, rmax, transp_water_stress, atol, rtol;
+    double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
+    double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
+    int64_t end_event, hpi;
+};
+
+// Look-up tables, row-major (roger/lookuptables.py).
+struct Luts {
+    double ilu[25 * 13];
+    double gc[25 * 13];
+    double gcm[25 * 2];
+    double rdlu[25 * 7];
+};
+
+// Per-step uniform values produced on the device by the scalar kernels and consumed by the
+// per-cell kernels (never round-trips to the host).
+struct StepCtx {
+    double dt;
+    double agg[9];        // shared-forcing aggregates: {prec, ta, pet} x {daily, hourly, 10 min}
+    int64_t month_tau;
+    int sel_daily, sel_hourly, sel_10min;  // prec/ta selection, adaptive_time_stepping.py:128-189
+    int sel_p;                             // the one that wins (applied last): -1 none, 0 daily, 1 hourly, 2 10 min
+    double prec_sel, ta_sel;               // its values when the forcing is shared by all columns
+    int sel_w;                             // pet/ta selection of cond6..11: -1 none, 0 daily, 1 hourly, 2 10 min
+    double pet_sel_w, ta_sel_w;            // its values when the forcing is shared
+    int cond1, cond2, cond3, cond4, cond5; // calculate_infiltration, infiltration.py:2155-2167
+    int cond_time;
+    int64_t dt_secs_prelim;
+    int64_t itt_day;
+};
+
+// predicate bit positions, word 0 (start of step) and word 1 (after prec/ta selection)
+enum {
+    PB_SWE_NOT_LE0 = 0, PB_SWE_GT0, PB_SWETOP_NOT_LE0, PB_SWETOP_GT0, PB_P_NOT_LE0, PB_P_GT0, PB_P_GT_HPI,
+    PB_P_NOT_LE_HPI, PB_TA_NOT_GT, PB_TA_GT, PB_PGT0_TALE, PB_NOT_PLE0_TALE
+};
+enum {
+    PC_RAIN = 0, PC_SNOWMELT, PC_PREC_NOT_LE0, PC_NOT_PGT0_TALE, PC_SWEM1_GT0, PC_SWE_NOT_LE0, PC_P_EQ0, PC_PM1_NE0,
+    PC_P_NE0, PC_PM1_EQ0
+};

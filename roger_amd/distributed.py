@@ -1,0 +1,115 @@
+"""Domain decomposition and the per-step predicate exchange for multi-GPU runs.
+
+Decomposition API follows the reference (roger/distributed.py:121-187): `num_proc = (px, py)`,
+ranks laid out x-fastest, even divisibility required, chunk slices with or without the 2-cell
+overlap.  On this path columns never read their neighbours, so no halo is exchanged; what the
+reference does per step -- gather 18 fields to rank 0, decide dt there, scatter back
+(adaptive_time_stepping_dist_safe.py:6-26) -- is replaced by two all-reduces of 64 predicate
+bits (as 64 int32, MAX) between the three phases of the native step.
+"""
+
+
+def validate_decomposition(nx, ny, num_proc, comm_size):
+    """roger/distributed.py:121-138"""
+    px, py = num_proc
+    if px * py != comm_size:
+        raise RuntimeError(f"number of processes ({px * py}) does not match size of communicator ({comm_size})")
+    if nx % px:
+        raise ValueError("processes do not divide domain evenly in x-direction")
+    if ny % py:
+        raise ValueError("processes do not divide domain evenly in y-direction")
+
+
+def get_chunk_size(nx, ny, num_proc):
+    return (nx // num_proc[0], ny // num_proc[1])
+
+
+def proc_rank_to_index(rank, num_proc):
+    return (rank % num_proc[0], rank // num_proc[0])
+
+
+def proc_index_to_rank(ix, iy, num_proc):
+    return ix + iy * num_proc[0]
+
+
+def get_chunk_slices(nx, ny, num_proc, rank, include_overlap=False):
+    """(global_slice, local_slice) over the (x, y) dims of a ghosted array; roger/distributed.py:153-187."""
+    px, py = proc_rank_to_index(rank, num_proc)
+    nxl, nyl = get_chunk_size(nx, ny, num_proc)
+    if include_overlap:
+        sxl = 0 if px == 0 else 2
+        sxu = nxl + 4 if (px + 1) == num_proc[0] else nxl + 2
+        syl = 0 if py == 0 else 2
+        syu = nyl + 4 if (py + 1) == num_proc[1] else nyl + 2
+    else:
+        sxl = syl = 0
+        sxu, syu = nxl, nyl
+    return ((slice(sxl + px * nxl, sxu + px * nxl), slice(syl + py * nyl, syu + py * nyl)),
+            (slice(sxl, sxu), slice(syl, syu)))
+
+
+class PhasedStepper:
+    """Runs whole time steps of a backend that exposes the three-phase step, all-reducing the two
+    predicate words over `group` between the phases.
+
+    `backend` needs: hooks_phase(), phase1(), phase2(), phase3(), predicate_buffer(word) -> a
+    torch tensor of 64 int32 holding 0/1, and load_predicates(word, tensor).  The HIP backend
+    (HipPhases below) and the CPU test double used by the gloo tests both provide them.
+    """
+
+    def __init__(self, backend, group=None):
+        self.backend = backend
+        self.group = group
+
+    def _exchange(self, word):
+        import torch.distributed as dist
+
+        buf = self.backend.predicate_buffer(word)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+        self.backend.load_predicates(word, buf)
+
+    def step(self):
+        b = self.backend
+        b.hooks_phase()
+        b.phase1()
+        self._exchange(0)
+        b.phase2()
+        self._exchange(1)
+        b.phase3()
+
+    def run(self, nsteps):
+        for _ in range(nsteps):
+            self.step()
+
+
+class HipPhases:
+    """Adapter of a `_native.Context` to PhasedStepper; the exchange buffers are torch tensors on
+    the context's device and all launches go to torch's current stream so that the RCCL
+    all-reduce is stream-ordered with the kernels."""
+
+    def __init__(self, ctx, device):
+        import torch
+
+        self.ctx = ctx
+        self.buf = [torch.zeros(64, dtype=torch.int32, device=device) for _ in range(2)]
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def hooks_phase(self):
+        self.ctx.call("rh_hooks_phase")
+
+    def phase1(self):
+        self.ctx.call("rh_step_phase1")
+
+    def phase2(self):
+        self.ctx.call("rh_step_phase2")
+
+    def phase3(self):
+        self.ctx.step_phase3(-1)
+
+    def predicate_buffer(self, word):
+        self.ctx.predicates_expand(word, self.buf[word].data_ptr())
+        return self.buf[word]
+
+    def load_predicates(self, word, tensor):
+        self.ctx.predicates_compress(word, tensor.data_ptr())

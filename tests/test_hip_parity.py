@@ -1,0 +1,261 @@
+"""HIP path (through the C ABI) against the golden vectors of the reference NumPy backend and
+against the oracle.  Needs a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from golden_util import ATOL, CASES, RTOL, compare, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from roger_amd import _native as N
+
+    N.load()
+    return N
+
+
+def _ctx(native, g, names, key="state0", scal_key="scal0"):
+    import hip_util as H
+
+    nx, ny = (int(v) for v in g["nx_ny"])
+    ctx = native.Context(nx, ny)
+    H.upload_snapshot(ctx, g[key], names)
+    ctx.set_scalars(H.scalars_from_row(g[scal_key]))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    return ctx
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_trajectory_golden(native, case):
+    """Fused rh_svat_step reproduces the reference trajectory (all planes at the stored steps,
+    the integer scalars exactly at every step)."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    ctx = _ctx(native, g, names)
+    drv = H.HipForcingDriver(ctx, forcing)
+    nsteps = int(g["nsteps"])
+    checked = 0
+    for step in range(1, nsteps + 1):
+        monthly = drv.before_step()
+        ctx.step(monthly)
+        s = ctx.get_scalars()
+        np.testing.assert_array_equal(H.scalars_to_row(s), g["scal"][step - 1], err_msg=f"{case} scalars step {step}")
+        assert s.sanity_ok == 1
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}")
+            checked += 1
+    assert checked >= 3
+    ctx.close()
+
+
+ROUTINE_ENTRY = {
+    "calculate_interception": ("rh_interception",),
+    "calculate_evapotranspiration": ("rh_evapotranspiration",),
+    "calculate_snow": ("rh_snow",),
+    "calculate_infiltration": ("rh_infiltration",),
+    "calculate_subsurface_runoff": ("rh_subsurface_runoff",),
+    "calculate_capillary_rise": ("rh_capillary_rise",),
+    "calculate_soil": ("rh_storage",),
+}
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_per_routine_golden(native, case):
+    """One entry point per reference routine: state before the routine in, state after it out."""
+    import hip_util as H
+
+    g, names, _ = load_case(case)
+    order = ["adaptive_time_stepping", "calculate_interception", "calculate_evapotranspiration", "calculate_snow",
+             "calculate_infiltration", "calculate_subsurface_runoff", "calculate_capillary_rise", "calculate_soil"]
+    steps = sorted({int(k[1:6]) for k in g.files if k.startswith("r") and k.endswith("_calc_storage")})
+    n = 0
+    for step in steps:
+        for prev, cur in zip(order[:-1], order[1:]):
+            kp = f"r{step:05d}_{prev}"
+            ctx = _ctx(native, g, names, key=kp, scal_key=kp + "_scal")
+            for entry in ROUTINE_ENTRY[cur]:
+                ctx.call(entry)
+            ref = g[f"r{step:05d}_calc_storage"] if cur == "calculate_soil" else g[f"r{step:05d}_{cur}"]
+            compare(H.download_snapshot(ctx, names), ref, names, what=f"{case} step {step} {cur}")
+            ctx.close()
+            n += 1
+    assert n >= 7
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_setup_kernels_golden(native, case):
+    import hip_util as H
+
+    g, names, _ = load_case(case)
+    ctx = _ctx(native, g, names, key="pre_surface")
+    ctx.call("rh_topo")
+    ctx.call("rh_params_surface")
+    compare(H.download_snapshot(ctx, names), g["pre_params"], names, what=f"{case} surface params")
+    ctx.close()
+    ctx = _ctx(native, g, names, key="pre_params")
+    ctx.call("rh_params_soil")
+    got, ref = H.download_snapshot(ctx, names), g["pre_ic"]
+    for nm in ("theta_rz", "theta_rz_m1", "theta_ss", "theta_ss_m1", "S_sur", "S_sur_m1"):
+        got[names.index(nm)] = ref[names.index(nm)]
+    compare(got, ref, names, what=f"{case} soil params")
+    ctx.close()
+    ctx = _ctx(native, g, names, key="pre_ic")
+    ctx.call("rh_initial_conditions")
+    compare(H.download_snapshot(ctx, names), g["state0"], names, what=f"{case} initial conditions")
+    ctx.close()
+
+
+def _oracle_setup(ob, nx, ny, seed, luts):
+    """Heterogeneous start state built with the oracle's setup kernels (same recipe as the
+    golden generator's hetero_params)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import hetero_params
+
+    p = hetero_params(nx, ny, seed=seed)
+    st = ob.OracleState(nx * ny)
+    st.set_luts(*luts)
+    P = st.planes
+    P["maskCatch"][:] = 1
+    for nm in ("ta", "ta_m1"):
+        P[nm][:] = 15.0
+    for nm in ("z_gw", "z_gw_m1"):
+        P[nm][:] = 1000.0
+    P["c_int"][:] = 1.0
+    P["c_root"][:] = 1.0
+    for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf", "sealing", "S_dep_tot"):
+        P[k][:] = p[k].ravel().astype(P[k].dtype)
+    st.scal.dt = 1.0
+    st.scal.dt_secs = 3600
+    st.scal.event_id_counter = 1
+    for k in ("year", "month", "doy"):
+        getattr(st.scal, k)[0] = getattr(st.scal, k)[1] = 1 if k != "year" else 1900
+    st.topo()
+    st.params_surface()
+    st.params_soil()
+    for lvl in ("", "_m1"):
+        P["theta_rz" + lvl][:] = p["theta_rz0"].ravel()
+        P["theta_ss" + lvl][:] = p["theta_ss0"].ravel()
+    st.initial_conditions()
+    return st
+
+
+@pytest.mark.parametrize("per_cell", [False, True])
+def test_vs_oracle_hetero_4096(native, oracle, per_cell):
+    """64x64 heterogeneous columns, 12 days of the combo forcing (all step classes): the HIP path
+    tracks the oracle on every plane; also with the forcing handed over per cell."""
+    import hip_util as H
+    from roger_amd.forcing import combo_forcing
+
+    g, names, _ = load_case("svat_hetero_combo")
+    luts = (g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    nx = ny = 64
+    st = _oracle_setup(oracle, nx, ny, 123, luts)
+    onames = st.names
+    ctx = native.Context(nx, ny)
+    H.upload_snapshot(ctx, st.snapshot(), onames)
+    ctx.set_scalars(H.scalars_from_row(st.scalars_row()))
+    ctx.set_luts(*luts)
+    F = combo_forcing(ndays=12)
+    odrv = oracle.ForcingDriver(F)
+    hdrv = H.HipForcingDriver(ctx, F, per_cell=per_cell)
+    step = 0
+    while st.scal.time < 12 * 86400:
+        step += 1
+        pd, td, ed, monthly = odrv.before_step(st)
+        st.step(pd, td, ed, monthly)
+        m2 = hdrv.before_step()
+        assert m2 == monthly
+        ctx.step(m2)
+        if step % 25 == 0 or step < 3:
+            np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
+            compare(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"step {step}")
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
+    compare(H.download_snapshot(ctx, onames), st.snapshot(), onames, what="final")
+    assert step > 100
+    ctx.close()
+
+
+def test_full_size_properties(native, oracle):
+    """BASELINE config 2 size (nx*ny = 10^6, uniform benchmark parameters): size-independent
+    properties -- every column equals the single-column oracle run bit-for-tolerance, the mass
+    balance closes, the sanity flag holds."""
+    import hip_util as H
+    from roger_amd.forcing import toy_forcing
+
+    g, names, _ = load_case("svat_uniform_rain")
+    luts = (g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    # oracle: the 6-cell uniform golden start state, one column is enough
+    st = oracle.OracleState(6)
+    st.load_snapshot(g["state0"], names)
+    st.load_scalars(g["scal0"])
+    st.set_luts(*luts)
+    nx = ny = 1000
+    ctx = native.Context(nx, ny)
+    for row, nm in zip(g["state0"], names):
+        ctx.upload(nm, np.full(nx * ny, row[0]))
+    ctx.set_scalars(H.scalars_from_row(g["scal0"]))
+    ctx.set_luts(*luts)
+    F = toy_forcing("rain", ndays=3)
+    odrv = oracle.ForcingDriver(F)
+    hdrv = H.HipForcingDriver(ctx, F)
+    for step in range(30):
+        pd, td, ed, monthly = odrv.before_step(st)
+        st.step(pd, td, ed, monthly)
+        ctx.step(hdrv.before_step())
+    s = ctx.get_scalars()
+    assert s.sanity_ok == 1
+    np.testing.assert_array_equal(H.scalars_to_row(s), st.scalars_row())
+    ref = st.snapshot()
+    for nm in ("S", "S_rz", "S_ss", "theta_rz", "theta_ss", "z0", "q_ss", "aet", "inf_mat_rz", "z_wf", "dS_num_error"):
+        col = ctx.download(nm)
+        assert col.min() == col.max(), nm  # identical inputs -> identical columns
+        r = ref[names.index(nm)][0]
+        assert abs(col[0] - r) <= ATOL + RTOL * abs(r), (nm, col[0], r)
+    assert ctx.download("dS_num_error").max() < 1e-9
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "svat_hetero_heavyrain"])
+def test_device_hooks_golden(native, case):
+    """rh_run_steps: forcing series resident on the device, `set_forcing`/`set_parameters` hooks
+    and the month-change decision taken on the device, no host round trip per step."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_series(forcing)
+    nsteps = int(g["nsteps"])
+    done = 0
+    for step in sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit()):
+        ctx.run_steps(step - done)
+        done = step
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][step - 1])
+        compare(H.download_snapshot(ctx, names), g[f"s{step:05d}"], names, what=f"{case} step {step}")
+    assert done == nsteps
+    ctx.close()
+
+
+def test_phased_stepper_single_rank(native):
+    """The multi-GPU orchestration (expand -> all-reduce -> compress between the phases) with one
+    rank equals rh_run_steps."""
+    import torch
+
+    import hip_util as H
+    from roger_amd.distributed import HipPhases, PhasedStepper
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    a, b = _ctx(native, g, names), _ctx(native, g, names)
+    a.set_forcing_series(forcing)
+    b.set_forcing_series(forcing)
+    a.run_steps(120)
+    PhasedStepper(HipPhases(b, torch.device("cuda", 0))).run(120)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(H.scalars_to_row(a.get_scalars()), H.scalars_to_row(b.get_scalars()))
+    np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(b, names))
+    a.close()
+    b.close()
