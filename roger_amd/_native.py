@@ -51,6 +51,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NativeError(
             f"{LIB_PATH} not found: build it with `python -m roger_amd.build` (there is no CPU fallback)")
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64).  Two HIP runtimes in one process do
+    # not work ("No HIP GPUs are available" from whichever initialises second), so when torch is
+    # installed let it load its copy first; libroger_hip.so then binds to the same one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     lib.rh_abi_version.restype = i32
@@ -215,7 +222,8 @@ class Context:
         self._check(self._lib.rh_svat_step(self._h, int(bool(monthly))), "rh_svat_step")
 
     def step_phase3(self, monthly=False):
-        self._check(self._lib.rh_step_phase3(self._h, int(bool(monthly))), "rh_step_phase3")
+        # monthly: False/True, or -1 to use the month-change flag computed on the device
+        self._check(self._lib.rh_step_phase3(self._h, int(monthly)), "rh_step_phase3")
 
     def sync(self):
         self.call("rh_sync")
@@ -236,7 +244,9 @@ class Context:
     def enable_timing(self, on=True):
         self._check(self._lib.rh_enable_timing(self._h, int(on)), "rh_enable_timing")
 
-    def last_step_kernel_ms(self):
-        ms = C.c_float()
-        self._check(self._lib.rh_last_step_kernel_ms(self._h, C.byref(ms)), "rh_timing_summary")
+    def timing_summary(self):
+        """(total kernel ms, launches) of the fused kernel since enable_timing(True)."""
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._lib.rh_timing_summary(self._h, C.byref(ms), C.byref(cnt)), "rh_timing_summary")
+        return float(ms.value), int(cnt.value)
         return float(ms.value)

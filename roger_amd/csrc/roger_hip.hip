@@ -69,9 +69,16 @@ static std::string g_create_err;
 // ---------------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------------
+// OR a wavefront's predicate bits into a global word.  The word only ever gains bits during a
+// kernel, so a wave whose bits are already present skips the atomic: after the first few waves
+// nobody touches the word any more (one address sustains only ~90 atomics/us chip-wide).  The
+// pre-check may read a stale (smaller) value, which costs an extra atomic, never a lost bit.
 RH_DEV void wave_or_to(unsigned long long *word, unsigned long long bits) {
     for (int off = 32; off; off >>= 1) bits |= __shfl_xor(bits, off);
-    if ((threadIdx.x & 63) == 0 && bits) atomicOr(word, bits);
+    if ((threadIdx.x & 63) == 0 && bits) {
+        const unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bits & ~seen) atomicOr(word, bits);
+    }
 }
 #define BIT(b) (1ull << (b))
 RH_DEV bool bit(unsigned long long w, int b) { return (w >> b) & 1ull; }
@@ -184,9 +191,39 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
     wave_or_to(&D->words[0], b);
 }
 
-// one workgroup; thread 0 does the flag logic, thread 1 the shared-forcing aggregates
-__global__ void k_agg(DevState *D) {
-    if (threadIdx.x == 0) {
+// Shared forcing: the nine aggregates of the day's 144-slot series in numpy's summation order,
+// computed by one workgroup from LDS.  np.sum over 144 contiguous float64 is
+// 0 + (half(0..71) + half(72..143)), each half = ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) with
+// r_j = a[j] + a[j+8] + ... + a[j+64] accumulated in that order (numpy pairwise_sum, n <= 128).
+// Lane j of a 16-lane group owns one r_j; six groups = six sums.
+RH_DEV double np_tree8(const double *r) { return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])); }
+
+__global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D) {
+    __shared__ double f[3][RH_SLOTS_PER_DAY];   // prec, ta, pet of the day
+    __shared__ double part[6][16];
+    const int tid = threadIdx.x;
+    const bool shared_forcing = !D->per_cell;
+    const int64_t itd = D->S.itt_day;
+    if (shared_forcing && tid < RH_SLOTS_PER_DAY)
+        for (int k = 0; k < 3; ++k) f[k][tid] = D->forc[k][tid];
+    __syncthreads();
+    if (shared_forcing && tid < 96) {
+        const int sum_id = tid >> 4, lane = tid & 15, half = lane >> 3, j = lane & 7;
+        const int var = sum_id % 3;          // 0 prec, 1 ta, 2 pet
+        const bool hourly = sum_id >= 3;     // sums 0..2 daily, 3..5 hourly window
+        double r = 0.0;
+        for (int q = 0; q < 9; ++q) {
+            const int k = half * 72 + j + 8 * q;
+            double v = f[var][k];
+            const bool in = !hourly || ((k >= itd) && (k < itd + 6));
+            if (var == 1) v = (in && !isnan(v)) ? v : 0.0;  // nanmean: NaN (and masked) slots count as 0
+            else v = in ? v : 0.0;
+            r = (q == 0) ? v : r + v;
+        }
+        part[sum_id][lane] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
         const unsigned long long w = D->words[0];
         const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
         const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
@@ -210,16 +247,32 @@ __global__ void k_agg(DevState *D) {
         if (X.sel_hourly) dts = 3600;
         if (X.sel_10min) dts = 600;
         X.dt_secs_prelim = dts;
-        X.itt_day = D->S.itt_day;
-    }
-    if (threadIdx.x == 1 && !D->per_cell) forcing_aggregates(D->forc[0], D->forc[1], D->forc[2], D->S.itt_day, D->X.agg);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        StepCtx &X = D->X;
+        X.itt_day = itd;
         X.sel_p = X.sel_10min ? 2 : (X.sel_hourly ? 1 : (X.sel_daily ? 0 : -1));
-        if (X.sel_p >= 0 && !D->per_cell) {
-            X.prec_sel = X.agg[3 * X.sel_p];
-            X.ta_sel = X.agg[3 * X.sel_p + 1];
+        if (shared_forcing) {
+            double s[6];
+            for (int q = 0; q < 6; ++q) s[q] = 0.0 + (np_tree8(&part[q][0]) + np_tree8(&part[q][8]));
+            int cnt_d = 0, cnt_h = 0;
+            for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) {
+                const bool ok = !isnan(f[1][k]);
+                cnt_d += ok;
+                cnt_h += ok && (k >= itd) && (k < itd + 6);
+            }
+            X.agg[0] = s[0];
+            X.agg[1] = s[1] / (double)cnt_d;
+            X.agg[2] = s[2];
+            X.agg[3] = s[3];
+            X.agg[4] = s[4] / (double)cnt_h;
+            X.agg[5] = s[5];
+            int64_t k = itd < 0 ? itd + RH_SLOTS_PER_DAY : itd;
+            k = k > RH_SLOTS_PER_DAY - 1 ? RH_SLOTS_PER_DAY - 1 : k;
+            X.agg[6] = f[0][k];
+            X.agg[7] = f[1][k];
+            X.agg[8] = f[2][k];
+            if (X.sel_p >= 0) {
+                X.prec_sel = X.agg[3 * X.sel_p];
+                X.ta_sel = X.agg[3 * X.sel_p + 1];
+            }
         }
     }
 }
@@ -509,6 +562,7 @@ static int fail(rh_ctx *ctx, int code, const std::string &msg) {
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RH_BLOCK - 1) / RH_BLOCK); }
 #define LAUNCH_CELLS(ctx, kern) hipLaunchKernelGGL(kern, dim3(grid_for((ctx)->n)), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev)
 #define LAUNCH_ONE(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, (ctx)->stream, __VA_ARGS__)
+#define LAUNCH_WG(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(RH_BLOCK), 0, (ctx)->stream, __VA_ARGS__)
 #define CHECK_LAUNCH(ctx) HIPCHK(ctx, hipGetLastError())
 
 extern "C" {
@@ -791,7 +845,7 @@ int rh_step_phase1(rh_ctx *ctx) {
 }
 int rh_step_phase2(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
-    LAUNCH_ONE(ctx, k_agg, ctx->dev);
+    LAUNCH_WG(ctx, k_agg, ctx->dev);
     if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
     LAUNCH_CELLS(ctx, k_select);
     CHECK_LAUNCH(ctx);

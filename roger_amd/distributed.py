@@ -64,9 +64,10 @@ class PhasedStepper:
     def _exchange(self, word):
         import torch.distributed as dist
 
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return  # single rank: the local predicate words already are the global ones
         buf = self.backend.predicate_buffer(word)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
         self.backend.load_predicates(word, buf)
 
     def step(self):

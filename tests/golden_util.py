@@ -36,3 +36,18 @@ def compare(got, ref, names, rtol=RTOL, atol=ATOL, what=""):
         for p, i in bad[:12]:
             lines.append(f"  {names[p]}[{i}]: got {got[p, i]!r} ref {ref[p, i]!r}")
         raise AssertionError(f"{what}: {len(bad)} mismatching values\n" + "\n".join(lines))
+
+
+def compare_bulk(got, ref, names, what="", rtol_bulk=RTOL, atol_bulk=ATOL, frac_bulk=0.999, rtol_max=1e-3, atol_max=1e-6):
+    """Stress-set comparison: at least `frac_bulk` of all values within the golden tolerance and
+    every value within (rtol_max, atol_max).  A handful of ill-conditioned columns (subsoil of a
+    few millimetres together with a Brooks-Corey exponent m_bc ~ 15) amplify 1-ulp differences of
+    `pow` by many orders of magnitude over a few hundred steps; they are bounded, not exempted."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+        tight = same | (np.abs(got - ref) <= atol_bulk + rtol_bulk * np.abs(ref))
+    frac = tight.mean()
+    assert frac >= frac_bulk, f"{what}: only {frac:.5f} of the values within rtol={rtol_bulk}"
+    compare(got, ref, names, rtol=rtol_max, atol=atol_max, what=what)

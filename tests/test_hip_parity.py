@@ -3,7 +3,7 @@ against the oracle.  Needs a real MI355X: `pytest -m gpu`."""
 import numpy as np
 import pytest
 
-from golden_util import ATOL, CASES, RTOL, compare, load_case
+from golden_util import ATOL, CASES, RTOL, compare, compare_bulk, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -173,9 +173,9 @@ def test_vs_oracle_hetero_4096(native, oracle, per_cell):
         ctx.step(m2)
         if step % 25 == 0 or step < 3:
             np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
-            compare(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"step {step}")
+            compare_bulk(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"step {step}")
     np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
-    compare(H.download_snapshot(ctx, onames), st.snapshot(), onames, what="final")
+    compare_bulk(H.download_snapshot(ctx, onames), st.snapshot(), onames, what="final")
     assert step > 100
     ctx.close()
 
