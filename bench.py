@@ -104,7 +104,11 @@ def main():
     total_steps = args.steps + args.warmup
     forcing = combo_forcing(ndays=max(30, total_steps // 20 + 5))
     ctx.set_forcing_series(forcing)
-    stepper = PhasedStepper(HipPhases(ctx, device))
+    if world > 1:
+        run = PhasedStepper(HipPhases(ctx, device)).run   # predicate all-reduce between the phases
+    else:
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        run = ctx.run_steps                               # single GPU: no exchange, fewer launches
 
     def fence():
         torch.cuda.synchronize(device)
@@ -112,12 +116,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    stepper.run(args.warmup)
+    run(args.warmup)
     s0 = ctx.get_scalars()
     ctx.enable_timing(True)
     fence()
     t0 = time.perf_counter()
-    stepper.run(args.steps)
+    run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.timing_summary()

@@ -1,15 +1,17 @@
 // roger_hip.hip -- kernels and C ABI of the MI355X-native SVAT backend (see include/roger_hip.h).
 //
 // Kernel inventory (one thread = one soil column, 256-thread workgroups = 4 wavefronts):
-//   k_pred1        start-of-step predicates over swe/swe_top (+ the day's forcing)  -> word 0
-//   k_agg          1 workgroup: step-class flags and the shared-forcing aggregates
-//   k_select       prec/ta selection per column, event + infiltration predicates    -> word 1
-//   k_scalars      1 thread: time-step bookkeeping (dt, event ids, ...), StepCtx for the step
+//   k_pred1        start-of-step predicates over swe/swe_top, grid-stride, one word per workgroup
+//   k_agg          1 workgroup: [user hooks] + OR of the workgroup words + forcing predicates,
+//                  step-class flags, aggregates of the shared forcing series (numpy summation order)
+//   k_select       prec/ta selection per column, event + infiltration predicates, one word per workgroup
+//   k_scalars      1 workgroup: OR of the words, time-step bookkeeping (dt, event ids, itt, time),
+//                  StepCtx for the step
 //   k_step<M>      THE hot kernel: whole SVAT step per column, state read once / written once
-//   k_finish       1 thread: itt/time increment, sanity flag, tau->taum1 of the scalars
+//   k_reduce       only for multi-GPU runs: materialises a predicate word for the all-reduce
 // plus one kernel per routine for the per-routine entry points and the setup-time kernels.
-// All are HBM-bound streaming kernels (no data reuse, no LDS tiling, no MFMA); k_step moves
-// ~2.8 KB per column.
+// All per-column kernels are HBM-bound streaming kernels (no data reuse, no LDS tiling, no
+// MFMA); k_step moves ~2 KB per column (2.8 KB by the reference's variable read/write sets).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -24,6 +26,7 @@
 #include "roger_hip.h"
 
 #define RH_BLOCK 256
+#define RH_PRED_BLOCKS 1024  // grid of the grid-stride predicate kernels
 
 // ---------------------------------------------------------------------------------------------
 // device-resident control block
@@ -32,7 +35,12 @@ struct DevState {
     Consts K;
     rh_scalars S;
     StepCtx X;
-    unsigned long long words[4];  // predicate words 0,1; word 2 = "sanity violated"
+    unsigned long long words[4];  // predicate words 0,1; word 2 = "sanity violated"; word 3 scratch
+    // per-workgroup partial predicate words of k_pred1 / k_select: plain stores, OR-reduced by the
+    // single-workgroup kernel that follows (a single word hammered by atomics from every wave
+    // costs ~100 us per pass: one address sustains ~90 atomics/us)
+    unsigned long long bflags[2][RH_PRED_BLOCKS];
+    int pred_blocks;               // workgroups launched for k_pred1 / k_select
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
     const double *forc_cell[3];        // per-cell forcing (n, 144) or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
@@ -57,6 +65,7 @@ struct rh_ctx {
     double *agg_cell_buf;
     void *series_buf;
     bool per_cell;
+    int pred_blocks;
     bool forcing_set;
     bool timing;
     std::vector<hipEvent_t> events;  // pairs (start, stop) around the fused kernel, one per timed step
@@ -79,6 +88,31 @@ RH_DEV void wave_or_to(unsigned long long *word, unsigned long long bits) {
         const unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bits & ~seen) atomicOr(word, bits);
     }
+}
+// OR over the workgroup, then one plain store per workgroup.
+RH_DEV void block_or_store(unsigned long long *slot, unsigned long long bits) {
+    __shared__ unsigned long long wv[RH_BLOCK / 64];
+    for (int off = 32; off; off >>= 1) bits |= __shfl_xor(bits, off);
+    if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int k = 0; k < RH_BLOCK / 64; ++k) b |= wv[k];
+        *slot = b;
+    }
+}
+// OR-reduce the per-workgroup words (one workgroup of RH_BLOCK threads); result valid in thread 0.
+RH_DEV unsigned long long reduce_bflags(const unsigned long long *bf, int nblk) {
+    __shared__ unsigned long long wv[RH_BLOCK / 64];
+    unsigned long long b = 0;
+    for (int k = threadIdx.x; k < nblk; k += RH_BLOCK) b |= bf[k];
+    for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
+    if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = b;
+    __syncthreads();
+    b = 0;
+    for (int k = 0; k < RH_BLOCK / 64; ++k) b |= wv[k];
+    __syncthreads();
+    return b;
 }
 #define BIT(b) (1ull << (b))
 RH_DEV bool bit(unsigned long long w, int b) { return (w >> b) & 1ull; }
@@ -147,15 +181,15 @@ RH_DEV unsigned long long forcing_bits(double p, double t, const Consts &K) {
 // ---------------------------------------------------------------------------------------------
 // The benchmark's `set_forcing` and `set_parameters` hooks (benchmarks/SVAT_benchmark.py:105-110,
 // 151-171) on the device: at midnight take the next 144 forcing slots and the calendar entry;
-// flag a month change.  One workgroup of 256 threads.
-__global__ void k_set_forcing(DevState *D) {
+// flag a month change.  Called by one whole workgroup of RH_BLOCK threads.
+RH_DEV void hooks_set_forcing(DevState *D) {
     rh_scalars &S = D->S;
     const bool midnight = (S.time % 86400 == 0);
     const int64_t i0 = S.itt_forc;
     const bool have = midnight && (i0 + RH_SLOTS_PER_DAY <= D->nitt_forc);
+    __syncthreads();  // everybody has read S before thread 0 changes it
     if (have && threadIdx.x < RH_SLOTS_PER_DAY)
         for (int k = 0; k < 3; ++k) D->forc[k][threadIdx.x] = D->series[k][i0 + threadIdx.x];
-    __syncthreads();
     if (threadIdx.x == 0) {
         if (have) {
             S.itt_day = 0;
@@ -167,13 +201,17 @@ __global__ void k_set_forcing(DevState *D) {
         }
         D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
     }
+    __threadfence();
+    __syncthreads();
 }
+__global__ __launch_bounds__(RH_BLOCK) void k_set_forcing(DevState *D) { hooks_set_forcing(D); }
 
+// start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
 __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
-    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const Consts K = D->K;
     unsigned long long b = 0;
-    if (i < a.n) {
+    const bool per_cell = D->per_cell != 0;
+    for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * RH_BLOCK) {
         double swe, swe_top;
         rh_ld(a, RH_P_swe, i, swe);
         rh_ld(a, RH_P_swe_top, i, swe_top);
@@ -181,14 +219,37 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
         b |= (swe > 0) ? BIT(PB_SWE_GT0) : 0;
         b |= !(swe_top <= 0) ? BIT(PB_SWETOP_NOT_LE0) : 0;
         b |= (swe_top > 0) ? BIT(PB_SWETOP_GT0) : 0;
-        if (D->per_cell) {
+        if (per_cell) {
             const double *p = D->forc_cell[0] + i * RH_SLOTS_PER_DAY, *t = D->forc_cell[1] + i * RH_SLOTS_PER_DAY;
             for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p[k], t[k], K);
         }
     }
-    if (!D->per_cell && blockIdx.x == 0 && threadIdx.x < RH_SLOTS_PER_DAY)
-        b |= forcing_bits(D->forc[0][threadIdx.x], D->forc[1][threadIdx.x], K);
-    wave_or_to(&D->words[0], b);
+    block_or_store(&D->bflags[0][blockIdx.x], b);
+}
+
+// word 0 = OR of the workgroup words of k_pred1 and the predicates of the shared forcing series
+RH_DEV void finish_word0(DevState *D) {
+    unsigned long long fb = 0;
+    if (!D->per_cell && threadIdx.x < RH_SLOTS_PER_DAY) fb = forcing_bits(D->forc[0][threadIdx.x], D->forc[1][threadIdx.x], D->K);
+    __shared__ unsigned long long fw[RH_BLOCK / 64];
+    for (int off = 32; off; off >>= 1) fb |= __shfl_xor(fb, off);
+    if ((threadIdx.x & 63) == 0) fw[threadIdx.x >> 6] = fb;
+    const unsigned long long cells = reduce_bflags(D->bflags[0], D->pred_blocks);  // contains __syncthreads
+    if (threadIdx.x == 0) {
+        unsigned long long w = cells;
+        for (int k = 0; k < RH_BLOCK / 64; ++k) w |= fw[k];
+        D->words[0] = w;
+    }
+    __threadfence();
+    __syncthreads();
+}
+__global__ __launch_bounds__(RH_BLOCK) void k_reduce(DevState *D, int which) {
+    if (which == 0) {
+        finish_word0(D);
+    } else {
+        const unsigned long long w = reduce_bflags(D->bflags[1], D->pred_blocks);
+        if (threadIdx.x == 0) D->words[1] = w;
+    }
 }
 
 // Shared forcing: the nine aggregates of the day's 144-slot series in numpy's summation order,
@@ -198,7 +259,9 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
 // Lane j of a 16-lane group owns one r_j; six groups = six sums.
 RH_DEV double np_tree8(const double *r) { return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])); }
 
-__global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D) {
+__global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int do_reduce) {
+    if (do_hooks) hooks_set_forcing(D);   // rh_run_steps: the user hooks ride along
+    if (do_reduce) finish_word0(D);       // single GPU: no exchange between k_pred1 and here
     __shared__ double f[3][RH_SLOTS_PER_DAY];   // prec, ta, pet of the day
     __shared__ double part[6][16];
     const int tid = threadIdx.x;
@@ -290,11 +353,11 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D) {
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
 
 __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
-    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const Consts K = D->K;
     const StepCtx X = D->X;
+    const bool per_cell = D->per_cell != 0;
     unsigned long long b = 0;
-    if (i < a.n) {
+    for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * RH_BLOCK) {
         Col c;
         rh_ld(a, RH_P_prec, i, c.prec);
         rh_ld(a, RH_P_ta, i, c.ta);
@@ -303,12 +366,14 @@ __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
         rh_ld(a, RH_P_swe, i, swe);
         rh_ld(a, RH_P_swe_top, i, swe_top);
         rh_ld(a, RH_P_swe_m1, i, swe_m1);
-        if (D->per_cell && X.sel_p >= 0)
-            rt_select_prec_ta(c, X, cell_agg(D, a.n, i, 3 * X.sel_p), cell_agg(D, a.n, i, 3 * X.sel_p + 1));
-        else
-            rt_select_prec_ta(c, X, X.prec_sel, X.ta_sel);
-        rh_st(a, RH_P_prec, i, c.prec);
-        rh_st(a, RH_P_ta, i, c.ta);
+        if (X.sel_p >= 0) {
+            if (per_cell)
+                rt_select_prec_ta(c, X, cell_agg(D, a.n, i, 3 * X.sel_p), cell_agg(D, a.n, i, 3 * X.sel_p + 1));
+            else
+                rt_select_prec_ta(c, X, X.prec_sel, X.ta_sel);
+            rh_st(a, RH_P_prec, i, c.prec);
+            rh_st(a, RH_P_ta, i, c.ta);
+        }
         const bool warm = c.ta > K.ta_fm;
         b |= ((c.prec > 0) && warm) ? BIT(PC_RAIN) : 0;
         b |= (((swe > 0) || (swe_top > 0)) && warm) ? BIT(PC_SNOWMELT) : 0;
@@ -321,7 +386,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
         b |= (c.prec != 0) ? BIT(PC_P_NE0) : 0;
         b |= (prec_m1 == 0) ? BIT(PC_PM1_EQ0) : 0;
     }
-    wave_or_to(&D->words[1], b);
+    block_or_store(&D->bflags[1][blockIdx.x], b);
 }
 
 // infiltration.py:2155-2167 from the predicate word and the event ids
@@ -336,11 +401,13 @@ RH_DEV void infiltration_conds(DevState *D, unsigned long long w) {
 }
 
 // adaptive_time_stepping.py:192-373, scalar part
-__global__ void k_scalars(DevState *D) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce, int do_finish) {
+    unsigned long long w = 0;
+    if (do_reduce) w = reduce_bflags(D->bflags[1], D->pred_blocks);
+    if (threadIdx.x != 0) return;
+    if (!do_reduce) w = D->words[1];
     rh_scalars &S = D->S;
     StepCtx &X = D->X;
-    const unsigned long long w = D->words[1];
     const bool ev_start = bit(w, PC_RAIN) || bit(w, PC_SNOWMELT);
     const bool ev_end = !bit(w, PC_PREC_NOT_LE0) || !bit(w, PC_NOT_PGT0_TALE) || (bit(w, PC_SWEM1_GT0) && !bit(w, PC_SWE_NOT_LE0));
     int64_t dts = X.dt_secs_prelim;
@@ -375,22 +442,19 @@ __global__ void k_scalars(DevState *D) {
     D->words[0] = 0;
     D->words[1] = 0;
     D->words[2] = 0;
-}
-
-// roger.py:449-450 and the scalar half of after_timestep (svat.py:352-366)
-__global__ void k_finish(DevState *D, int rotate) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    rh_scalars &S = D->S;
-    S.itt += 1;
-    S.time += S.dt_secs;
-    S.sanity_ok = D->words[2] ? 0 : 1;
-    if (rotate) {
+    if (do_finish) {
+        // roger.py:449-450 and the scalar half of after_timestep (svat.py:352-366).  Nothing below
+        // this kernel reads these scalars during the step (k_step works from StepCtx), so they are
+        // advanced here instead of in a kernel of their own.
+        S.itt += 1;
+        S.time += S.dt_secs;
         S.event_id[0] = S.event_id[1];
         S.year[0] = S.year[1];
         S.month[0] = S.month[1];
         S.doy[0] = S.doy[1];
     }
 }
+
 __global__ void k_rotate_scalars(DevState *D) {
     rh_scalars &S = D->S;
     S.event_id[0] = S.event_id[1];
@@ -668,6 +732,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     if ((e = hipMemcpyAsync(&ctx->dev->S, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(scalars)");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // K, S are stack locals
+    ctx->pred_blocks = (int)(grid_for(ctx->n) < RH_PRED_BLOCKS ? grid_for(ctx->n) : RH_PRED_BLOCKS);
+    if ((e = hipMemcpyAsync(&ctx->dev->pred_blocks, &ctx->pred_blocks, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        return bail(e, "hipMemcpy(pred_blocks)");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     hipLaunchKernelGGL(k_init_registry, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena);
     hipLaunchKernelGGL(k_sync_ctx, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "kernel launch (is this a gfx950 device?)");
@@ -750,8 +818,11 @@ int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
 
 int rh_get_scalars(rh_ctx *ctx, rh_scalars *s) {
     if (!ctx || !s) return RH_ERR_ARG;
+    unsigned long long bad = 0;
     HIPCHK(ctx, hipMemcpyAsync(s, &ctx->dev->S, sizeof(*s), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&bad, &ctx->dev->words[2], sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    s->sanity_ok = bad ? 0 : 1;  // word 2 collects the sanity violations of the last step
     return RH_OK;
 }
 
@@ -836,24 +907,9 @@ int rh_after_timestep(rh_ctx *ctx) {
     return RH_OK;
 }
 
-int rh_step_phase1(rh_ctx *ctx) {
-    if (!ctx) return RH_ERR_ARG;
-    if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day must be called before the first step");
-    LAUNCH_CELLS(ctx, k_pred1);
-    CHECK_LAUNCH(ctx);
-    return RH_OK;
-}
-int rh_step_phase2(rh_ctx *ctx) {
-    if (!ctx) return RH_ERR_ARG;
-    LAUNCH_WG(ctx, k_agg, ctx->dev);
-    if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
-    LAUNCH_CELLS(ctx, k_select);
-    CHECK_LAUNCH(ctx);
-    return RH_OK;
-}
-int rh_step_phase3(rh_ctx *ctx, int monthly) {
-    if (!ctx) return RH_ERR_ARG;
-    LAUNCH_ONE(ctx, k_scalars, ctx->dev);
+#define LAUNCH_PRED(ctx, kern) hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev)
+
+static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
     if (ctx->timing) {
         while (ctx->events.size() < ctx->ev_used + 2) {
             hipEvent_t ev;
@@ -863,7 +919,7 @@ int rh_step_phase3(rh_ctx *ctx, int monthly) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used], ctx->stream));
     }
     const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
-    if (monthly < 0) {  // decided on the device (rh_run_steps)
+    if (monthly < 0) {  // decided on the device
         hipLaunchKernelGGL(k_step<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 1);
         hipLaunchKernelGGL(k_step<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 1);
     } else if (monthly) {
@@ -875,16 +931,50 @@ int rh_step_phase3(rh_ctx *ctx, int monthly) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used + 1], ctx->stream));
         ctx->ev_used += 2;
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, ctx->stream, ctx->dev, 1);
+    return RH_OK;
+}
+
+int rh_step_phase1(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
+    LAUNCH_PRED(ctx, k_pred1);
+    LAUNCH_WG(ctx, k_reduce, ctx->dev, 0);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+int rh_step_phase2(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    LAUNCH_WG(ctx, k_agg, ctx->dev, 0, 0);
+    if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
+    LAUNCH_PRED(ctx, k_select);
+    LAUNCH_WG(ctx, k_reduce, ctx->dev, 1);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+int rh_step_phase3(rh_ctx *ctx, int monthly) {
+    if (!ctx) return RH_ERR_ARG;
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 0, 1);
+    int rc = launch_fused_kernel(ctx, monthly);
+    if (rc) return rc;
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+// single GPU: the same step with the reductions folded into the single-workgroup kernels
+static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
+    if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
+    LAUNCH_PRED(ctx, k_pred1);
+    LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
+    if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
+    LAUNCH_PRED(ctx, k_select);
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1);
+    int rc = launch_fused_kernel(ctx, monthly);
+    if (rc) return rc;
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
 int rh_svat_step(rh_ctx *ctx, int monthly) {
-    int rc = rh_step_phase1(ctx);
-    if (rc) return rc;
-    rc = rh_step_phase2(ctx);
-    if (rc) return rc;
-    return rh_step_phase3(ctx, monthly);
+    if (!ctx) return RH_ERR_ARG;
+    return step_fused_launches(ctx, monthly, 0);
 }
 
 // stand-alone adaptive time stepping: phases 1-2, the scalar kernel and the pet/ta selection
@@ -893,7 +983,7 @@ int rh_adaptive_dt(rh_ctx *ctx) {
     if (rc) return rc;
     rc = rh_step_phase2(ctx);
     if (rc) return rc;
-    LAUNCH_ONE(ctx, k_scalars, ctx->dev);
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 0, 0);
     LAUNCH_CELLS(ctx, k_select_pet);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -930,11 +1020,9 @@ int rh_hooks_phase(rh_ctx *ctx) {
 
 int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
+    if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     for (int64_t k = 0; k < nsteps; ++k) {
-        int rc = rh_hooks_phase(ctx);
-        if (!rc) rc = rh_step_phase1(ctx);
-        if (!rc) rc = rh_step_phase2(ctx);
-        if (!rc) rc = rh_step_phase3(ctx, -1);
+        int rc = step_fused_launches(ctx, -1, 1);
         if (rc) return rc;
     }
     return RH_OK;
