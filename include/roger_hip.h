@@ -137,6 +137,10 @@ int rh_capillary_rise(rh_ctx *ctx);     /* calculate_capillary_rise, core/capill
 int rh_storage(rh_ctx *ctx);            /* calculate_surface/root_zone/subsoil/soil + numerics.calc_storage */
 int rh_num_error(rh_ctx *ctx);          /* numerics.sanity_check + calculate_num_error, core/numerics.py:716-1011 */
 int rh_after_timestep(rh_ctx *ctx);     /* after_timestep_kernel, roger/models/svat/svat.py:187-384 */
+/* interception ... calculate_num_error fused into one kernel plus `itt += 1; time += dt_secs`
+ * (roger/roger.py:410-457): the part of step() between the user hooks set_parameters and
+ * after_timestep, for drivers that keep those hooks on the host.  Needs rh_adaptive_dt first. */
+int rh_step_core(rh_ctx *ctx);
 
 /* ---- the fused step ------------------------------------------------------------------------
  * One whole time step in the order of RogerSetup.step, without the user hooks: adaptive dt ->

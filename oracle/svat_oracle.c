@@ -98,77 +98,93 @@ double oc_np_sum(const double *a, int64_t n) { return 0.0 + np_pairwise(a, n); }
 /* ======================================================================== */
 /* forcing of the current day: prec_day/ta_day/pet_day, each (n, 144) when
  * fstride==144 or one shared (144) vector when fstride==0
- * (benchmarks/SVAT_benchmark.py:162-170 broadcasts one station series). */
-void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, const double *ta_day,
-                    const double *pet_day, int64_t fstride, oc_scalars *s, const oc_settings *st) {
-    /* global predicates, adaptive_time_stepping.py:38-81 */
-    int all_p_le0 = 1, any_p_gt0 = 0, any_p_gthpi = 0, all_p_lehpi = 1;
-    int all_ta_gt = 1, any_ta_gt = 0, any_pgt0_tale = 0, all_ple0_tale = 1;
-    int all_swe_le0 = 1, any_swe_gt0 = 0, all_swetop_le0 = 1, any_swetop_gt0 = 0;
-    int pi_swe = -1, pi_swetop = -1, pi_swe_m1 = -1;
-    int pi_prec = -1, pi_ta = -1, pi_pet = -1, pi_petres = -1, pi_mask = -1;
-    for (int p = 0; p < OC_NPLANES; ++p) {
-        if (!strcmp(OC_TABLE[p].name, "swe")) pi_swe = p;
-        if (!strcmp(OC_TABLE[p].name, "swe_m1")) pi_swe_m1 = p;
-        if (!strcmp(OC_TABLE[p].name, "swe_top")) pi_swetop = p;
-        if (!strcmp(OC_TABLE[p].name, "prec")) pi_prec = p;
-        if (!strcmp(OC_TABLE[p].name, "ta")) pi_ta = p;
-        if (!strcmp(OC_TABLE[p].name, "pet")) pi_pet = p;
-        if (!strcmp(OC_TABLE[p].name, "pet_res")) pi_petres = p;
-        if (!strcmp(OC_TABLE[p].name, "maskCatch")) pi_mask = p;
-    }
-    (void)pi_mask;
-    const double *swe = planes[pi_swe], *swe_m1 = planes[pi_swe_m1], *swe_top = planes[pi_swetop];
-    double *prec = planes[pi_prec], *ta = planes[pi_ta], *pet = planes[pi_pet], *pet_res = planes[pi_petres];
+ * (benchmarks/SVAT_benchmark.py:162-170 broadcasts one station series).
+ *
+ * The routine is written in three phases so that a domain-decomposed test can combine the
+ * global predicates of several ranks (bitwise OR of the returned words) between them, the way
+ * the reference's MPI variant combines them by gathering to rank 0
+ * (adaptive_time_stepping_dist_safe.py).  oc_adaptive_dt runs the three back to back. */
+enum { W0_SWE_NOT_LE0 = 0, W0_SWE_GT0, W0_SWETOP_NOT_LE0, W0_SWETOP_GT0, W0_P_NOT_LE0, W0_P_GT0, W0_P_GTHPI,
+       W0_P_NOT_LEHPI, W0_TA_NOT_GT, W0_TA_GT, W0_PGT0_TALE, W0_NOT_PLE0_TALE };
+enum { W1_EV1A = 0, W1_EV1B, W1_PREC_NOT_LE0, W1_NOT_PGT0_TALE, W1_SWEM1_GT0, W1_SWE_NOT_LE0, W1_P_EQ0, W1_PM1_NE0,
+       W1_P_NE0, W1_PM1_EQ0 };
+#define WB(b) (1ull << (b))
+#define HAS(w, b) (((w) >> (b)) & 1ull)
+
+static int plane_index(const char *name) {
+    for (int p = 0; p < OC_NPLANES; ++p)
+        if (!strcmp(OC_TABLE[p].name, name)) return p;
+    return -1;
+}
+
+typedef struct {
+    int sel_daily, sel_hourly, sel_10min;
+    int64_t dt_secs;
+} adt_sel;
+
+/* phase 1: predicates of lines 38-81 over the local cells and the forcing */
+uint64_t oc_adt_pred1(void *const *planes, int64_t n, const double *prec_day, const double *ta_day, int64_t fstride,
+                      const oc_settings *st) {
+    const double *swe = planes[plane_index("swe")], *swe_top = planes[plane_index("swe_top")];
+    uint64_t w = 0;
     int64_t nf = fstride ? n : 1;
     for (int64_t i = 0; i < nf; ++i) {
         const double *pd = prec_day + i * fstride, *td = ta_day + i * fstride;
         for (int k = 0; k < 144; ++k) {
             double p = pd[k], t = td[k];
-            all_p_le0 &= (p <= 0);
-            any_p_gt0 |= (p > 0);
-            any_p_gthpi |= (p > (double)st->hpi);
-            all_p_lehpi &= (p <= (double)st->hpi);
-            all_ta_gt &= (t > st->ta_fm);
-            any_ta_gt |= (t > st->ta_fm);
-            any_pgt0_tale |= ((p > 0) && (t <= st->ta_fm));
-            all_ple0_tale &= ((p <= 0) && (t <= st->ta_fm));
+            if (!(p <= 0)) w |= WB(W0_P_NOT_LE0);
+            if (p > 0) w |= WB(W0_P_GT0);
+            if (p > (double)st->hpi) w |= WB(W0_P_GTHPI);
+            if (!(p <= (double)st->hpi)) w |= WB(W0_P_NOT_LEHPI);
+            if (!(t > st->ta_fm)) w |= WB(W0_TA_NOT_GT);
+            if (t > st->ta_fm) w |= WB(W0_TA_GT);
+            if ((p > 0) && (t <= st->ta_fm)) w |= WB(W0_PGT0_TALE);
+            if (!((p <= 0) && (t <= st->ta_fm))) w |= WB(W0_NOT_PLE0_TALE);
         }
     }
     for (int64_t i = 0; i < n; ++i) {
-        all_swe_le0 &= (swe[i] <= 0);
-        any_swe_gt0 |= (swe[i] > 0);
-        all_swetop_le0 &= (swe_top[i] <= 0);
-        any_swetop_gt0 |= (swe_top[i] > 0);
+        if (!(swe[i] <= 0)) w |= WB(W0_SWE_NOT_LE0);
+        if (swe[i] > 0) w |= WB(W0_SWE_GT0);
+        if (!(swe_top[i] <= 0)) w |= WB(W0_SWETOP_NOT_LE0);
+        if (swe_top[i] > 0) w |= WB(W0_SWETOP_GT0);
     }
+    return w;
+}
+
+static adt_sel adt_select_flags(uint64_t w, const oc_scalars *s) {
+    int all_p_le0 = !HAS(w, W0_P_NOT_LE0), any_p_gt0 = HAS(w, W0_P_GT0), any_p_gthpi = HAS(w, W0_P_GTHPI);
+    int all_p_lehpi = !HAS(w, W0_P_NOT_LEHPI), all_ta_gt = !HAS(w, W0_TA_NOT_GT), any_ta_gt = HAS(w, W0_TA_GT);
+    int any_pgt0_tale = HAS(w, W0_PGT0_TALE), all_ple0_tale = !HAS(w, W0_NOT_PLE0_TALE);
+    int all_swe_le0 = !HAS(w, W0_SWE_NOT_LE0), all_swetop_le0 = !HAS(w, W0_SWETOP_NOT_LE0);
+    int snow_any = (HAS(w, W0_SWE_GT0) || HAS(w, W0_SWETOP_GT0)) && any_ta_gt;
     int cond0 = all_p_le0 && all_swe_le0 && all_swetop_le0 && all_ta_gt;
     int cond00 = any_pgt0_tale || all_ple0_tale;
     int cond1 = any_p_gthpi && any_p_gt0 && any_ta_gt;
     int cond2 = all_p_lehpi && any_p_gt0 && any_ta_gt;
-    int snow_any = (any_swe_gt0 || any_swetop_gt0) && any_ta_gt;
     int cond3 = any_p_gthpi && any_p_gt0 && snow_any;
     int cond4 = all_p_lehpi && any_p_gt0 && snow_any;
     int cond5 = all_p_le0 && snow_any;
     int cond_time = (s->time % (24 * 60 * 60) == 0);
-
-    int sel_daily = cond0 || cond00;
-    int sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
-    int sel_10min = (cond1 || cond3) && !cond2 && !cond4 && !cond5;
-
+    adt_sel r;
+    r.sel_daily = cond0 || cond00;
+    r.sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
+    r.sel_10min = (cond1 || cond3) && !cond2 && !cond4 && !cond5;
     /* dt_secs, lines 143-144, 166, 190 (line 144 overwrites line 143 unconditionally) */
-    int64_t dt_secs = cond_time ? 24 * 60 * 60 : 60 * 60;
-    if (sel_hourly) dt_secs = 60 * 60;
-    if (sel_10min) dt_secs = 10 * 60;
+    r.dt_secs = cond_time ? 24 * 60 * 60 : 60 * 60;
+    if (r.sel_hourly) r.dt_secs = 60 * 60;
+    if (r.sel_10min) r.dt_secs = 10 * 60;
+    return r;
+}
 
-    /* per-cell aggregates, lines 384-437, and prec/ta selection, lines 128-189 */
+/* per-cell aggregates {prec, ta, pet} x {daily, hourly, 10 min}, lines 384-437 */
+static double *adt_aggregates(int64_t n, const double *prec_day, const double *ta_day, const double *pet_day,
+                              int64_t fstride, int64_t itd) {
+    int64_t nf = fstride ? n : 1;
     double *buf = (double *)malloc(sizeof(double) * 144 * 3);
-    double *pdaily = (double *)malloc(sizeof(double) * 6 * (size_t)nf);
     double *agg = (double *)malloc(sizeof(double) * 9 * (size_t)nf);
-    int64_t itd = s->itt_day;
     for (int64_t i = 0; i < nf; ++i) {
         const double *pd = prec_day + i * fstride, *td = ta_day + i * fstride, *ed = pet_day + i * fstride;
         double *a = agg + 9 * i;
-        /* daily: sum / nanmean over the 144 slots */
         a[0] = oc_np_sum(pd, 144);
         {
             int cnt = 0;
@@ -179,7 +195,6 @@ void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, cons
             a[1] = oc_np_sum(buf, 144) / (double)cnt;
         }
         a[2] = oc_np_sum(ed, 144);
-        /* hourly: window [itt_day, itt_day+6) */
         {
             int cnt = 0;
             for (int k = 0; k < 144; ++k) {
@@ -194,7 +209,6 @@ void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, cons
             a[4] = oc_np_sum(buf + 144, 144) / (double)cnt;
             a[5] = oc_np_sum(buf + 288, 144);
         }
-        /* 10 minutes: slot itt_day (python index; itt_day <= 143 on this path) */
         {
             int64_t k = itd;
             if (k < 0) k += 144;
@@ -204,25 +218,52 @@ void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, cons
             a[8] = ed[k];
         }
     }
+    free(buf);
+    return agg;
+}
+
+/* phase 2: prec/ta selection (lines 128-189) and the predicates of lines 192-201 and of
+ * calculate_infiltration (infiltration.py:2155-2167) over the local cells */
+uint64_t oc_adt_select(void *const *planes, int64_t n, const double *prec_day, const double *ta_day,
+                       const double *pet_day, int64_t fstride, const oc_scalars *s, const oc_settings *st,
+                       uint64_t word0) {
+    adt_sel f = adt_select_flags(word0, s);
+    double *prec = planes[plane_index("prec")], *ta = planes[plane_index("ta")];
+    const double *prec_m1 = planes[plane_index("prec_m1")];
+    const double *swe = planes[plane_index("swe")], *swe_m1 = planes[plane_index("swe_m1")];
+    const double *swe_top = planes[plane_index("swe_top")];
+    double *agg = adt_aggregates(n, prec_day, ta_day, pet_day, fstride, s->itt_day);
+    uint64_t w = 0;
     for (int64_t i = 0; i < n; ++i) {
         const double *a = agg + 9 * (fstride ? i : 0);
-        if (sel_daily) { prec[i] = a[0]; ta[i] = a[1]; }
-        if (sel_hourly) { prec[i] = a[3]; ta[i] = a[4]; }
-        if (sel_10min) { prec[i] = a[6]; ta[i] = a[7]; }
+        if (f.sel_daily) { prec[i] = a[0]; ta[i] = a[1]; }
+        if (f.sel_hourly) { prec[i] = a[3]; ta[i] = a[4]; }
+        if (f.sel_10min) { prec[i] = a[6]; ta[i] = a[7]; }
+        if ((prec[i] > 0) && (ta[i] > st->ta_fm)) w |= WB(W1_EV1A);
+        if (((swe[i] > 0) || (swe_top[i] > 0)) && (ta[i] > st->ta_fm)) w |= WB(W1_EV1B);
+        if (!(prec[i] <= 0)) w |= WB(W1_PREC_NOT_LE0);
+        if (!((prec[i] > 0) && (ta[i] <= st->ta_fm))) w |= WB(W1_NOT_PGT0_TALE);
+        if (swe_m1[i] > 0) w |= WB(W1_SWEM1_GT0);
+        if (!(swe[i] <= 0)) w |= WB(W1_SWE_NOT_LE0);
+        if (prec[i] == 0) w |= WB(W1_P_EQ0);
+        if (prec_m1[i] != 0) w |= WB(W1_PM1_NE0);
+        if (prec[i] != 0) w |= WB(W1_P_NE0);
+        if (prec_m1[i] == 0) w |= WB(W1_PM1_EQ0);
     }
+    free(agg);
+    return w;
+}
 
-    /* event start / end, lines 192-205 */
-    int ev1a = 0, ev1b = 0, all_prec_le0 = 1, all_pgt0_tale = 1, any_swem1_gt0 = 0, all_swe_le0b = 1;
-    for (int64_t i = 0; i < n; ++i) {
-        ev1a |= ((prec[i] > 0) && (ta[i] > st->ta_fm));
-        ev1b |= (((swe[i] > 0) || (swe_top[i] > 0)) && (ta[i] > st->ta_fm));
-        all_prec_le0 &= (prec[i] <= 0);
-        all_pgt0_tale &= ((prec[i] > 0) && (ta[i] <= st->ta_fm));
-        any_swem1_gt0 |= (swe_m1[i] > 0);
-        all_swe_le0b &= (swe[i] <= 0);
-    }
-    int cond_event1 = ev1a || ev1b;
-    int cond_event2 = all_prec_le0 || all_pgt0_tale || (any_swem1_gt0 && all_swe_le0b);
+/* phase 3: scalar bookkeeping (lines 192-373) and the pet/ta selection (lines 262-376) */
+void oc_adt_finish(void *const *planes, int64_t n, const double *prec_day, const double *ta_day, const double *pet_day,
+                   int64_t fstride, oc_scalars *s, const oc_settings *st, uint64_t word0, uint64_t word1) {
+    adt_sel f = adt_select_flags(word0, s);
+    int64_t dt_secs = f.dt_secs;
+    double *ta = planes[plane_index("ta")], *pet = planes[plane_index("pet")], *pet_res = planes[plane_index("pet_res")];
+    double *agg = adt_aggregates(n, prec_day, ta_day, pet_day, fstride, s->itt_day);
+    int cond_event1 = HAS(word1, W1_EV1A) || HAS(word1, W1_EV1B);
+    int cond_event2 = !HAS(word1, W1_PREC_NOT_LE0) || !HAS(word1, W1_NOT_PGT0_TALE) ||
+                      (HAS(word1, W1_SWEM1_GT0) && !HAS(word1, W1_SWE_NOT_LE0));
     if (cond_event1) s->time_event0 = 0;
     if (cond_event2) s->time_event0 = s->time_event0 + dt_secs;
 
@@ -263,9 +304,14 @@ void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, cons
     if ((s->event_id[0] > 0) && (s->event_id[1] == 0)) s->event_id_counter += 1;
     /* line 376 */
     for (int64_t i = 0; i < n; ++i) pet_res[i] = pet[i];
-    free(buf);
-    free(pdaily);
     free(agg);
+}
+
+void oc_adaptive_dt(void *const *planes, int64_t n, const double *prec_day, const double *ta_day,
+                    const double *pet_day, int64_t fstride, oc_scalars *s, const oc_settings *st) {
+    uint64_t w0 = oc_adt_pred1(planes, n, prec_day, ta_day, fstride, st);
+    uint64_t w1 = oc_adt_select(planes, n, prec_day, ta_day, pet_day, fstride, s, st, w0);
+    oc_adt_finish(planes, n, prec_day, ta_day, pet_day, fstride, s, st, w0, w1);
 }
 
 /* ======================================================================== */
@@ -1371,20 +1417,7 @@ typedef struct {
     int cond1, cond2, cond3, cond4, cond5;
 } inf_conds;
 
-static inf_conds infiltration_conds(void *const *planes, int64_t n, const oc_scalars *s) {
-    int pp = -1, pm = -1;
-    for (int p = 0; p < OC_NPLANES; ++p) {
-        if (!strcmp(OC_TABLE[p].name, "prec")) pp = p;
-        if (!strcmp(OC_TABLE[p].name, "prec_m1")) pm = p;
-    }
-    const double *prec = planes[pp], *prec_m1 = planes[pm];
-    int any_p0 = 0, any_pm1_n0 = 0, any_pn0 = 0, any_pm1_0 = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        any_p0 |= (prec[i] == 0);
-        any_pm1_n0 |= (prec_m1[i] != 0);
-        any_pn0 |= (prec[i] != 0);
-        any_pm1_0 |= (prec_m1[i] == 0);
-    }
+static inf_conds infiltration_conds_from(int any_p0, int any_pm1_n0, int any_pn0, int any_pm1_0, const oc_scalars *s) {
     inf_conds k;
     k.cond1 = (s->event_id[0] == 0) && (s->event_id[1] >= 1);
     k.cond2 = any_p0 && any_pm1_n0 && (s->event_id[0] >= 1);
@@ -1392,6 +1425,17 @@ static inf_conds infiltration_conds(void *const *planes, int64_t n, const oc_sca
     k.cond4 = (s->event_id[0] >= 1) && (s->event_id[1] == 0);
     k.cond5 = s->event_id[1] >= 1;
     return k;
+}
+static inf_conds infiltration_conds(void *const *planes, int64_t n, const oc_scalars *s) {
+    const double *prec = planes[plane_index("prec")], *prec_m1 = planes[plane_index("prec_m1")];
+    int any_p0 = 0, any_pm1_n0 = 0, any_pn0 = 0, any_pm1_0 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        any_p0 |= (prec[i] == 0);
+        any_pm1_n0 |= (prec_m1[i] != 0);
+        any_pn0 |= (prec[i] != 0);
+        any_pm1_0 |= (prec_m1[i] == 0);
+    }
+    return infiltration_conds_from(any_p0, any_pm1_n0, any_pn0, any_pm1_0, s);
 }
 
 static void infiltration_cell(oc_cell *c, const oc_settings *st, double dt, inf_conds k) {
@@ -1447,17 +1491,14 @@ void oc_params_soil(void *const *planes, int64_t n, const oc_settings *st, const
 }
 void oc_initial_conditions(void *const *planes, int64_t n) { FOR_CELLS(initial_conditions_cell(c)) }
 
-/* One full SVAT time step in the order of RogerSetup.step (roger/roger.py:396-485), without the
- * user hooks (set_forcing / set_parameters) which the caller runs before.  `monthly` != 0 runs
- * calc_parameters_surface_kernel first (svat.py:115-120).  Gathers each cell once. */
-int oc_step(void *const *planes, int64_t n, const double *prec_day, const double *ta_day, const double *pet_day,
-            int64_t fstride, oc_scalars *s, const oc_settings *st, int monthly, const double *ilu, const double *gc,
-            const double *gcm, const double *rdlu) {
-    oc_adaptive_dt(planes, n, prec_day, ta_day, pet_day, fstride, s, st);
+/* Everything of a step after the adaptive time stepping, with the infiltration predicates taken
+ * from predicate word 1 (global over all ranks in a decomposed run).  `core_only` != 0 stops
+ * before after_timestep (the hook-preserving driver runs that separately). */
+int oc_step_after_adt(void *const *planes, int64_t n, oc_scalars *s, const oc_settings *st, int monthly, int core_only,
+                      uint64_t word1, const double *ilu, const double *gc, const double *gcm, const double *rdlu) {
     oc_luts L = {ilu, gc, gcm, rdlu};
-    /* interception..snow only touch the own cell, but infiltration needs global predicates on
-     * prec[tau]/prec[taum1], which are final after oc_adaptive_dt. */
-    inf_conds k = infiltration_conds(planes, n, s);
+    inf_conds k = infiltration_conds_from(HAS(word1, W1_P_EQ0), HAS(word1, W1_PM1_NE0), HAS(word1, W1_P_NE0),
+                                          HAS(word1, W1_PM1_EQ0), s);
     int ok = 1;
     s->itt += 1;
     s->time += s->dt_secs;
@@ -1472,11 +1513,25 @@ int oc_step(void *const *planes, int64_t n, const double *prec_day, const double
         storage_cell(c, s->month[1]);
         ok &= sanity_cell(c, st);
         num_error_cell(c, st);
-        after_timestep_cell(c);)
+        if (!core_only) after_timestep_cell(c);)
     s->sanity_ok = ok;
-    s->event_id[0] = s->event_id[1];
-    s->year[0] = s->year[1];
-    s->month[0] = s->month[1];
-    s->doy[0] = s->doy[1];
+    if (!core_only) {
+        s->event_id[0] = s->event_id[1];
+        s->year[0] = s->year[1];
+        s->month[0] = s->month[1];
+        s->doy[0] = s->doy[1];
+    }
     return ok;
+}
+
+/* One full SVAT time step in the order of RogerSetup.step (roger/roger.py:396-485), without the
+ * user hooks (set_forcing / set_parameters) which the caller runs before.  `monthly` != 0 runs
+ * calc_parameters_surface_kernel first (svat.py:115-120).  Gathers each cell once. */
+int oc_step(void *const *planes, int64_t n, const double *prec_day, const double *ta_day, const double *pet_day,
+            int64_t fstride, oc_scalars *s, const oc_settings *st, int monthly, const double *ilu, const double *gc,
+            const double *gcm, const double *rdlu) {
+    uint64_t w0 = oc_adt_pred1(planes, n, prec_day, ta_day, fstride, st);
+    uint64_t w1 = oc_adt_select(planes, n, prec_day, ta_day, pet_day, fstride, s, st, w0);
+    oc_adt_finish(planes, n, prec_day, ta_day, pet_day, fstride, s, st, w0, w1);
+    return oc_step_after_adt(planes, n, s, st, monthly, 0, w1, ilu, gc, gcm, rdlu);
 }

@@ -39,7 +39,7 @@ _lib = None
 _ENTRY_POINTS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
-    "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase",
+    "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core",
 )
 
 
@@ -108,7 +108,7 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core",
 )
 
 

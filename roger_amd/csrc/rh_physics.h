@@ -1005,7 +1005,8 @@ RH_DEV void rt_select_pet(Col &c, const StepCtx &X, double pet_v, double ta_v) {
 // ---------------------------------------------------------------------------------------------
 // the whole step for one column, in the order of RogerSetup.step (roger/roger.py:396-485)
 // ---------------------------------------------------------------------------------------------
-RH_DEV bool h_step_body(Col &c, const Consts &K, const StepCtx &X) {
+// interception ... numerics: everything between the `set_parameters` and `after_timestep` hooks
+RH_DEV bool rt_step_core(Col &c, const Consts &K, const StepCtx &X) {
     rt_interception(c, K);
     rt_evapotranspiration(c, K);
     rt_snow(c, K, X);
@@ -1013,7 +1014,10 @@ RH_DEV bool h_step_body(Col &c, const Consts &K, const StepCtx &X) {
     rt_subsurface_runoff(c, X);
     rt_capillary_rise(c, X);
     rt_storage(c, X);
-    const bool bad = rt_num_error(c, K);
+    return rt_num_error(c, K);
+}
+RH_DEV bool h_step_body(Col &c, const Consts &K, const StepCtx &X) {
+    const bool bad = rt_step_core(c, K, X);
     rt_after_timestep(c);
     return bad;
 }

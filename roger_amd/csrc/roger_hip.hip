@@ -455,6 +455,10 @@ __global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce
     }
 }
 
+__global__ void k_advance(DevState *D) {  // roger.py:449-450
+    D->S.itt += 1;
+    D->S.time += D->S.dt_secs;
+}
 __global__ void k_rotate_scalars(DevState *D) {
     rh_scalars &S = D->S;
     S.event_id[0] = S.event_id[1];
@@ -535,6 +539,7 @@ RH_CELL_KERNEL(k_capillary_rise, rt_capillary_rise, rt_capillary_rise(c, X))
 RH_CELL_KERNEL(k_storage, rt_storage, rt_storage(c, X))
 RH_CELL_KERNEL(k_num_error, rt_num_error, if (rt_num_error(c, K)) atomicOr(&D->words[2], 1ull))
 RH_CELL_KERNEL(k_after_timestep, rt_after_timestep, rt_after_timestep(c))
+RH_CELL_KERNEL(k_step_core, rt_step_core, if (rt_step_core(c, K, X)) atomicOr(&D->words[2], 1ull))
 RH_CELL_KERNEL(k_topo, rt_topo, rt_topo(c))
 RH_CELL_KERNEL(k_params_surface, rt_params_surface, rt_params_surface(c, D->L, X))
 RH_CELL_KERNEL(k_params_soil, rt_params_soil, rt_params_soil(c, K, D->L))
@@ -895,6 +900,16 @@ int rh_num_error(rh_ctx *ctx) {
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
     LAUNCH_CELLS(ctx, k_num_error);
     LAUNCH_ONE(ctx, k_sanity_to_scalars, ctx->dev);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
+// interception ... numerics in one kernel, then itt/time (roger/roger.py:410-457); for drivers that
+// keep the user hooks `set_parameters` and `after_timestep` on the host
+int rh_step_core(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    LAUNCH_CELLS(ctx, k_step_core);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }

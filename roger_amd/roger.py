@@ -1,0 +1,195 @@
+"""`RogerSetup`: the driver of a model run, mirroring roger/roger.py for the SVAT path.
+
+Same abstract hooks, same call order in `setup()` (roger.py:258-336) and `step()`
+(roger.py:355-489).  The process routines between the hooks are native:
+
+    read_data, set_boundary_conditions, set_forcing          user hooks (host)
+    adaptive time stepping                                   rh_adaptive_dt
+    set_parameters                                           user hook (host); its
+                                                             calc_parameters_surface_kernel is native
+    interception ... numerics, itt/time                      rh_step_core (one fused kernel)
+    after_timestep                                           user hook; its after_timestep_kernel
+                                                             is native
+
+`run()` uses that hook-preserving sequence.  `run_device(nsteps)` is the fast path for setups
+whose hooks are the benchmark's (forcing series sliced at midnight, monthly surface parameters):
+it uploads vs.PREC/TA/PET/YEAR/MONTH/DOY once and advances with rh_run_steps, no host round trip.
+"""
+import abc
+
+from . import distributed, logger, runtime_settings as rs
+from . import settings as settings_mod
+from .routines import is_roger_routine, roger_routine, run_native
+from .state import RogerState
+from .timer import Timer  # noqa: F401
+
+
+class RogerSetup(metaclass=abc.ABCMeta):
+    """Main class for roger setups on the hip backend (roger/roger.py:17-45)."""
+
+    def __init__(self, override=None):
+        self.override_settings = override or {}
+        from . import core  # noqa: F401  (locks the runtime settings, roger/roger.py:40)
+
+        self.state = RogerState()
+        self._setup_done = False
+
+    # -- the abstract hooks, roger/roger.py:47-252 -------------------------------------------
+    @abc.abstractmethod
+    def set_settings(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_grid(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_topography(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_look_up_tables(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_parameters_setup(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_parameters(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_initial_conditions_setup(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_initial_conditions(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_boundary_conditions_setup(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_boundary_conditions(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_forcing_setup(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_forcing(self, state):
+        pass
+
+    @abc.abstractmethod
+    def set_diagnostics(self, state):
+        pass
+
+    @abc.abstractmethod
+    def after_timestep(self, state):
+        pass
+
+    def read_data(self, state):
+        pass
+
+    def _ensure_setup_done(self):
+        if not self._setup_done:
+            raise RuntimeError("setup() method has to be called before running the model")
+
+    # -- setup, roger/roger.py:258-336 ----------------------------------------------------------
+    def setup(self):
+        from .core import soil, surface
+
+        for f in (self.set_parameters_setup, self.set_grid, self.set_topography, self.set_initial_conditions_setup,
+                  self.set_initial_conditions, self.set_boundary_conditions_setup, self.set_boundary_conditions,
+                  self.set_diagnostics, self.set_forcing_setup, self.after_timestep):
+            if not is_roger_routine(f):
+                raise RuntimeError(
+                    f"{f.__name__} method is not a roger routine. Please make sure to decorate it "
+                    "with @roger_routine and try again.")
+        state = self.state
+        with state.timers["setup"]:
+            with state.settings.unlock():
+                self.set_settings(state)
+                for setting, value in self.override_settings.items():
+                    setattr(state.settings, setting, value)
+            settings_mod.check_setting_conflicts(state.settings)
+            distributed.validate_decomposition(state.settings.nx, state.settings.ny, rs.num_proc,
+                                               rs.num_proc[0] * rs.num_proc[1])
+            state.initialize_variables()
+            self.set_grid(state)
+            self.set_topography(state)
+            self.set_look_up_tables(state)
+            self._upload_luts()
+            self.set_parameters_setup(state)
+            surface.calculate_parameters(state)
+            soil.calculate_parameters(state)
+            self.set_initial_conditions_setup(state)
+            self.set_initial_conditions(state)
+            surface.calculate_initial_conditions(state)
+            soil.calculate_initial_conditions(state)
+            self.set_diagnostics(state)
+            self.set_boundary_conditions_setup(state)
+            self.set_boundary_conditions(state)
+            self.set_forcing_setup(state)
+        self._setup_done = True
+        with state.settings.unlock():
+            state.settings.warmup_done = True
+
+    def _upload_luts(self):
+        vs = self.state.variables
+        self.state.backend_context.set_luts(vs.lut_ilu, vs.lut_gc, vs.lut_gcm, vs.lut_rdlu)
+
+    # -- one time step, roger/roger.py:355-489 ------------------------------------------------------
+    @roger_routine
+    def step(self, state):
+        self._ensure_setup_done()
+        with state.timers["main"]:
+            with state.timers["read data"]:
+                self.read_data(state)
+            with state.timers["boundary conditions"]:
+                self.set_boundary_conditions(state)
+            with state.timers["forcing"]:
+                self.set_forcing(state)
+            with state.timers["adaptive time-stepping"]:
+                run_native(state, "rh_adaptive_dt", ("prec", "ta", "pet", "pet_res"))
+            with state.timers["time-variant parameters"]:
+                self.set_parameters(state)
+            with state.timers["processes"]:
+                run_native(state, "rh_step_core")
+        self.after_timestep(state)
+        if rs.profile_mode:
+            state.backend_context.sync()
+            logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
+
+    def run(self, show_progress_bar=None):
+        """roger/roger.py:523-580"""
+        self._ensure_setup_done()
+        vs = self.state.variables
+        runlen = self.state.settings.runlen
+        start_time = vs.time
+        while vs.time - start_time < runlen:
+            self.step(self.state)
+        self.state.backend_context.sync()
+
+    # -- fast path --------------------------------------------------------------------------------
+    def enable_device_hooks(self):
+        """Hand the forcing series of set_forcing_setup (vs.PREC, vs.TA, vs.PET, vs.YEAR, vs.MONTH,
+        vs.DOY) to the device; `run_device` then performs the benchmark's set_forcing /
+        set_parameters hooks there."""
+        self._ensure_setup_done()
+        vs = self.state.variables
+        vs.flush_to_device()
+        self.state.backend_context.set_forcing_series(
+            dict(PREC=vs.PREC, TA=vs.TA, PET=vs.PET, YEAR=vs.YEAR, MONTH=vs.MONTH, DOY=vs.DOY))
+        self._device_hooks = True
+
+    def run_device(self, nsteps):
+        if not getattr(self, "_device_hooks", False):
+            self.enable_device_hooks()
+        vs = self.state.variables
+        vs.flush_to_device()
+        self.state.backend_context.run_steps(nsteps)
+        vs.mark_device_newer()

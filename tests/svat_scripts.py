@@ -1,0 +1,92 @@
+"""Setup scripts used by the host-package tests.  `GoldenSVAT` has the same hook bodies as the
+class tests/golden/make_golden.py drives through the *reference* (`from roger import ...` there,
+`from roger_amd import ...` here) -- the point of the operator surface is that such a script
+runs unchanged."""
+import numpy as np
+
+from roger_amd import roger_routine
+from roger_amd.core.operators import at, numpy as npx, update
+from roger_amd.models.svat import SVATSetup
+
+
+def make_model(params, forcing, ndays):
+    nx, ny = params["lu_id"].shape
+    F = forcing
+
+    class GoldenSVAT(SVATSetup):
+        @roger_routine
+        def set_settings(self, state):
+            s = state.settings
+            s.identifier = "GoldenSVAT"
+            s.nx, s.ny = nx, ny
+            s.runlen = 24 * 60 * 60 * ndays
+            s.nitt_forc = len(F["PREC"])
+            s.dx = 1
+            s.dy = 1
+            s.x_origin = 0.0
+            s.y_origin = 0.0
+            s.time_origin = "2018-01-01 00:00:00"
+            s.enable_groundwater_boundary = False
+            s.enable_macropore_lower_boundary_condition = False
+            s.enable_adaptive_time_stepping = True
+
+        @roger_routine
+        def set_parameters_setup(self, state):
+            vs = state.variables
+            for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf",
+                      "sealing", "S_dep_tot"):
+                setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], params[k]))
+
+        @roger_routine
+        def set_initial_conditions(self, state):
+            vs = state.variables
+            vs.theta_rz = update(vs.theta_rz, at[2:-2, 2:-2, : vs.taup1], params["theta_rz0"][:, :, None])
+            vs.theta_ss = update(vs.theta_ss, at[2:-2, 2:-2, : vs.taup1], params["theta_ss0"][:, :, None])
+
+        @roger_routine
+        def set_forcing_setup(self, state):
+            vs = state.variables
+            for k in ("PREC", "TA", "PET"):
+                setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
+            for k in ("YEAR", "MONTH", "DOY"):   # kept in vs so that run_device can hand them over
+                setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
+
+        @roger_routine
+        def set_forcing(self, state):
+            vs = state.variables
+            if vs.time % (24 * 60 * 60) == 0:
+                vs.itt_day = 0
+                vs.year = update(vs.year, at[1], F["YEAR"][vs.itt_forc])
+                vs.month = update(vs.month, at[1], F["MONTH"][vs.itt_forc])
+                vs.doy = update(vs.doy, at[1], F["DOY"][vs.itt_forc])
+                sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
+                vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
+                vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
+                vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
+                vs.itt_forc = vs.itt_forc + 6 * 24
+
+    return GoldenSVAT(forcing=F, nx=nx, ny=ny, ndays=ndays)
+
+
+def params_from_golden(g, names):
+    """Recover the raw user parameters of a golden case from its recorded states."""
+    nx, ny = (int(v) for v in g["nx_ny"])
+    pre, ic = g["pre_params"], g["pre_ic"]
+    p = {k: pre[names.index(k)].reshape(nx, ny) for k in
+         ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf", "sealing", "S_dep_tot")}
+    p["lu_id"] = p["lu_id"].astype(np.int32)
+    p["theta_rz0"] = ic[names.index("theta_rz")].reshape(nx, ny)
+    p["theta_ss0"] = ic[names.index("theta_ss")].reshape(nx, ny)
+    return p
+
+
+def snapshot_from_vs(vs, names):
+    cols = []
+    for nm in names:
+        if nm.endswith("_m1") and nm[:-3] in vs:
+            a = np.asarray(getattr(vs, nm[:-3]))[2:-2, 2:-2, 0]
+        else:
+            a = np.asarray(getattr(vs, nm))
+            a = a[2:-2, 2:-2, 1] if a.ndim == 3 else a[2:-2, 2:-2]
+        cols.append(np.asarray(a, dtype=np.float64).ravel())
+    return np.stack(cols)

@@ -1,0 +1,71 @@
+"""The C-ABI library loads and exports every entry point include/roger_hip.h declares; the
+generated load/store sets are up to date.  No compute calls (CPU-only suite)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(REPO, "include", "roger_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rh_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from roger_amd import _native
+    from roger_amd.build import build_native
+
+    build_native()
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 40
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, missing
+    # the binding declares the same set
+    assert sorted(_native.DECLARED_SYMBOLS) == declared
+
+
+def test_plane_registry_matches_fields_def():
+    from roger_amd import _native
+
+    txt = open(os.path.join(REPO, "include", "rh_fields.def")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    fields = re.findall(r"RH_FIELD\((\w+),\s*(\w+),\s*(\d)\)", txt)
+    expect = []
+    for name, typ, lv in fields:
+        expect.append((name, typ == "I32"))
+        if lv == "2":
+            expect.append((name + "_m1", typ == "I32"))
+    assert _native.plane_table() == expect
+    lib = _native.load()
+    assert lib.rh_plane_index(b"theta_rz_m1") == [n for n, _ in expect].index("theta_rz_m1")
+    assert lib.rh_plane_index(b"no_such_plane") == -1
+
+
+def test_generated_sets_are_current():
+    inc = os.path.join(REPO, "roger_amd", "csrc", "rh_sets.inc")
+    before = open(inc).read()
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_sets.py")], check=True)
+    assert open(inc).read() == before, "rh_sets.inc is stale: run tools/gen_sets.py"
+    # the fused step stores what the reference writes per step: 153 planes = 1224 B
+    m = re.search(r"// rt_step: loads (\d+) planes, stores (\d+) planes", before)
+    assert m and int(m.group(2)) == 153
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    from roger_amd import _native
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("a GPU is present")
+    import pytest
+
+    with pytest.raises(_native.NativeError, match="no CPU fallback"):
+        _native.Context(2, 2)

@@ -1,0 +1,132 @@
+"""Host package (operator surface mirroring the reference) on CPU, with the oracle standing in
+for the device through the OracleContext test double."""
+import numpy as np
+import pytest
+
+from golden_util import compare, load_case
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch, oracle):
+    import oracle_context
+    from roger_amd import _native
+
+    monkeypatch.setattr(_native, "Context", oracle_context.OracleContext)
+    monkeypatch.setattr(_native, "plane_table", lambda: list(zip(oracle.plane_names(), oracle.plane_is_int())))
+    return oracle_context
+
+
+def test_runtime_settings():
+    from roger_amd.runtime import RuntimeSettings
+
+    rs = RuntimeSettings()
+    assert rs.backend == "hip" and rs.float_type == "float64"
+    rs.update(num_proc=(2, 1), profile_mode="true")
+    assert rs.num_proc == (2, 1) and rs.profile_mode is True
+    with pytest.raises(ValueError):
+        rs.update(backend="numpy")          # roger/runtime.py:30-40 parse_choice
+    with pytest.raises(AttributeError):
+        rs.update(no_such_setting=1)
+    rs.__locked__ = True
+    with pytest.raises(RuntimeError):
+        rs.update(device="gpu")             # locked after core import, roger/core/__init__.py:42-44
+
+
+def test_operators_are_value_semantics():
+    from roger_amd.core.operators import at, update, update_add, update_multiply
+    from roger_amd.variables import allocate
+
+    a = allocate({"x": 2, "y": 3}, ("x", "y"))
+    assert a.shape == (6, 7) and not a.flags.writeable   # +4 ghosts, immutable (variables.py:6431-6433)
+    b = update(a, at[2:-2, 2:-2], 5.0)
+    assert a.sum() == 0 and b[2:-2, 2:-2].sum() == 30 and not b.flags.writeable
+    c = update_add(b, at[2, 2], 1.0)
+    d = update_multiply(c, at[2:-2, 2:-2], 2.0)
+    assert c[2, 2] == 6 and d[2, 2] == 12 and b[2, 2] == 5
+
+
+def test_variables_contract(oracle_backend):
+    """Shape/dtype validation and locking as roger/state.py:240-251,112-140."""
+    from roger_amd.state import RogerState
+
+    st = RogerState()
+    with st.settings.unlock():
+        st.settings.nx, st.settings.ny = 3, 2
+    with pytest.raises(RuntimeError):
+        st.settings.nx = 5                  # locked
+    with pytest.raises(RuntimeError):
+        st.variables                        # not initialised yet
+    st.initialize_variables()
+    vs = st.variables
+    assert vs.z_soil.shape == (7, 6) and vs.theta_rz.shape == (7, 6, 2) and vs.prec_day.shape == (7, 6, 144)
+    assert vs.ta[2, 2, 1] == 15 and vs.z_gw[3, 3, 0] == 1000 and bool(vs.maskCatch[2, 2])
+    assert vs.tau == 1 and vs.taum1 == 0 and vs.dt == 1 and vs.dt_secs == 3600 and list(vs.month) == [1, 1]
+    with pytest.raises(RuntimeError):
+        vs.z_soil = np.zeros((7, 6))        # locked outside routines
+    with vs.unlock():
+        with pytest.raises(ValueError):
+            vs.z_soil = np.zeros((3, 2))    # wrong shape
+        with pytest.raises(AttributeError):
+            vs.not_a_variable = 1
+        vs.z_soil = np.full((7, 6), 900.0)
+        vs.time = 86400
+    assert vs.time == 86400
+    vs.flush_to_device()
+    assert np.all(st.backend_context.download("z_soil") == 900.0)
+    assert st.backend_context.get_scalars().time == 86400
+
+
+@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain"])
+def test_setup_and_run_reproduce_reference(oracle_backend, case):
+    """The same setup script the golden generator ran through the reference, run through this
+    package: setup() state and the trajectory of step() match the reference."""
+    import svat_scripts as S
+
+    g, names, forcing = load_case(case)
+    ndays = len(forcing["PREC"]) // 144
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+    model.setup()
+    vs = model.state.variables
+    compare(S.snapshot_from_vs(vs, names), g["state0"], names, what=f"{case} after setup()")
+    nsteps = int(g["nsteps"])
+    for step in range(1, nsteps + 1):
+        model.step(model.state)
+        for i, k in enumerate(("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")):
+            assert getattr(vs, k) == g["scal"][step - 1][i], (step, k)
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case} step {step}")
+    assert vs.time >= model.state.settings.runlen
+
+
+def test_run_and_run_device_agree(oracle_backend):
+    """`run()` (user hooks on the host every step) and `run_device()` (hooks on the device) give
+    the same trajectory."""
+    import svat_scripts as S
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    ndays = 6
+    a = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+    b = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+    a.setup()
+    b.setup()
+    a.run()
+    nsteps = a.state.variables.itt
+    b.run_device(nsteps)
+    assert b.state.variables.time == a.state.variables.time
+    np.testing.assert_array_equal(S.snapshot_from_vs(a.state.variables, names), S.snapshot_from_vs(b.state.variables, names))
+
+
+def test_scope_errors(oracle_backend):
+    """Switches outside the hot path fail loudly instead of silently doing something else."""
+    import svat_scripts as S
+
+    g, names, forcing = load_case("svat_uniform_rain")
+    model = S.make_model(S.params_from_golden(g, names), forcing, 1)
+    model.override_settings = {"enable_lateral_flow": True}
+    with pytest.raises(NotImplementedError):
+        model.setup()
+    bad = S.params_from_golden(g, names)
+    bad["ks"] = bad["ks"] * -1
+    with pytest.raises(ValueError, match="ks-parameter is out of range"):
+        S.make_model(bad, forcing, 1).setup()   # numerics.validate_parameters_soil
