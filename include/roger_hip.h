@@ -180,6 +180,11 @@ int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64);
 int rh_enable_timing(rh_ctx *ctx, int on);
 int rh_timing_summary(rh_ctx *ctx, double *total_ms, int64_t *launches);
 
+/* Profiling aid: one kernel that copies `nplanes` float64 planes src_plane0.. -> dst_plane0.. with
+ * the access shape of the fused kernel (8 bytes per lane and plane); moves a known
+ * 2 * nplanes * n_cells * 8 bytes, used to calibrate the HBM counters.  Overwrites the planes. */
+int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes);
+
 #ifdef __cplusplus
 }
 #endif

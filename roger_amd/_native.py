@@ -92,6 +92,7 @@ def load():
     lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
     lib.rh_predicates_expand.argtypes = [vp, i32, vp]
     lib.rh_predicates_compress.argtypes = [vp, i32, vp]
+    lib.rh_calibrate_copy.argtypes = [vp, i32, i32, i32]
     lib.rh_predicate_words.argtypes = [vp]
     lib.rh_predicate_words.restype = vp
     lib.rh_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -108,7 +109,7 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy",
 )
 
 
@@ -237,6 +238,9 @@ class Context:
     def predicates_compress(self, word, dev_ptr):
         self._check(self._lib.rh_predicates_compress(self._h, int(word), C.c_void_p(dev_ptr)),
                     "rh_predicates_compress")
+
+    def calibrate_copy(self, src_plane0, dst_plane0, nplanes):
+        self._check(self._lib.rh_calibrate_copy(self._h, src_plane0, dst_plane0, nplanes), "rh_calibrate_copy")
 
     def predicate_words_ptr(self):
         return self._lib.rh_predicate_words(self._h)

@@ -578,6 +578,23 @@ __global__ void k_inf_conds(DevState *D) {
     D->words[3] = 0;
 }
 
+// Counter calibration (profiles/): copies `nplanes` float64 planes with the access shape of k_step
+// (one 8-byte element per lane and plane), so FETCH_SIZE / WRITE_SIZE can be scaled on a known
+// byte count as MI355X_MICROARCH.md prescribes for access widths other than 16 B per lane.
+__global__ __launch_bounds__(RH_BLOCK) void k_calib_copy(Arena a, int src0, int dst0, int nplanes) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    double v[32];
+    for (int p0 = 0; p0 < nplanes; p0 += 32) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (p0 + k < nplanes) rh_ld(a, src0 + p0 + k, i, v[k]);
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (p0 + k < nplanes) rh_st(a, dst0 + p0 + k, i, v[k]);
+    }
+}
+
 // initial values of the variable registry that are not zero (roger/variables.py `initial=`)
 __global__ __launch_bounds__(RH_BLOCK) void k_init_registry(Arena a) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -1052,6 +1069,17 @@ int rh_predicates_expand(rh_ctx *ctx, int word, int32_t *dev_dst64) {
 int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64) {
     if (!ctx || word < 0 || word > 3 || !dev_src64) return RH_ERR_ARG;
     hipLaunchKernelGGL(k_words_compress, dim3(1), dim3(64), 0, ctx->stream, ctx->dev, word, dev_src64);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
+int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) {
+    if (!ctx || nplanes <= 0 || src_plane0 < 0 || dst_plane0 < 0 || src_plane0 + nplanes > RH_NPLANES ||
+        dst_plane0 + nplanes > RH_NPLANES)
+        return RH_ERR_ARG;
+    for (int p = 0; p < nplanes; ++p)
+        if (PLANE_IS_INT[src_plane0 + p] || PLANE_IS_INT[dst_plane0 + p]) return fail(ctx, RH_ERR_ARG, "calibration planes must be float64");
+    hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }

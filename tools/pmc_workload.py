@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Workload for the PMC passes: a calibration copy of known size, then fused SVAT steps.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/pmc_workload.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/pmc_workload.py
+
+tools/pmc_summarise.py turns the two counter CSVs into profiles/traffic.json.
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from roger_amd import _native as N          # noqa: E402
+from roger_amd.forcing import combo_forcing  # noqa: E402
+from roger_amd.svat import create_svat        # noqa: E402
+
+NX, NY = (int(v) for v in os.environ.get("RH_PMC_SIZE", "1000x1000").split("x"))
+CALIB_PLANES = 96
+
+if __name__ == "__main__":
+    scratch = N.Context(NX, NY)
+    first = next(i for i, (_, is_int) in enumerate(scratch.planes) if not is_int)
+    for _ in range(5):
+        scratch.calibrate_copy(first, first + 100, CALIB_PLANES)
+    scratch.sync()
+    scratch.close()
+    ctx = create_svat(NX, NY)
+    ctx.set_forcing_series(combo_forcing(ndays=30))
+    ctx.run_steps(25)
+    ctx.sync()
+    ctx.close()
