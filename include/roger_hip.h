@@ -52,11 +52,14 @@ typedef struct rh_config {
     int64_t nx, ny;   /* local interior grid of this rank (reference arrays carry +4 ghosts per
                          axis, roger/variables.py:170-173; the arena stores the interior only) */
     int32_t device;   /* HIP device ordinal */
-    int32_t reserved;
+    int32_t enable_lateral_flow; /* settings.enable_lateral_flow: the oneD model (roger/models/oneD), lateral
+                                    subsurface runoff (core/subsurface_runoff.py:1456-1471) and its num-error /
+                                    after_timestep variants */
     double pi, r_mp, l_sc, sf, ta_fm, rmax, transp_water_stress, atol, rtol;
     double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
     double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
     int64_t end_event, hpi;
+    double dx;        /* settings.dx, grid spacing in m (enters the lateral flow rates) */
 } rh_config;
 
 /* Per-domain scalars of the reference (roger/variables.py:189-330).  event_id/year/month/doy
@@ -105,6 +108,10 @@ int rh_get_scalars(rh_ctx *ctx, rh_scalars *s); /* synchronises */
  * (25,2), vs.lut_rdlu (25,7)), row-major float64. */
 int rh_set_luts(rh_ctx *ctx, const double *ilu, const double *gc, const double *gcm, const double *rdlu);
 
+/* vs.lut_mlms (n_slope, 9): horizontal macropore flow velocities by slope (roger/lookuptables.py ARR_MLMS),
+ * needed by rh_params_lateral (oneD model).  Row-major float64; nrows <= 10000. */
+int rh_set_lut_mlms(rh_ctx *ctx, const double *mlms, int64_t nrows);
+
 /* Forcing of the current day: what `set_forcing` assigns to vs.prec_day / vs.ta_day /
  * vs.pet_day (benchmarks/SVAT_benchmark.py:151-171).  per_cell == 0: three vectors of 144
  * values shared by all cells (the broadcast the benchmark performs); per_cell != 0: three
@@ -124,6 +131,7 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
 int rh_topo(rh_ctx *ctx);               /* surface.calc_topo_kernel, roger/core/surface.py:40-71 */
 int rh_params_surface(rh_ctx *ctx);     /* calc_parameters_surface_kernel, surface.py:74-343 */
 int rh_params_soil(rh_ctx *ctx);        /* soil.calculate_parameters, roger/core/soil.py:143-557,727-739 */
+int rh_params_lateral(rh_ctx *ctx);     /* calc_parameters_lateral_flow_kernel, roger/core/soil.py:560-641 (oneD) */
 int rh_initial_conditions(rh_ctx *ctx); /* surface/soil.calculate_initial_conditions, surface.py:398-427, soil.py:742-1010 */
 
 /* ---- one entry point per routine of RogerSetup.step (roger/roger.py:396-457,485) ---------- */

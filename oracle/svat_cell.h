@@ -74,7 +74,19 @@
     X(F2, z_sat) X(F, S_zsat) X(F, S_zsat_rz) X(F, S_zsat_ss) X(F, q_pot_rz)    \
     X(F, q_rz) X(F, q_pot_ss) X(F, q_ss) X(F, cpr_rz)                           \
     /* numerics */                                                              \
-    X(F, dS_num_error) X(F, dS_rz_num_error) X(F, dS_ss_num_error)
+    X(F, dS_num_error) X(F, dS_rz_num_error) X(F, dS_ss_num_error)              \
+    /* lateral subsurface flow (oneD) */                                        \
+    X(I, slope_per) X(F, slope) X(F, dmph)                                      \
+    X(F2, z_sat_layer_1) X(F2, z_sat_layer_2) X(F2, z_sat_layer_3)              \
+    X(F2, z_sat_layer_4) X(F2, z_sat_layer_5) X(F2, z_sat_layer_6)              \
+    X(F2, z_sat_layer_7) X(F2, z_sat_layer_8)                                   \
+    X(F, v_mp_layer_1) X(F, v_mp_layer_2) X(F, v_mp_layer_3) X(F, v_mp_layer_4) \
+    X(F, v_mp_layer_5) X(F, v_mp_layer_6) X(F, v_mp_layer_7) X(F, v_mp_layer_8) \
+    X(F, q_sub_mat_pot) X(F, q_sub_mp_pot) X(F, q_sub_pot) X(F, q_sub_mat_share)\
+    X(F, q_sub_mp_share) X(F, q_sub_rz) X(F, q_sub_mat_rz) X(F, q_sub_mp_rz)    \
+    X(F, q_sub_mp_pot_rz) X(F, q_sub_mat_pot_ss) X(F, q_sub_mp_pot_ss)          \
+    X(F, q_sub_pot_ss) X(F, q_sub_ss) X(F, q_sub_mat_ss) X(F, q_sub_mp_ss)      \
+    X(F, q_sub_mat) X(F, q_sub_mp) X(F, q_sub)
 
 typedef struct oc_cell {
 #define OC_DECL_F(n) double n;
@@ -104,6 +116,8 @@ typedef struct oc_settings {
     double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
     double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
     int64_t end_event, hpi;
+    int64_t enable_lateral_flow; /* oneD model: lateral subsurface runoff, settings.py:88 */
+    double dx;                   /* grid spacing (m), enters the lateral flow rates */
 } oc_settings;
 
 #endif

@@ -968,8 +968,112 @@ static void surface_runoff_cell(oc_cell *c) { /* calc_surface_runoff :1480-1516 
 /* ======================================================================== */
 /* a10 subsurface runoff, SVAT branch: roger/core/subsurface_runoff.py        */
 /* ======================================================================== */
-static void subsurface_runoff_cell(oc_cell *c, double dt) {
+/* oneD model: saturated thickness per 200 mm layer, subsurface_runoff.py:51-245 */
+static void z_sat_layer_cell(oc_cell *c) {
     const double mk = (double)c->maskCatch;
+    double *L[8] = {&c->z_sat_layer_1, &c->z_sat_layer_2, &c->z_sat_layer_3, &c->z_sat_layer_4,
+                    &c->z_sat_layer_5, &c->z_sat_layer_6, &c->z_sat_layer_7, &c->z_sat_layer_8};
+    for (int k = 0; k < 8; ++k) {
+        double v = (k == 0) ? c->z_sat * mk : c->z_sat - (200.0 * k) * mk;
+        if (k < 7) v = (v > 200 ? 200 : v) * mk;
+        v = (v <= 0 ? 0 : v) * mk;
+        *L[k] = v;
+    }
+}
+
+/* calc_potential_lateral_subsurface_runoff :248-372 */
+static void pot_lateral_cell(oc_cell *c, const oc_settings *st, double dt) {
+    const double mk = (double)c->maskCatch;
+    const double dx = st->dx, r2 = st->r_mp * st->r_mp;
+    const double per_len = (1 / (dx * (c->z_soil / 1000)));
+    c->q_sub_mat_pot = ((c->ks * c->slope * c->z_sat * dx * 1000 * dt) * 1e-6 * per_len) * mk;
+    c->q_sub_mat_pot = (c->z_sat <= 0 ? 0 : c->q_sub_mat_pot) * mk;
+    const double zl[8] = {c->z_sat_layer_1, c->z_sat_layer_2, c->z_sat_layer_3, c->z_sat_layer_4,
+                          c->z_sat_layer_5, c->z_sat_layer_6, c->z_sat_layer_7, c->z_sat_layer_8};
+    const double vl[8] = {c->v_mp_layer_1, c->v_mp_layer_2, c->v_mp_layer_3, c->v_mp_layer_4,
+                          c->v_mp_layer_5, c->v_mp_layer_6, c->v_mp_layer_7, c->v_mp_layer_8};
+    double sum = 0;
+    for (int k = 0; k < 8; ++k) {
+        double term = zl[k] * vl[k] * dt * dx * 1000 * c->dmph * 1e-6 * r2 * st->pi * 1e-6;
+        sum = (k == 0) ? term : sum + term;
+    }
+    c->q_sub_mp_pot = (sum * per_len) * mk;
+    c->q_sub_mp_pot = (c->q_sub_mp_pot < 0 ? 0 : c->q_sub_mp_pot) * mk;
+    c->q_sub_mp_pot = (c->z_sat <= 0 ? 0 : c->q_sub_mp_pot) * mk;
+    c->q_sub_pot = (c->q_sub_mp_pot + c->q_sub_mat_pot) * mk;
+    c->q_sub_mat_share = (c->q_sub_mat_pot / c->q_sub_pot) * mk;
+    c->q_sub_mat_share = (c->q_sub_pot == 0 ? 0 : c->q_sub_mat_share) * mk;
+    c->q_sub_mp_share = (c->q_sub_mp_pot / c->q_sub_pot) * mk;
+    c->q_sub_mp_share = (c->q_sub_pot == 0 ? 0 : c->q_sub_mp_share) * mk;
+    int mask1 = c->q_sub_pot > c->S_lp_rz + c->S_lp_ss;
+    c->q_sub_pot = (mask1 ? c->S_lp_rz + c->S_lp_ss : c->q_sub_pot) * mk;
+    c->q_sub_mat_pot = c->q_sub_pot * c->q_sub_mat_share * mk;
+    c->q_sub_mp_pot = c->q_sub_pot * c->q_sub_mp_share * mk;
+}
+
+/* calc_lateral_subsurface_runoff_rz :375-457 */
+static void lateral_rz_cell(oc_cell *c) {
+    const double mk = (double)c->maskCatch;
+    double share = (c->z_sat > 0 ? ((c->z_sat - (c->z_soil - c->z_root)) / c->z_sat) : 0) * mk;
+    int mask1 = (c->z_sat <= c->z_soil - c->z_root) || (c->S_lp_rz <= 0);
+    share = (mask1 ? 0 : share) * mk;
+    share = (isnan(share) ? 0 : share) * mk;
+    c->S_zsat_rz = ((c->z_sat * share) * c->theta_ac) * mk;
+    c->q_sub_rz = (c->q_sub_pot * share < c->S_zsat_rz ? c->q_sub_pot * share : c->S_zsat_rz) * mk;
+    c->q_sub_mat_rz = c->q_sub_rz * c->q_sub_mat_share * mk;
+    c->q_sub_mp_rz = c->q_sub_rz * c->q_sub_mp_share * mk;
+    c->q_sub_mp_pot_rz = c->q_sub_mp_pot * share * mk;
+    c->z_sat += -c->q_sub_rz / c->theta_ac * mk;
+    c->S_lp_rz += -c->q_sub_rz * mk;
+}
+
+/* calc_potential_lateral_subsurface_runoff_ss :460-515 */
+static void pot_lateral_ss_cell(oc_cell *c) {
+    const double mk = (double)c->maskCatch;
+    double share = ((c->z_soil - c->z_root) / c->z_sat) * mk;
+    int mask1 = (c->z_sat <= c->z_soil - c->z_root) || (c->S_lp_rz <= 0);
+    int mask2 = c->z_sat <= 0;
+    int mask3 = isnan(share);
+    share = (mask1 ? 1 : share) * mk;
+    share = (mask2 ? 0 : share) * mk;
+    share = (mask3 ? 0 : share) * mk;
+    c->q_sub_mat_pot_ss = c->q_sub_mat_pot * share * mk;
+    c->q_sub_mp_pot_ss = c->q_sub_mp_pot * share * mk;
+    c->q_sub_pot_ss = (c->q_sub_mat_pot_ss + c->q_sub_mp_pot_ss) * mk;
+}
+
+/* calc_lateral_subsurface_runoff_ss :518-659, calc_lateral_subsurface_runoff :662-690 */
+static void lateral_ss_cell(oc_cell *c) {
+    const double mk = (double)c->maskCatch;
+    c->q_ss = 0;
+    c->q_ss = (c->z_sat <= 0 ? c->q_pot_ss : c->q_ss) * mk;
+    double tot = c->q_pot_ss + c->q_sub_pot_ss;
+    double fv = (tot > 0 ? c->q_pot_ss / tot : 0) * mk;
+    double fl = (tot > 0 ? c->q_sub_pot_ss / tot : 0) * mk;
+    double q_ss_sat = (tot <= c->S_zsat_ss ? tot * fv : c->S_zsat_ss * fv) * mk;
+    c->q_ss = (c->z_sat > 0 ? q_ss_sat : c->q_ss);
+    c->q_sub_ss = 0;
+    c->q_sub_ss = (tot <= c->S_zsat_ss ? tot * fl : c->S_zsat_ss * fl) * mk;
+    c->q_sub_mat_ss = c->q_sub_ss * c->q_sub_mat_share * mk;
+    c->q_sub_mp_ss = c->q_sub_ss * c->q_sub_mp_share * mk;
+    int mask1 = c->S_lp_ss < c->q_ss;
+    int mask2 = c->S_lp_ss >= c->q_ss;
+    c->S_fp_ss += (mask1 ? -(c->q_ss - c->S_lp_ss) : 0) * mk;
+    c->S_lp_ss = (mask1 ? 0 : c->S_lp_ss) * mk;
+    c->S_lp_ss += (mask2 ? -c->q_ss : 0) * mk;
+    int mask = c->z_sat > 0;
+    c->S_lp_ss += (mask ? -c->q_sub_ss : 0) * mk;
+    c->z_sat += -((c->q_sub_ss + c->q_ss) / c->theta_ac) * mk;
+    c->z_sat = (c->z_sat < 0 ? 0 : c->z_sat) * mk;
+    c->S_zsat = c->z_sat * c->theta_ac * mk;
+    c->q_sub_mat = (c->q_sub_mat_rz + c->q_sub_mat_ss) * mk;
+    c->q_sub_mp = (c->q_sub_mp_rz + c->q_sub_mp_ss) * mk;
+    c->q_sub = (c->q_sub_rz + c->q_sub_ss) * mk;
+}
+
+static void subsurface_runoff_cell(oc_cell *c, double dt, const oc_settings *st) {
+    const double mk = (double)c->maskCatch;
+    const int lateral = (int)st->enable_lateral_flow;
     /* calc_rise_of_saturation_water_table :693-765 */
     {
         double lmpv_ss = c->lmpv - c->z_root * mk;
@@ -992,6 +1096,7 @@ static void subsurface_runoff_cell(oc_cell *c, double dt) {
         c->S_zsat_ss = (c->z_sat <= c->z_soil - c->z_root ? c->S_zsat : (c->z_soil - c->z_root) * c->theta_ac) * mk;
         c->S_zsat_rz = (c->z_sat > c->z_soil - c->z_root ? (c->z_sat - (c->z_soil - c->z_root)) * c->theta_ac : 0) * mk;
     }
+    if (lateral) z_sat_layer_cell(c);
     /* calc_potential_percolation_rz :768-896 */
     {
         int mask1 = (c->z_wf < c->z_root) && (c->z_sat <= 0);
@@ -1040,6 +1145,11 @@ static void subsurface_runoff_cell(oc_cell *c, double dt) {
         c->S_lp_rz += (m ? c->S_lp_ss - c->S_ac_ss : 0) * mk;
         c->S_lp_ss = (m ? c->S_ac_ss : c->S_lp_ss) * mk;
     }
+    if (lateral) {
+        pot_lateral_cell(c, st, dt);
+        lateral_rz_cell(c);
+        pot_lateral_ss_cell(c);
+    }
     /* calc_potential_percolation_ss :971-1098 (the second perc_pot assignment replaces the first) */
     {
         double z = (c->z_gw * 1000 - c->z_soil) + ((c->z_soil - c->z_root) / 2) * mk;
@@ -1062,6 +1172,10 @@ static void subsurface_runoff_cell(oc_cell *c, double dt) {
         int mask3 = (c->z_gw * 1000 - c->z_soil > 10000);
         cpr_pot = (mask3 ? 0 : cpr_pot) * mk;
         c->q_pot_ss = (cpr_pot > 0 ? 0 : c->q_pot_ss) * mk;
+    }
+    if (lateral) {
+        lateral_ss_cell(c);
+        return;
     }
     /* calc_percolation_ss :1101-1154 */
     {
@@ -1159,6 +1273,10 @@ static int np_isclose(double a, double b, double atol, double rtol) {
 static double nan0(double x) { return isnan(x) ? 0 : x; }
 
 static int num_error_cell(oc_cell *c, const oc_settings *st) {
+    if (st->enable_lateral_flow) { /* numerics.py:226-245: only dS_num_error in this branch */
+        c->dS_num_error = fabs((c->S - c->S_m1) - (c->prec - c->q_sur - c->aet - c->q_ss - c->q_sub));
+        return 0;
+    }
     c->dS_num_error = fabs((c->S - c->S_m1) - (c->prec - c->q_sur - c->aet - c->q_ss));
     c->dS_rz_num_error = fabs((c->S_rz - c->S_rz_m1) - (c->inf_mat_rz + c->inf_mp_rz + c->inf_sc_rz + c->cpr_rz -
                                                         c->transp - c->evap_soil - c->q_rz));
@@ -1166,7 +1284,9 @@ static int num_error_cell(oc_cell *c, const oc_settings *st) {
     return 0;
 }
 static int sanity_cell(const oc_cell *c, const oc_settings *st) {
-    int check1 = c->maskCatch ? np_isclose(c->S - c->S_m1, c->prec - c->q_sur - c->aet - c->q_ss, st->atol, st->rtol) : 1;
+    double rhs = st->enable_lateral_flow ? c->prec - c->q_sur - c->aet - c->q_ss - c->q_sub /* numerics.py:744-759 */
+                                         : c->prec - c->q_sur - c->aet - c->q_ss;
+    int check1 = c->maskCatch ? np_isclose(c->S - c->S_m1, rhs, st->atol, st->rtol) : 1;
     int check2 = (nan0(c->S_fp_rz) > -st->atol) && (nan0(c->S_lp_rz) > -st->atol) && (nan0(c->S_fp_ss) > -st->atol) &&
                  (nan0(c->S_lp_ss) > -st->atol);
     int check3 = (nan0(c->S_fp_rz) - st->atol <= nan0(c->S_ufc_rz)) && (nan0(c->S_lp_rz) - st->atol <= nan0(c->S_ac_rz)) &&
@@ -1176,7 +1296,7 @@ static int sanity_cell(const oc_cell *c, const oc_settings *st) {
 
 /* a14 after_timestep_kernel: roger/models/svat/svat.py:187-384 */
 static double snap0(double x) { return ((x > -1e-6) && (x < 0)) ? 0 : x; }
-static void after_timestep_cell(oc_cell *c) {
+static void after_timestep_cell(oc_cell *c, int snap) {
     c->ta_m1 = c->ta;
     c->z_root_m1 = c->z_root;
     c->ground_cover_m1 = c->ground_cover;
@@ -1206,10 +1326,12 @@ static void after_timestep_cell(oc_cell *c) {
     c->h_ss_m1 = c->h_ss;
     c->h_m1 = c->h;
     c->z0_m1 = c->z0;
-    c->S_fp_rz = snap0(c->S_fp_rz);
-    c->S_lp_rz = snap0(c->S_lp_rz);
-    c->S_fp_ss = snap0(c->S_fp_ss);
-    c->S_lp_ss = snap0(c->S_lp_ss);
+    if (snap) { /* models/svat/svat.py:326-345; the oneD model's kernel has no such lines */
+        c->S_fp_rz = snap0(c->S_fp_rz);
+        c->S_lp_rz = snap0(c->S_lp_rz);
+        c->S_fp_ss = snap0(c->S_fp_ss);
+        c->S_lp_ss = snap0(c->S_lp_ss);
+    }
     c->prec_m1 = c->prec;
 }
 
@@ -1351,6 +1473,24 @@ static void params_soil_cell(oc_cell *c, const oc_luts *L, const oc_settings *st
     c->S_fc_ss = ((c->theta_ufc + c->theta_pwp) * dz) * mk;
 }
 
+/* calc_parameters_lateral_flow_kernel: soil.py:560-641.  lut_mlms is (10000, 9): slope in percent,
+ * then the macropore flow velocity (m/h) of layers 8..1 */
+static void params_lateral_cell(oc_cell *c, const double *mlms, int64_t nrows, int max_slope_per) {
+    const double mk = (double)c->maskCatch;
+    double *V[8] = {&c->v_mp_layer_1, &c->v_mp_layer_2, &c->v_mp_layer_3, &c->v_mp_layer_4,
+                    &c->v_mp_layer_5, &c->v_mp_layer_6, &c->v_mp_layer_7, &c->v_mp_layer_8};
+    int key = c->slope_per;
+    int hit = (key >= 1) && (key <= max_slope_per);
+    int64_t row = 0; /* utilities._get_row_no: first match, else row 0 */
+    if (hit)
+        for (int64_t r = 0; r < nrows; ++r)
+            if (mlms[r * 9] == (double)key) { row = r; break; }
+    for (int k = 0; k < 8; ++k) {
+        double v = hit ? mlms[row * 9 + (8 - k)] * 1000 : 0.0;
+        *V[k] = (v * mk) * mk;
+    }
+}
+
 static void initial_conditions_cell(oc_cell *c) {
     const double mk = (double)c->maskCatch;
     /* surface.calc_initial_conditions_surface_kernel :398-414 */
@@ -1460,8 +1600,8 @@ void oc_infiltration(void *const *planes, int64_t n, const oc_scalars *s, const 
     inf_conds k = infiltration_conds(planes, n, s);
     FOR_CELLS(infiltration_cell(c, st, s->dt, k))
 }
-void oc_subsurface_runoff(void *const *planes, int64_t n, const oc_scalars *s) {
-    FOR_CELLS(subsurface_runoff_cell(c, s->dt))
+void oc_subsurface_runoff(void *const *planes, int64_t n, const oc_scalars *s, const oc_settings *st) {
+    FOR_CELLS(subsurface_runoff_cell(c, s->dt, st))
 }
 void oc_capillary_rise(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(capillary_rise_cell(c, s->dt)) }
 void oc_storage(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(storage_cell(c, s->month[1])) }
@@ -1471,8 +1611,8 @@ int oc_num_error(void *const *planes, int64_t n, oc_scalars *s, const oc_setting
     s->sanity_ok = ok;
     return ok;
 }
-void oc_after_timestep(void *const *planes, int64_t n, oc_scalars *s) {
-    FOR_CELLS(after_timestep_cell(c))
+void oc_after_timestep(void *const *planes, int64_t n, oc_scalars *s, const oc_settings *st) {
+    FOR_CELLS(after_timestep_cell(c, !st->enable_lateral_flow))
     s->event_id[0] = s->event_id[1];
     s->year[0] = s->year[1];
     s->month[0] = s->month[1];
@@ -1488,6 +1628,12 @@ void oc_params_soil(void *const *planes, int64_t n, const oc_settings *st, const
                     const double *gcm, const double *rdlu) {
     oc_luts L = {ilu, gc, gcm, rdlu};
     FOR_CELLS(params_soil_cell(c, &L, st))
+}
+void oc_params_lateral(void *const *planes, int64_t n, const double *mlms, int64_t nrows) {
+    const int32_t *sp = planes[plane_index("slope_per")];
+    int mx = 0;
+    for (int64_t i = 0; i < n; ++i) mx = sp[i] > mx ? sp[i] : mx;
+    FOR_CELLS(params_lateral_cell(c, mlms, nrows, mx))
 }
 void oc_initial_conditions(void *const *planes, int64_t n) { FOR_CELLS(initial_conditions_cell(c)) }
 
@@ -1508,12 +1654,12 @@ int oc_step_after_adt(void *const *planes, int64_t n, oc_scalars *s, const oc_se
         evapotranspiration_cell(c, st);
         snow_cell(c, st, s->dt);
         infiltration_cell(c, st, s->dt, k);
-        subsurface_runoff_cell(c, s->dt);
+        subsurface_runoff_cell(c, s->dt, st);
         capillary_rise_cell(c, s->dt);
         storage_cell(c, s->month[1]);
         ok &= sanity_cell(c, st);
         num_error_cell(c, st);
-        if (!core_only) after_timestep_cell(c);)
+        if (!core_only) after_timestep_cell(c, !st->enable_lateral_flow);)
     s->sanity_ok = ok;
     if (!core_only) {
         s->event_id[0] = s->event_id[1];

@@ -13,12 +13,12 @@ LIB_PATH = os.path.join(PKG, "libroger_hip.so")
 
 
 class RhConfig(C.Structure):
-    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("device", C.c_int32), ("reserved", C.c_int32)] + [
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("device", C.c_int32), ("enable_lateral_flow", C.c_int32)] + [
         (k, C.c_double) for k in (
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min",
             "clay_max", "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max",
             "a_bc", "b_bc")
-    ] + [("end_event", C.c_int64), ("hpi", C.c_int64)]
+    ] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("dx", C.c_double)]
 
 
 class RhScalars(C.Structure):
@@ -39,7 +39,7 @@ _lib = None
 _ENTRY_POINTS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
-    "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core",
+    "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core", "rh_params_lateral",
 )
 
 
@@ -84,6 +84,7 @@ def load():
     lib.rh_get_scalars.argtypes = [vp, C.POINTER(RhScalars)]
     lib.rh_set_luts.argtypes = [vp, vp, vp, vp, vp]
     lib.rh_set_forcing_day.argtypes = [vp, vp, vp, vp, i32]
+    lib.rh_set_lut_mlms.argtypes = [vp, vp, i64]
     for name in _ENTRY_POINTS:
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
@@ -109,7 +110,7 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
 )
 
 
@@ -191,6 +192,12 @@ class Context:
             if a.shape != shape:
                 raise ValueError(f"look-up table has shape {a.shape}, expected {shape}")
         self._check(self._lib.rh_set_luts(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), "rh_set_luts")
+
+    def set_lut_mlms(self, mlms):
+        a = np.ascontiguousarray(mlms, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 9:
+            raise ValueError(f"lut_mlms has shape {a.shape}, expected (n_slope, 9)")
+        self._check(self._lib.rh_set_lut_mlms(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0]), "rh_set_lut_mlms")
 
     def set_forcing_day(self, prec_day, ta_day, pet_day):
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (prec_day, ta_day, pet_day)]

@@ -8,6 +8,8 @@ def calculate_parameters(state):
     """roger/core/soil.py:727-739"""
     numerics.validate_parameters_soil(state)
     run_native(state, "rh_params_soil")
+    if state.settings.enable_lateral_flow:
+        run_native(state, "rh_params_lateral")   # calc_parameters_lateral_flow_kernel, soil.py:560-641
 
 
 @roger_routine

@@ -53,6 +53,8 @@ struct Consts {
     double clay_min, clay_max, theta_rew_min, theta_rew_max, rew_min, rew_max;
     double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
     int64_t end_event, hpi;
+    double dx;      // grid spacing in m (settings.dx), enters the lateral flow rates
+    int lateral;    // settings.enable_lateral_flow (oneD model)
 };
 
 // Look-up tables, row-major (roger/lookuptables.py).

@@ -612,29 +612,28 @@ RH_DEV double h_salvucci(double z, double hpot, double ha, double n) {
     return (p1 - p2) / (1 + p2 + (n - 1) * p1);
 }
 
-RH_DEV void rt_subsurface_runoff(Col &c, const StepCtx &X) {
-    const double mk = (double)c.maskCatch;
-    const double dt = X.dt;
+// perched water table :693-765 and its storage :7-48
+RH_DEV void h_sub_water_table(Col &c, double mk) {
     const double dz_ss = c.z_soil - c.z_root;
-    // perched water table :693-765
-    {
-        double lmpv_ss = c.lmpv - c.z_root * mk;
-        lmpv_ss = (c.lmpv < c.z_root ? 0.0 : lmpv_ss) * mk;
-        const double lp_ss_mm = c.S_lp_ss / c.theta_ac;
-        const double top = (c.S_lp_ss < c.theta_ac ? lp_ss_mm : c.S_lp_rz + lp_ss_mm) * mk;
-        double nomp = dz_ss - lmpv_ss - c.z_sat * mk;
-        nomp = (nomp < 0 ? 0.0 : nomp);
-        const double risen = ((c.S_fp_ss >= c.S_ufc_ss) && (((c.S_lp_ss + 1e-6) / c.theta_ac) < dz_ss))
-                                 ? lp_ss_mm
-                                 : (((c.S_fp_rz >= c.S_ufc_rz) && (c.S_lp_ss + 1e-6 >= c.S_ac_ss)) ? c.S_lp_rz / c.theta_ac + lp_ss_mm
-                                                                                                     : lp_ss_mm);
-        c.z_sat = (top > nomp ? risen : lp_ss_mm) * mk;
-    }
-    // :7-48
+    double lmpv_ss = c.lmpv - c.z_root * mk;
+    lmpv_ss = (c.lmpv < c.z_root ? 0.0 : lmpv_ss) * mk;
+    const double lp_ss_mm = c.S_lp_ss / c.theta_ac;
+    const double top = (c.S_lp_ss < c.theta_ac ? lp_ss_mm : c.S_lp_rz + lp_ss_mm) * mk;
+    double nomp = dz_ss - lmpv_ss - c.z_sat * mk;
+    nomp = (nomp < 0 ? 0.0 : nomp);
+    const double risen = ((c.S_fp_ss >= c.S_ufc_ss) && (((c.S_lp_ss + 1e-6) / c.theta_ac) < dz_ss))
+                             ? lp_ss_mm
+                             : (((c.S_fp_rz >= c.S_ufc_rz) && (c.S_lp_ss + 1e-6 >= c.S_ac_ss)) ? c.S_lp_rz / c.theta_ac + lp_ss_mm
+                                                                                                 : lp_ss_mm);
+    c.z_sat = (top > nomp ? risen : lp_ss_mm) * mk;
     c.S_zsat = (c.z_sat <= c.z_soil ? c.z_sat * c.theta_ac : c.z_soil * c.theta_ac) * mk;
     c.S_zsat_ss = (c.z_sat <= dz_ss ? c.S_zsat : dz_ss * c.theta_ac) * mk;
     c.S_zsat_rz = (c.z_sat > dz_ss ? (c.z_sat - dz_ss) * c.theta_ac : 0.0) * mk;
-    // potential percolation root zone :768-896
+}
+
+// potential + actual percolation out of the root zone :768-968
+RH_DEV void h_sub_percolation_rz(Col &c, double dt, double mk) {
+    const double dz_ss = c.z_soil - c.z_root;
     {
         const bool dryb = c.z_sat <= 0;
         const bool m3 = (c.z_sat > 0) && (c.z_root < c.z_soil - c.z_sat);
@@ -653,7 +652,6 @@ RH_DEV void rt_subsurface_runoff(Col &c, const StepCtx &X) {
         q = (c.z_root_m1 >= c.z_soil - c.z_sat ? 0.0 : q) * mk;
         c.q_pot_rz = q;
     }
-    // percolation root zone :900-968
     {
         const bool above = c.z_sat < dz_ss;
         const bool m1 = (c.S_lp_rz < c.q_pot_rz) && above, m2 = (c.S_lp_rz >= c.q_pot_rz) && above;
@@ -672,33 +670,145 @@ RH_DEV void rt_subsurface_runoff(Col &c, const StepCtx &X) {
         c.S_lp_rz += (m ? back : 0.0) * mk;
         c.S_lp_ss = (m ? c.S_ac_ss : c.S_lp_ss) * mk;
     }
-    // potential percolation subsoil :971-1098 (the second of the two assignments is the live one)
-    {
-        const double zgw = c.z_gw * 1000;
-        const double z = (zgw - c.z_soil) + (dz_ss / 2) * mk;
-        const double sal = h_salvucci(z, c.h_ss, c.ha, c.n_salv);
-        const bool shallow = (c.z_gw <= 10) && (zgw > c.z_soil) && (c.z_sat > 0);
-        double perc = shallow ? fmin(fmin(c.kf * dt, c.ks_ss * dt), c.k_ss * dt) : fmin(c.kf * dt, sal * dt * c.ks_ss * (-1));
-        perc = perc * mk;
-        const bool drain = (perc > 0) && (c.z_soil < zgw);
-        const double avail = c.S_fp_ss + c.S_lp_ss;
-        double q = (drain && (perc <= avail) ? perc : 0.0) * mk;
-        q = (drain && (perc > avail) ? avail : q) * mk;
-        double cpr = sal * dt * c.ks_ss * mk;
-        cpr = (drain ? 0.0 : cpr) * mk;
-        cpr = (zgw - c.z_soil > 10000 ? 0.0 : cpr) * mk;
-        c.q_pot_ss = (cpr > 0 ? 0.0 : q) * mk;
-    }
+}
+
+// potential percolation out of the subsoil :971-1098 (the second of the two assignments is the live one)
+RH_DEV void h_sub_pot_percolation_ss(Col &c, double dt, double mk) {
+    const double dz_ss = c.z_soil - c.z_root;
+    const double zgw = c.z_gw * 1000;
+    const double z = (zgw - c.z_soil) + (dz_ss / 2) * mk;
+    const double sal = h_salvucci(z, c.h_ss, c.ha, c.n_salv);
+    const bool shallow = (c.z_gw <= 10) && (zgw > c.z_soil) && (c.z_sat > 0);
+    double perc = shallow ? fmin(fmin(c.kf * dt, c.ks_ss * dt), c.k_ss * dt) : fmin(c.kf * dt, sal * dt * c.ks_ss * (-1));
+    perc = perc * mk;
+    const bool drain = (perc > 0) && (c.z_soil < zgw);
+    const double avail = c.S_fp_ss + c.S_lp_ss;
+    double q = (drain && (perc <= avail) ? perc : 0.0) * mk;
+    q = (drain && (perc > avail) ? avail : q) * mk;
+    double cpr = sal * dt * c.ks_ss * mk;
+    cpr = (drain ? 0.0 : cpr) * mk;
+    cpr = (zgw - c.z_soil > 10000 ? 0.0 : cpr) * mk;
+    c.q_pot_ss = (cpr > 0 ? 0.0 : q) * mk;
+}
+
+// SVAT branch of calculate_subsurface_runoff :1473-1479
+RH_DEV void rt_subsurface_runoff(Col &c, const StepCtx &X) {
+    const double mk = (double)c.maskCatch;
+    const double dt = X.dt;
+    h_sub_water_table(c, mk);
+    h_sub_percolation_rz(c, dt, mk);
+    h_sub_pot_percolation_ss(c, dt, mk);
     // percolation subsoil :1101-1154
+    c.q_ss = c.q_pot_ss * mk;
+    c.z_sat += (c.z_sat > 0 ? -c.q_ss / c.theta_ac : 0.0) * mk;
+    c.z_sat = (c.z_sat < 0 ? 0.0 : c.z_sat) * mk;
+    c.S_zsat_ss = c.z_sat * c.theta_ac * mk;
+    const bool m1 = c.S_lp_ss < c.q_pot_ss, m2 = c.S_lp_ss >= c.q_pot_ss;
+    c.S_fp_ss += (m1 ? -(c.q_ss - c.S_lp_ss) : 0.0) * mk;
+    c.S_lp_ss = (m1 ? 0.0 : c.S_lp_ss) * mk;
+    c.S_lp_ss += (m2 ? -c.q_ss : 0.0) * mk;
+}
+
+// saturated thickness of one 200 mm layer, :51-245 (`top` = the deepest layer has no upper clamp)
+RH_DEV double h_layer(double z_sat, double offset, bool first, bool last, double mk) {
+    double v = first ? z_sat * mk : z_sat - offset * mk;
+    if (!last) v = (v > 200 ? 200.0 : v) * mk;
+    return (v <= 0 ? 0.0 : v) * mk;
+}
+
+// oneD model, lateral branch of calculate_subsurface_runoff :1456-1471: Darcy flow in the matrix and
+// pipe flow in horizontal macropores of eight layers, leaving the column as a sink term (no
+// neighbour receives it without routing, SURVEY.md a10')
+RH_DEV void rt_subsurface_runoff_lateral(Col &c, const Consts &K, const StepCtx &X) {
+    const double mk = (double)c.maskCatch;
+    const double dt = X.dt;
+    h_sub_water_table(c, mk);
+    c.z_sat_layer_1 = h_layer(c.z_sat, 0.0, true, false, mk);
+    c.z_sat_layer_2 = h_layer(c.z_sat, 200.0, false, false, mk);
+    c.z_sat_layer_3 = h_layer(c.z_sat, 400.0, false, false, mk);
+    c.z_sat_layer_4 = h_layer(c.z_sat, 600.0, false, false, mk);
+    c.z_sat_layer_5 = h_layer(c.z_sat, 800.0, false, false, mk);
+    c.z_sat_layer_6 = h_layer(c.z_sat, 1000.0, false, false, mk);
+    c.z_sat_layer_7 = h_layer(c.z_sat, 1200.0, false, false, mk);
+    c.z_sat_layer_8 = h_layer(c.z_sat, 1400.0, false, true, mk);
+    h_sub_percolation_rz(c, dt, mk);
+
+    // potential lateral runoff :248-372
+    const double dx = K.dx, per_len = (1 / (dx * (c.z_soil / 1000)));
+    const double r2 = K.r_mp * K.r_mp;
+    c.q_sub_mat_pot = ((c.ks * c.slope * c.z_sat * dx * 1000 * dt) * 1e-6 * per_len) * mk;
+    c.q_sub_mat_pot = (c.z_sat <= 0 ? 0.0 : c.q_sub_mat_pot) * mk;
+    double sum = c.z_sat_layer_1 * c.v_mp_layer_1 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_2 * c.v_mp_layer_2 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_3 * c.v_mp_layer_3 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_4 * c.v_mp_layer_4 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_5 * c.v_mp_layer_5 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_6 * c.v_mp_layer_6 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_7 * c.v_mp_layer_7 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    sum += c.z_sat_layer_8 * c.v_mp_layer_8 * dt * dx * 1000 * c.dmph * 1e-6 * r2 * K.pi * 1e-6;
+    double mp = (sum * per_len) * mk;
+    mp = (mp < 0 ? 0.0 : mp) * mk;
+    mp = (c.z_sat <= 0 ? 0.0 : mp) * mk;
+    double pot = (mp + c.q_sub_mat_pot) * mk;
+    double sh_mat = (c.q_sub_mat_pot / pot) * mk, sh_mp = (mp / pot) * mk;
+    sh_mat = (pot == 0 ? 0.0 : sh_mat) * mk;
+    sh_mp = (pot == 0 ? 0.0 : sh_mp) * mk;
+    c.q_sub_mat_share = sh_mat;
+    c.q_sub_mp_share = sh_mp;
+    pot = (pot > c.S_lp_rz + c.S_lp_ss ? c.S_lp_rz + c.S_lp_ss : pot) * mk;
+    c.q_sub_pot = pot;
+    c.q_sub_mat_pot = pot * sh_mat * mk;
+    c.q_sub_mp_pot = pot * sh_mp * mk;
+
+    // lateral runoff from the root zone :375-457
+    const double dz_ss = c.z_soil - c.z_root;
     {
-        c.q_ss = c.q_pot_ss * mk;
-        c.z_sat += (c.z_sat > 0 ? -c.q_ss / c.theta_ac : 0.0) * mk;
-        c.z_sat = (c.z_sat < 0 ? 0.0 : c.z_sat) * mk;
-        c.S_zsat_ss = c.z_sat * c.theta_ac * mk;
-        const bool m1 = c.S_lp_ss < c.q_pot_ss, m2 = c.S_lp_ss >= c.q_pot_ss;
-        c.S_fp_ss += (m1 ? -(c.q_ss - c.S_lp_ss) : 0.0) * mk;
+        double share = (c.z_sat > 0 ? ((c.z_sat - dz_ss) / c.z_sat) : 0.0) * mk;
+        share = ((c.z_sat <= dz_ss) || (c.S_lp_rz <= 0) ? 0.0 : share) * mk;
+        share = (isnan(share) ? 0.0 : share) * mk;
+        c.S_zsat_rz = ((c.z_sat * share) * c.theta_ac) * mk;
+        c.q_sub_rz = (pot * share < c.S_zsat_rz ? pot * share : c.S_zsat_rz) * mk;
+        c.q_sub_mat_rz = c.q_sub_rz * sh_mat * mk;
+        c.q_sub_mp_rz = c.q_sub_rz * sh_mp * mk;
+        c.q_sub_mp_pot_rz = c.q_sub_mp_pot * share * mk;
+        c.z_sat += -c.q_sub_rz / c.theta_ac * mk;
+        c.S_lp_rz += -c.q_sub_rz * mk;
+    }
+    // potential lateral runoff from the subsoil :460-515
+    {
+        double share = (dz_ss / c.z_sat) * mk;
+        const bool nan0 = isnan(share);
+        share = ((c.z_sat <= dz_ss) || (c.S_lp_rz <= 0) ? 1.0 : share) * mk;
+        share = (c.z_sat <= 0 ? 0.0 : share) * mk;
+        share = (nan0 ? 0.0 : share) * mk;
+        c.q_sub_mat_pot_ss = c.q_sub_mat_pot * share * mk;
+        c.q_sub_mp_pot_ss = c.q_sub_mp_pot * share * mk;
+        c.q_sub_pot_ss = (c.q_sub_mat_pot_ss + c.q_sub_mp_pot_ss) * mk;
+    }
+    h_sub_pot_percolation_ss(c, dt, mk);
+    // vertical and lateral drainage of the subsoil share the perched water :518-690
+    {
+        const double tot = c.q_pot_ss + c.q_sub_pot_ss;
+        const double fv = (tot > 0 ? c.q_pot_ss / tot : 0.0) * mk, fl = (tot > 0 ? c.q_sub_pot_ss / tot : 0.0) * mk;
+        const bool fits = tot <= c.S_zsat_ss;
+        double q = (c.z_sat <= 0 ? c.q_pot_ss : 0.0) * mk;
+        const double q_sat = (fits ? tot * fv : c.S_zsat_ss * fv) * mk;
+        q = (c.z_sat > 0 ? q_sat : q);
+        c.q_ss = q;
+        c.q_sub_ss = (fits ? tot * fl : c.S_zsat_ss * fl) * mk;
+        c.q_sub_mat_ss = c.q_sub_ss * sh_mat * mk;
+        c.q_sub_mp_ss = c.q_sub_ss * sh_mp * mk;
+        const bool m1 = c.S_lp_ss < q, m2 = c.S_lp_ss >= q;
+        c.S_fp_ss += (m1 ? -(q - c.S_lp_ss) : 0.0) * mk;
         c.S_lp_ss = (m1 ? 0.0 : c.S_lp_ss) * mk;
-        c.S_lp_ss += (m2 ? -c.q_ss : 0.0) * mk;
+        c.S_lp_ss += (m2 ? -q : 0.0) * mk;
+        c.S_lp_ss += (c.z_sat > 0 ? -c.q_sub_ss : 0.0) * mk;
+        c.z_sat += -((c.q_sub_ss + q) / c.theta_ac) * mk;
+        c.z_sat = (c.z_sat < 0 ? 0.0 : c.z_sat) * mk;
+        c.S_zsat = c.z_sat * c.theta_ac * mk;
+        c.q_sub_mat = (c.q_sub_mat_rz + c.q_sub_mat_ss) * mk;
+        c.q_sub_mp = (c.q_sub_mp_rz + c.q_sub_mp_ss) * mk;
+        c.q_sub = (c.q_sub_rz + c.q_sub_ss) * mk;
     }
 }
 
@@ -793,9 +903,21 @@ RH_DEV bool rt_num_error(Col &c, const Consts &K) {
     return !(close && lower && upper);
 }
 
-// models/svat/svat.py:187-384
-RH_DEV double h_snap0(double x) { return ((x > -1e-6) && (x < 0)) ? 0.0 : x; }
-RH_DEV void rt_after_timestep(Col &c) {
+// oneD model: numerics.py:226-245 (only dS_num_error) and the sanity check with q_sub :744-759
+RH_DEV bool rt_num_error_lateral(Col &c, const Consts &K) {
+    const double lhs = c.S - c.S_m1, rhs = c.prec - c.q_sur - c.aet - c.q_ss - c.q_sub;
+    c.dS_num_error = fabs(lhs - rhs);
+    bool close = (isfinite(lhs) && isfinite(rhs)) ? (fabs(lhs - rhs) <= K.atol + K.rtol * fabs(rhs)) : (lhs == rhs);
+    close = c.maskCatch ? close : true;
+    const double a = h_nan0(c.S_fp_rz), b = h_nan0(c.S_lp_rz), d = h_nan0(c.S_fp_ss), e = h_nan0(c.S_lp_ss);
+    const bool lower = (a > -K.atol) && (b > -K.atol) && (d > -K.atol) && (e > -K.atol);
+    const bool upper = (a - K.atol <= h_nan0(c.S_ufc_rz)) && (b - K.atol <= h_nan0(c.S_ac_rz)) &&
+                       (d - K.atol <= h_nan0(c.S_ufc_ss)) && (e - K.atol <= h_nan0(c.S_ac_ss));
+    return !(close && lower && upper);
+}
+
+// tau -> taum1 of the prognostic variables (models/svat/svat.py:187-324, models/oneD/oneD.py)
+RH_DEV void h_rotate(Col &c) {
     c.ta_m1 = c.ta;
     c.z_root_m1 = c.z_root;
     c.ground_cover_m1 = c.ground_cover;
@@ -825,12 +947,19 @@ RH_DEV void rt_after_timestep(Col &c) {
     c.h_ss_m1 = c.h_ss;
     c.h_m1 = c.h;
     c.z0_m1 = c.z0;
+    c.prec_m1 = c.prec;
+}
+// models/svat/svat.py:187-384: rotation + tiny negative pore storages snapped to zero (:326-345)
+RH_DEV double h_snap0(double x) { return ((x > -1e-6) && (x < 0)) ? 0.0 : x; }
+RH_DEV void rt_after_timestep(Col &c) {
+    h_rotate(c);
     c.S_fp_rz = h_snap0(c.S_fp_rz);
     c.S_lp_rz = h_snap0(c.S_lp_rz);
     c.S_fp_ss = h_snap0(c.S_fp_ss);
     c.S_lp_ss = h_snap0(c.S_lp_ss);
-    c.prec_m1 = c.prec;
 }
+// the oneD model's after_timestep_kernel has the rotation only
+RH_DEV void rt_after_timestep_oned(Col &c) { h_rotate(c); }
 
 // ---------------------------------------------------------------------------------------------
 // setup-time / monthly parameter kernels
@@ -941,6 +1070,32 @@ RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     c.S_fc_ss = (fc * dz) * mk;
 }
 
+// soil.py:560-641: horizontal macropore flow velocity per layer from the slope look-up table
+// lut_mlms (rows: slope in percent, then m/h of layers 8..1), converted to mm/h
+RH_DEV void rt_params_lateral(Col &c, const double *mlms, int64_t nrows, int max_slope_per) {
+    const double mk = (double)c.maskCatch;
+    const int key = c.slope_per;
+    const bool hit = (key >= 1) && (key <= max_slope_per);   // the reference loops i = 1 .. max(slope_per)
+    int64_t row = 0;                                         // _get_row_no: first match, else row 0
+    if (hit) {
+        if (key <= nrows && mlms[(int64_t)(key - 1) * 9] == (double)key) {
+            row = key - 1;
+        } else {
+            for (int64_t r = 0; r < nrows; ++r)
+                if (mlms[r * 9] == (double)key) { row = r; break; }
+        }
+    }
+    const double *m = mlms + row * 9;
+    c.v_mp_layer_8 = ((hit ? m[1] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_7 = ((hit ? m[2] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_6 = ((hit ? m[3] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_5 = ((hit ? m[4] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_4 = ((hit ? m[5] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_3 = ((hit ? m[6] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_2 = ((hit ? m[7] * 1000 : 0.0) * mk) * mk;
+    c.v_mp_layer_1 = ((hit ? m[8] * 1000 : 0.0) * mk) * mk;
+}
+
 // Splits an initial water content into fine / large pore fractions, soil.py:767-800 / :852-885
 RH_DEV void h_split_theta(double theta, const Col &c, double &fp, double &lp, double mk) {
     fp = (theta > c.theta_pwp ? theta - c.theta_pwp : fp) * mk;
@@ -1016,18 +1171,40 @@ RH_DEV bool rt_step_core(Col &c, const Consts &K, const StepCtx &X) {
     rt_storage(c, X);
     return rt_num_error(c, K);
 }
-RH_DEV bool h_step_body(Col &c, const Consts &K, const StepCtx &X) {
-    const bool bad = rt_step_core(c, K, X);
-    rt_after_timestep(c);
-    return bad;
+RH_DEV bool rt_step_core_lateral(Col &c, const Consts &K, const StepCtx &X) {   // oneD model
+    rt_interception(c, K);
+    rt_evapotranspiration(c, K);
+    rt_snow(c, K, X);
+    rt_infiltration(c, K, X);
+    rt_subsurface_runoff_lateral(c, K, X);
+    rt_capillary_rise(c, X);
+    rt_storage(c, X);
+    return rt_num_error_lateral(c, K);
 }
 RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
     rt_select_pet(c, X, pet_v, ta_v);
-    return h_step_body(c, K, X);
+    const bool bad = rt_step_core(c, K, X);
+    rt_after_timestep(c);
+    return bad;
 }
 // first step of a month: `set_parameters` re-derives the surface parameters (svat.py:115-120)
 RH_DEV bool rt_step_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
     rt_select_pet(c, X, pet_v, ta_v);
     rt_params_surface(c, L, X);
-    return h_step_body(c, K, X);
+    const bool bad = rt_step_core(c, K, X);
+    rt_after_timestep(c);
+    return bad;
+}
+RH_DEV bool rt_step_lateral(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
+    rt_select_pet(c, X, pet_v, ta_v);
+    const bool bad = rt_step_core_lateral(c, K, X);
+    rt_after_timestep_oned(c);
+    return bad;
+}
+RH_DEV bool rt_step_lateral_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
+    rt_select_pet(c, X, pet_v, ta_v);
+    rt_params_surface(c, L, X);
+    const bool bad = rt_step_core_lateral(c, K, X);
+    rt_after_timestep_oned(c);
+    return bad;
 }

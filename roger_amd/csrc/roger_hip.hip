@@ -51,6 +51,9 @@ struct DevState {
     const int64_t *calendar[3];
     int64_t nitt_forc;
     int monthly;                       // set_parameters' month-change test, evaluated on the device
+    const double *mlms;                // lut_mlms rows (oneD model), device copy
+    int64_t mlms_rows;
+    int max_slope_per;
     Luts L;
 };
 
@@ -64,6 +67,7 @@ struct rh_ctx {
     double *forc_cell_buf[3];
     double *agg_cell_buf;
     void *series_buf;
+    double *mlms_buf;
     bool per_cell;
     int pred_blocks;
     bool forcing_set;
@@ -490,7 +494,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 
 // THE hot kernel.  Loads every plane the step reads once, runs the whole step in registers,
 // stores every plane the step assigns once.
-template <bool MONTHLY>
+template <bool MONTHLY, bool LATERAL>
 __global__ __launch_bounds__(RH_BLOCK) void k_step(Arena a, DevState *D, int guarded) {
     // device-driven stepping launches both variants; the one that does not apply exits at once
     if (guarded && (D->monthly != 0) != MONTHLY) return;
@@ -505,7 +509,15 @@ __global__ __launch_bounds__(RH_BLOCK) void k_step(Arena a, DevState *D, int gua
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
         ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
     }
-    if (MONTHLY) {
+    if (MONTHLY && LATERAL) {
+        RH_SET_LOAD_rt_step_lateral_monthly(LD)
+        bad = rt_step_lateral_monthly(c, K, X, D->L, pet_v, ta_v);
+        RH_SET_STORE_rt_step_lateral_monthly(ST)
+    } else if (LATERAL) {
+        RH_SET_LOAD_rt_step_lateral(LD)
+        bad = rt_step_lateral(c, K, X, pet_v, ta_v);
+        RH_SET_STORE_rt_step_lateral(ST)
+    } else if (MONTHLY) {
         RH_SET_LOAD_rt_step_monthly(LD)
         bad = rt_step_monthly(c, K, X, D->L, pet_v, ta_v);
         RH_SET_STORE_rt_step_monthly(ST)
@@ -540,6 +552,24 @@ RH_CELL_KERNEL(k_storage, rt_storage, rt_storage(c, X))
 RH_CELL_KERNEL(k_num_error, rt_num_error, if (rt_num_error(c, K)) atomicOr(&D->words[2], 1ull))
 RH_CELL_KERNEL(k_after_timestep, rt_after_timestep, rt_after_timestep(c))
 RH_CELL_KERNEL(k_step_core, rt_step_core, if (rt_step_core(c, K, X)) atomicOr(&D->words[2], 1ull))
+// oneD model variants
+RH_CELL_KERNEL(k_subsurface_runoff_lateral, rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X))
+RH_CELL_KERNEL(k_num_error_lateral, rt_num_error_lateral, if (rt_num_error_lateral(c, K)) atomicOr(&D->words[2], 1ull))
+RH_CELL_KERNEL(k_after_timestep_oned, rt_after_timestep_oned, rt_after_timestep_oned(c))
+RH_CELL_KERNEL(k_step_core_lateral, rt_step_core_lateral, if (rt_step_core_lateral(c, K, X)) atomicOr(&D->words[2], 1ull))
+RH_CELL_KERNEL(k_params_lateral, rt_params_lateral, rt_params_lateral(c, D->mlms, D->mlms_rows, D->max_slope_per))
+
+// max over the columns of slope_per (the trip count of the reference's look-up loop, soil.py:621)
+__global__ __launch_bounds__(RH_BLOCK) void k_max_slope(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    int v = 0;
+    if (i < a.n) rh_ld(a, RH_P_slope_per, i, v);
+    for (int off = 32; off; off >>= 1) {
+        const int o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&D->max_slope_per, v);
+}
 RH_CELL_KERNEL(k_topo, rt_topo, rt_topo(c))
 RH_CELL_KERNEL(k_params_surface, rt_params_surface, rt_params_surface(c, D->L, X))
 RH_CELL_KERNEL(k_params_soil, rt_params_soil, rt_params_soil(c, K, D->L))
@@ -680,6 +710,8 @@ void rh_default_config(rh_config *cfg) {
     cfg->b_bc = 2;
     cfg->end_event = 21600;
     cfg->hpi = 5;
+    cfg->dx = 1;
+    cfg->enable_lateral_flow = 0;
 }
 
 const char *rh_last_error(const rh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -716,6 +748,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
     ctx->agg_cell_buf = nullptr;
     ctx->series_buf = nullptr;
+    ctx->mlms_buf = nullptr;
     ctx->per_cell = false;
     const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256;
     ctx->arena.stride = stride;
@@ -739,6 +772,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     K.theta_rew_max = cfg->theta_rew_max; K.rew_min = cfg->rew_min; K.rew_max = cfg->rew_max;
     K.z_evap_max = cfg->z_evap_max; K.zroot_to_zsoil_max = cfg->zroot_to_zsoil_max; K.a_bc = cfg->a_bc; K.b_bc = cfg->b_bc;
     K.end_event = cfg->end_event; K.hpi = cfg->hpi;
+    K.dx = cfg->dx; K.lateral = cfg->enable_lateral_flow ? 1 : 0;
     if ((e = hipMemcpyAsync(&ctx->dev->K, &K, sizeof(K), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(Consts)");
     // scalars: roger/variables.py initial values (dt=1, dt_secs=3600, event_id_counter=1, year=1900, month=doy=1)
@@ -774,6 +808,7 @@ void rh_destroy(rh_ctx *ctx) {
         if (b) (void)hipFree(b);
     if (ctx->agg_cell_buf) (void)hipFree(ctx->agg_cell_buf);
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
+    if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -858,6 +893,29 @@ int rh_set_luts(rh_ctx *ctx, const double *ilu, const double *gc, const double *
     return RH_OK;
 }
 
+int rh_set_lut_mlms(rh_ctx *ctx, const double *mlms, int64_t nrows) {
+    if (!ctx || !mlms || nrows <= 0) return RH_ERR_ARG;
+    if (ctx->mlms_buf) HIPCHK(ctx, hipFree(ctx->mlms_buf));
+    ctx->mlms_buf = nullptr;
+    const size_t nb = sizeof(double) * 9 * (size_t)nrows;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->mlms_buf, nb));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->mlms_buf, mlms, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->mlms, &ctx->mlms_buf, sizeof(double *), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->mlms_rows, &nrows, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+
+int rh_params_lateral(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->mlms_buf) return fail(ctx, RH_ERR_STATE, "rh_set_lut_mlms must be called first");
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->max_slope_per, 0, sizeof(int), ctx->stream));
+    LAUNCH_CELLS(ctx, k_max_slope);
+    LAUNCH_CELLS(ctx, k_params_lateral);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
 int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day, const double *pet_day, int per_cell) {
     if (!ctx || !prec_day || !ta_day || !pet_day) return RH_ERR_ARG;
     const double *src[3] = {prec_day, ta_day, pet_day};
@@ -899,9 +957,18 @@ SIMPLE_ENTRY(rh_initial_conditions, k_initial_conditions)
 SIMPLE_ENTRY(rh_interception, k_interception)
 SIMPLE_ENTRY(rh_evapotranspiration, k_evapotranspiration)
 SIMPLE_ENTRY(rh_snow, k_snow)
-SIMPLE_ENTRY(rh_subsurface_runoff, k_subsurface_runoff)
 SIMPLE_ENTRY(rh_capillary_rise, k_capillary_rise)
 SIMPLE_ENTRY(rh_storage, k_storage)
+
+int rh_subsurface_runoff(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    if (ctx->cfg.enable_lateral_flow)
+        LAUNCH_CELLS(ctx, k_subsurface_runoff_lateral);
+    else
+        LAUNCH_CELLS(ctx, k_subsurface_runoff);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
 
 int rh_infiltration(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
@@ -915,7 +982,10 @@ int rh_infiltration(rh_ctx *ctx) {
 int rh_num_error(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
-    LAUNCH_CELLS(ctx, k_num_error);
+    if (ctx->cfg.enable_lateral_flow)
+        LAUNCH_CELLS(ctx, k_num_error_lateral);
+    else
+        LAUNCH_CELLS(ctx, k_num_error);
     LAUNCH_ONE(ctx, k_sanity_to_scalars, ctx->dev);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -925,7 +995,10 @@ int rh_num_error(rh_ctx *ctx) {
 // keep the user hooks `set_parameters` and `after_timestep` on the host
 int rh_step_core(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
-    LAUNCH_CELLS(ctx, k_step_core);
+    if (ctx->cfg.enable_lateral_flow)
+        LAUNCH_CELLS(ctx, k_step_core_lateral);
+    else
+        LAUNCH_CELLS(ctx, k_step_core);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -933,7 +1006,10 @@ int rh_step_core(rh_ctx *ctx) {
 
 int rh_after_timestep(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
-    LAUNCH_CELLS(ctx, k_after_timestep);
+    if (ctx->cfg.enable_lateral_flow)
+        LAUNCH_CELLS(ctx, k_after_timestep_oned);
+    else
+        LAUNCH_CELLS(ctx, k_after_timestep);
     LAUNCH_ONE(ctx, k_rotate_scalars, ctx->dev);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -951,14 +1027,23 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used], ctx->stream));
     }
     const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
+    const bool lat = ctx->cfg.enable_lateral_flow != 0;
+#define RH_LAUNCH_STEP(M, guard)                                                                              \
+    do {                                                                                                      \
+        if (lat)                                                                                              \
+            hipLaunchKernelGGL((k_step<M, true>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, guard);  \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_step<M, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, guard); \
+    } while (0)
     if (monthly < 0) {  // decided on the device
-        hipLaunchKernelGGL(k_step<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 1);
-        hipLaunchKernelGGL(k_step<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 1);
+        RH_LAUNCH_STEP(false, 1);
+        RH_LAUNCH_STEP(true, 1);
     } else if (monthly) {
-        hipLaunchKernelGGL(k_step<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 0);
+        RH_LAUNCH_STEP(true, 0);
     } else {
-        hipLaunchKernelGGL(k_step<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 0);
+        RH_LAUNCH_STEP(false, 0);
     }
+#undef RH_LAUNCH_STEP
     if (ctx->timing) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used + 1], ctx->stream));
         ctx->ev_used += 2;

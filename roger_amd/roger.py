@@ -141,6 +141,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
     def _upload_luts(self):
         vs = self.state.variables
         self.state.backend_context.set_luts(vs.lut_ilu, vs.lut_gc, vs.lut_gcm, vs.lut_rdlu)
+        if self.state.settings.enable_lateral_flow:
+            self.state.backend_context.set_lut_mlms(vs.lut_mlms)
 
     # -- one time step, roger/roger.py:355-489 ------------------------------------------------------
     @roger_routine

@@ -70,7 +70,7 @@ SETTINGS = {
 }
 
 _UNSUPPORTED_SWITCHES = (
-    "enable_distributed_input", "enable_film_flow", "enable_lateral_flow", "enable_crop_phenology",
+    "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_offline_transport", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
 )

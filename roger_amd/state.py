@@ -291,6 +291,8 @@ class RogerState:
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min", "clay_max",
             "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max", "a_bc", "b_bc",
             "end_event", "hpi")}
+        consts["enable_lateral_flow"] = int(bool(s.enable_lateral_flow))   # oneD model
+        consts["dx"] = float(s.dx)
         self._ctx = _native.Context(s.nx // px, s.ny // py, device=device, **consts)
         self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx)
 

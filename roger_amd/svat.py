@@ -32,17 +32,21 @@ def hetero_params(n, seed=42):
     return p
 
 
-def create_svat(nx, ny, params=None, device=0, **settings):
+def create_svat(nx, ny, params=None, device=0, lateral=False, **settings):
     """Returns a `_native.Context` holding a fully initialised SVAT state.
 
     params: dict of scalars or arrays (n_cells) for lu_id, z_soil, dmpv, lmpv, theta_ac, theta_ufc,
     theta_pwp, ks, kf (+ optional sealing, S_dep_tot) and the initial theta_rz, theta_ss.
     """
+    if lateral:
+        settings = dict(settings, enable_lateral_flow=1)
     ctx = N.Context(nx, ny, device=device, **settings)
     n = ctx.n
     p = dict(BENCHMARK_PARAMS)
     p.update(params or {})
     ctx.set_luts(lut.ARR_ILU, lut.ARR_GC, lut.ARR_GCM, lut.ARR_RDLU)
+    if lateral:
+        ctx.set_lut_mlms(lut.ARR_MLMS)
 
     def full(v, dtype):
         a = np.asarray(v)
@@ -55,6 +59,8 @@ def create_svat(nx, ny, params=None, device=0, **settings):
     ctx.call("rh_topo")
     ctx.call("rh_params_surface")
     ctx.call("rh_params_soil")
+    if lateral:
+        ctx.call("rh_params_lateral")
     for k in ("theta_rz", "theta_ss"):
         a = full(p[k], np.float64)
         ctx.upload(k, a)

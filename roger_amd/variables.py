@@ -20,7 +20,7 @@ GHOST_DIMENSIONS = ("x", "y")
 # roger/variables.py:101-131
 DIM_TO_SHAPE_VAR = {
     "x": "nx", "y": "ny", "t_forc": "nitt_forc", "timesteps": 2, "timesteps_day": 6 * 24,
-    "n_lu": 25, "n_sealing": 101, "n_params2": 2, "n_params7": 7, "n_params13": 13,
+    "n_lu": 25, "n_sealing": 101, "n_slope": 10000, "n_params2": 2, "n_params7": 7, "n_params9": 9, "n_params13": 13,
 }
 
 
@@ -97,6 +97,7 @@ def build_variables():
     V["lut_gcm"] = Variable("lut_gcm", ("n_lu", "n_params2"))
     V["lut_is"] = Variable("lut_is", ("n_sealing", "n_params2"))
     V["lut_rdlu"] = Variable("lut_rdlu", ("n_lu", "n_params7"))
+    V["lut_mlms"] = Variable("lut_mlms", ("n_slope", "n_params9"))
     for name in ("PREC", "TA", "PET"):
         V[name] = Variable(name, ("t_forc",))
     for name in ("YEAR", "MONTH", "DOY"):

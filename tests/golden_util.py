@@ -4,7 +4,9 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo")
+SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo")
+ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo")   # oneD model: lateral subsurface flow
+CASES = SVAT_CASES + ONED_CASES
 
 # Tolerance of the oracle against the reference NumPy backend, and of the HIP path against the
 # oracle.  fp64 throughout; differences come only from libm `pow/log/exp` implementations
@@ -20,6 +22,10 @@ def load_case(name):
     names = [str(x) for x in g["plane_names"]]
     forcing = {k[5:]: g[k] for k in g.files if k.startswith("forc_")}
     return g, names, forcing
+
+
+def is_lateral(g):
+    return bool(int(g["lateral"])) if "lateral" in g.files else False
 
 
 def compare(got, ref, names, rtol=RTOL, atol=ATOL, what=""):

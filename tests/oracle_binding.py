@@ -30,7 +30,7 @@ class OcSettings(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min", "clay_max",
         "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max", "a_bc", "b_bc",
-    )] + [("end_event", C.c_int64), ("hpi", C.c_int64)]
+    )] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("enable_lateral_flow", C.c_int64), ("dx", C.c_double)]
 
 
 def default_settings():
@@ -39,7 +39,7 @@ def default_settings():
         pi=3.14159265358979323846264338327950588, r_mp=2.5, l_sc=10000, sf=3, ta_fm=0, rmax=30,
         transp_water_stress=0.75, atol=1e-2, rtol=1e-2, clay_min=0.01, clay_max=0.71, theta_rew_min=0.02,
         theta_rew_max=0.24, rew_min=2, rew_max=12, z_evap_max=150, zroot_to_zsoil_max=0.7, a_bc=2, b_bc=2,
-        end_event=21600, hpi=5,
+        end_event=21600, hpi=5, enable_lateral_flow=0, dx=1.0,
     )
 
 
@@ -150,7 +150,7 @@ class OracleState:
         lib().oc_infiltration(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings))
 
     def subsurface_runoff(self):
-        lib().oc_subsurface_runoff(self._ptrs, C.c_int64(self.n), C.byref(self.scal))
+        lib().oc_subsurface_runoff(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings))
 
     def capillary_rise(self):
         lib().oc_capillary_rise(self._ptrs, C.c_int64(self.n), C.byref(self.scal))
@@ -162,7 +162,7 @@ class OracleState:
         return bool(lib().oc_num_error(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings)))
 
     def after_timestep(self):
-        lib().oc_after_timestep(self._ptrs, C.c_int64(self.n), C.byref(self.scal))
+        lib().oc_after_timestep(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings))
 
     def params_surface(self):
         lib().oc_params_surface(self._ptrs, C.c_int64(self.n), C.byref(self.scal), *self._lut_args())
@@ -172,6 +172,11 @@ class OracleState:
 
     def params_soil(self):
         lib().oc_params_soil(self._ptrs, C.c_int64(self.n), C.byref(self.settings), *self._lut_args())
+
+    def params_lateral(self, mlms):
+        self._mlms = np.ascontiguousarray(mlms, dtype=np.float64)
+        lib().oc_params_lateral(self._ptrs, C.c_int64(self.n), self._mlms.ctypes.data_as(C.c_void_p),
+                                C.c_int64(self._mlms.shape[0]))
 
     def initial_conditions(self):
         lib().oc_initial_conditions(self._ptrs, C.c_int64(self.n))

@@ -21,6 +21,7 @@ class OracleContext:
         self.st = ob.OracleState(self.n)
         for k, v in settings.items():
             setattr(self.st.settings, k, v)
+        self.mlms = None
         self.planes = list(zip(self.st.names, self.st.is_int))
         self.index = {nm: i for i, nm in enumerate(self.st.names)}
         P = self.st.planes
@@ -75,6 +76,9 @@ class OracleContext:
     def set_luts(self, ilu, gc, gcm, rdlu):
         self.st.set_luts(ilu, gc, gcm, rdlu)
 
+    def set_lut_mlms(self, mlms):
+        self.mlms = np.ascontiguousarray(mlms, dtype=np.float64)
+
     def set_forcing_day(self, prec_day, ta_day, pet_day):
         self.day = [np.ascontiguousarray(a, dtype=np.float64) for a in (prec_day, ta_day, pet_day)]
 
@@ -95,6 +99,9 @@ class OracleContext:
             return
         if entry == "rh_step_core":
             self._after_adt(monthly=False, core_only=True, word1=self._local_word1())
+            return
+        if entry == "rh_params_lateral":
+            st.params_lateral(self.mlms)
             return
         {"rh_topo": st.topo, "rh_params_surface": st.params_surface, "rh_params_soil": st.params_soil,
          "rh_initial_conditions": st.initial_conditions, "rh_interception": st.interception,

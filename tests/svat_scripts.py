@@ -9,11 +9,14 @@ from roger_amd.core.operators import at, numpy as npx, update
 from roger_amd.models.svat import SVATSetup
 
 
-def make_model(params, forcing, ndays):
+def make_model(params, forcing, ndays, lateral=False):
+    from roger_amd.models.oned import ONEDSetup
+
     nx, ny = params["lu_id"].shape
     F = forcing
+    Base = ONEDSetup if lateral else SVATSetup
 
-    class GoldenSVAT(SVATSetup):
+    class GoldenSVAT(Base):
         @roger_routine
         def set_settings(self, state):
             s = state.settings
@@ -28,6 +31,7 @@ def make_model(params, forcing, ndays):
             s.time_origin = "2018-01-01 00:00:00"
             s.enable_groundwater_boundary = False
             s.enable_macropore_lower_boundary_condition = False
+            s.enable_lateral_flow = bool(lateral)
             s.enable_adaptive_time_stepping = True
 
         @roger_routine
@@ -36,6 +40,10 @@ def make_model(params, forcing, ndays):
             for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf",
                       "sealing", "S_dep_tot"):
                 setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], params[k]))
+            if lateral:   # benchmarks/oneD_benchmark.py:106-117
+                vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
+                vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)
+                vs.dmph = update(vs.dmph, at[2:-2, 2:-2], params["dmph"])
 
         @roger_routine
         def set_initial_conditions(self, state):
@@ -75,6 +83,9 @@ def params_from_golden(g, names):
     p = {k: pre[names.index(k)].reshape(nx, ny) for k in
          ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf", "sealing", "S_dep_tot")}
     p["lu_id"] = p["lu_id"].astype(np.int32)
+    if "lateral" in g.files and int(g["lateral"]):
+        p["slope"] = pre[names.index("slope")].reshape(nx, ny)
+        p["dmph"] = pre[names.index("dmph")].reshape(nx, ny)
     p["theta_rz0"] = ic[names.index("theta_rz")].reshape(nx, ny)
     p["theta_ss0"] = ic[names.index("theta_ss")].reshape(nx, ny)
     return p

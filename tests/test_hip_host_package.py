@@ -8,13 +8,14 @@ from golden_util import compare, load_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_combo"])
+@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_combo", "oned_hetero_heavyrain"])
 def test_setup_step_reproduce_reference(case):
     import svat_scripts as S
+    from golden_util import is_lateral
 
     g, names, forcing = load_case(case)
     ndays = len(forcing["PREC"]) // 144
-    model = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=is_lateral(g))
     model.setup()
     vs = model.state.variables
     compare(S.snapshot_from_vs(vs, names), g["state0"], names, what=f"{case} after setup()")

@@ -76,7 +76,7 @@ def test_variables_contract(oracle_backend):
     assert st.backend_context.get_scalars().time == 86400
 
 
-@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain"])
+@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain", "oned_hetero_heavyrain"])
 def test_setup_and_run_reproduce_reference(oracle_backend, case):
     """The same setup script the golden generator ran through the reference, run through this
     package: setup() state and the trajectory of step() match the reference."""
@@ -84,7 +84,9 @@ def test_setup_and_run_reproduce_reference(oracle_backend, case):
 
     g, names, forcing = load_case(case)
     ndays = len(forcing["PREC"]) // 144
-    model = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+    from golden_util import is_lateral
+
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=is_lateral(g))
     model.setup()
     vs = model.state.variables
     compare(S.snapshot_from_vs(vs, names), g["state0"], names, what=f"{case} after setup()")
@@ -123,7 +125,7 @@ def test_scope_errors(oracle_backend):
 
     g, names, forcing = load_case("svat_uniform_rain")
     model = S.make_model(S.params_from_golden(g, names), forcing, 1)
-    model.override_settings = {"enable_lateral_flow": True}
+    model.override_settings = {"enable_routing_1D": True}
     with pytest.raises(NotImplementedError):
         model.setup()
     bad = S.params_from_golden(g, names)
