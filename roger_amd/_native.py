@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libroger_hip.so")
+LIB_PATH = os.environ.get("ROGER_HIP_LIB", os.path.join(PKG, "libroger_hip.so"))  # override: kernel experiments
 
 
 class RhConfig(C.Structure):

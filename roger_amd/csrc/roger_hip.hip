@@ -27,6 +27,12 @@
 
 #define RH_BLOCK 256
 #define RH_PRED_BLOCKS 1024  // grid of the grid-stride predicate kernels
+#ifndef RH_STEP_PREFETCH
+#define RH_STEP_PREFETCH 0  // 1: request the next stage's planes before computing the current one (measured slower: spills)
+#endif
+#ifndef RH_STEP_WAVES
+#define RH_STEP_WAVES 2     // waves per SIMD the fused kernel is compiled for (register budget 512 / waves)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // device-resident control block
@@ -494,8 +500,52 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 
 // THE hot kernel.  Loads every plane the step reads once, runs the whole step in registers,
 // stores every plane the step assigns once.
+// The fused step runs as a pipeline of stages (sets generated per sequence by tools/gen_sets.py):
+// every routine stores the planes it is the last to assign right away, and the planes the NEXT
+// routine is the first to mention are requested before the current routine computes, so their
+// latency hides behind its arithmetic.
+#define RH_LOADS(seq, rt) RH_SEQ_##seq##_LOAD_##rt(LD)
+#define RH_STORES(seq, rt) RH_SEQ_##seq##_STORE_##rt(ST)
+#if RH_STEP_PREFETCH
+#define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
+    RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)                                \
+    rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
+    MON_RUN                                                                                              \
+    RH_LOADS(seq, rt_evapotranspiration)                                                                 \
+    rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
+    RH_LOADS(seq, rt_snow)                                                                               \
+    rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)                                   \
+    RH_LOADS(seq, rt_infiltration)                                                                       \
+    rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
+    RH_LOADS(seq, sub_rt)                                                                                \
+    rt_infiltration(c, K, X); RH_STORES(seq, rt_infiltration)                                            \
+    RH_LOADS(seq, rt_capillary_rise)                                                                     \
+    sub_call; RH_STORES(seq, sub_rt)                                                                     \
+    RH_LOADS(seq, rt_storage)                                                                            \
+    rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
+    RH_LOADS(seq, ne_rt)                                                                                 \
+    rt_storage(c, X); RH_STORES(seq, rt_storage)                                                         \
+    RH_LOADS(seq, at_rt)                                                                                 \
+    bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
+    at_call; RH_STORES(seq, at_rt)
+#else
+#define RH_STAGE(seq, rt, call) RH_LOADS(seq, rt) call; RH_STORES(seq, rt)
+#define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
+    RH_STAGE(seq, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))                                       \
+    MON_LOADS MON_RUN                                                                                    \
+    RH_STAGE(seq, rt_interception, rt_interception(c, K))                                                \
+    RH_STAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                    \
+    RH_STAGE(seq, rt_snow, rt_snow(c, K, X))                                                             \
+    RH_STAGE(seq, rt_infiltration, rt_infiltration(c, K, X))                                             \
+    RH_STAGE(seq, sub_rt, sub_call)                                                                      \
+    RH_STAGE(seq, rt_capillary_rise, rt_capillary_rise(c, X))                                            \
+    RH_STAGE(seq, rt_storage, rt_storage(c, X))                                                          \
+    RH_STAGE(seq, ne_rt, bad = ne_call)                                                                  \
+    RH_STAGE(seq, at_rt, at_call)
+#endif
+
 template <bool MONTHLY, bool LATERAL>
-__global__ __launch_bounds__(RH_BLOCK) void k_step(Arena a, DevState *D, int guarded) {
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int guarded) {
     // device-driven stepping launches both variants; the one that does not apply exits at once
     if (guarded && (D->monthly != 0) != MONTHLY) return;
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -503,28 +553,27 @@ __global__ __launch_bounds__(RH_BLOCK) void k_step(Arena a, DevState *D, int gua
     const Consts K = D->K;
     const StepCtx X = D->X;
     Col c;
-    bool bad;
+    bool bad = false;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     if (D->per_cell && X.sel_w >= 0) {
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
         ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
     }
     if (MONTHLY && LATERAL) {
-        RH_SET_LOAD_rt_step_lateral_monthly(LD)
-        bad = rt_step_lateral_monthly(c, K, X, D->L, pet_v, ta_v);
-        RH_SET_STORE_rt_step_lateral_monthly(ST)
+        RH_STEP_BODY(step_lateral_monthly, rt_params_surface, RH_LOADS(step_lateral_monthly, rt_params_surface),
+                     rt_params_surface(c, D->L, X); RH_STORES(step_lateral_monthly, rt_params_surface),
+                     rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X), rt_num_error_lateral,
+                     rt_num_error_lateral(c, K), rt_after_timestep_oned, rt_after_timestep_oned(c))
     } else if (LATERAL) {
-        RH_SET_LOAD_rt_step_lateral(LD)
-        bad = rt_step_lateral(c, K, X, pet_v, ta_v);
-        RH_SET_STORE_rt_step_lateral(ST)
+        RH_STEP_BODY(step_lateral, , , , rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X),
+                     rt_num_error_lateral, rt_num_error_lateral(c, K), rt_after_timestep_oned, rt_after_timestep_oned(c))
     } else if (MONTHLY) {
-        RH_SET_LOAD_rt_step_monthly(LD)
-        bad = rt_step_monthly(c, K, X, D->L, pet_v, ta_v);
-        RH_SET_STORE_rt_step_monthly(ST)
+        RH_STEP_BODY(step_monthly, rt_params_surface, RH_LOADS(step_monthly, rt_params_surface),
+                     rt_params_surface(c, D->L, X); RH_STORES(step_monthly, rt_params_surface), rt_subsurface_runoff,
+                     rt_subsurface_runoff(c, X), rt_num_error, rt_num_error(c, K), rt_after_timestep, rt_after_timestep(c))
     } else {
-        RH_SET_LOAD_rt_step(LD)
-        bad = rt_step(c, K, X, pet_v, ta_v);
-        RH_SET_STORE_rt_step(ST)
+        RH_STEP_BODY(step, , , , rt_subsurface_runoff, rt_subsurface_runoff(c, X), rt_num_error, rt_num_error(c, K),
+                     rt_after_timestep, rt_after_timestep(c))
     }
     if (bad) atomicOr(&D->words[2], 1ull);
 }

@@ -123,6 +123,29 @@ def analyse(funcs):
     return {name: closure(name) for name in funcs if name.startswith("rt_")}
 
 
+# The fused step as a sequence of stages.  For a sequence the generator emits per-stage sets so that
+# the kernel can load a plane right before the first routine that mentions it and store a plane
+# right after the last routine that assigns it (short live ranges -> fewer registers -> two waves
+# per SIMD, one computing while the other waits on memory):
+#   LOAD_<rt>  = mention(rt) minus everything mentioned by earlier stages (already in registers)
+#   STORE_<rt> = write(rt)   minus everything written again by a later stage
+_COMMON_HEAD = ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_infiltration"]
+SEQUENCES = {
+    "step": ["rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff", "rt_capillary_rise", "rt_storage",
+                                                "rt_num_error", "rt_after_timestep"],
+    "step_monthly": ["rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
+        "rt_subsurface_runoff", "rt_capillary_rise", "rt_storage", "rt_num_error", "rt_after_timestep"],
+    "step_lateral": ["rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff_lateral", "rt_capillary_rise",
+                                                        "rt_storage", "rt_num_error_lateral", "rt_after_timestep_oned"],
+    "step_lateral_monthly": ["rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
+        "rt_subsurface_runoff_lateral", "rt_capillary_rise", "rt_storage", "rt_num_error_lateral",
+        "rt_after_timestep_oned"],
+}
+# each sequence must cover exactly what the corresponding single-function routine does
+SEQUENCE_CHECK = {"step": "rt_step", "step_monthly": "rt_step_monthly", "step_lateral": "rt_step_lateral",
+                  "step_lateral_monthly": "rt_step_lateral_monthly"}
+
+
 def main():
     src = strip_comments(open(SRC).read())
     fields = field_names()
@@ -139,6 +162,23 @@ def main():
         lines.append(f"// {name}: loads {len(ld)} planes, stores {len(st)} planes")
         lines.append(f"#define RH_SET_LOAD_{name}(X) " + " ".join(f"X({n})" for n in ld))
         lines.append(f"#define RH_SET_STORE_{name}(X) " + " ".join(f"X({n})" for n in st))
+        lines.append("")
+    for seq, stages in SEQUENCES.items():
+        resident, all_m, all_w = set(), set(), set()
+        lines.append(f"// sequence {seq}: " + " -> ".join(stages))
+        for i, rt in enumerate(stages):
+            mention, write = sets[rt]
+            later_w = set().union(*[sets[r][1] for r in stages[i + 1:]]) if i + 1 < len(stages) else set()
+            ld = sorted(mention - resident, key=order.get)
+            st = sorted(write - later_w, key=order.get)
+            resident |= mention
+            all_m |= mention
+            all_w |= write
+            lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in ld))
+            lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in st))
+        ref_m, ref_w = sets[SEQUENCE_CHECK[seq]]
+        if all_m != ref_m or all_w != ref_w:
+            sys.exit(f"sequence {seq} does not match {SEQUENCE_CHECK[seq]}")
         lines.append("")
     txt = "\n".join(lines)
     if not os.path.exists(OUT) or open(OUT).read() != txt:
