@@ -32,12 +32,12 @@ def main(fetch_dir, write_dir, n_cells, out):
     known = CALIB_PLANES * n_cells * 8
     f_cal, w_cal = avg(fetch[key(fetch, "k_calib_copy")]) * 1024, avg(write[key(write, "k_calib_copy")]) * 1024
     f_scale, w_scale = known / f_cal, known / w_cal
-    ks_f = fetch[key(fetch, "k_step<false>")]
-    ks_w = write[key(write, "k_step<false>")]
+    ks_f = fetch[key(fetch, "k_step<false")]
+    ks_w = write[key(write, "k_step<false")]
     fb, wb = avg(ks_f) * 1024 * f_scale, avg(ks_w) * 1024 * w_scale
     rec = {
         "n_cells": n_cells,
-        "kernel": "k_step<false>",
+        "kernel": "k_step<false, false>",
         "hbm_bytes_per_launch": fb + wb,
         "fetch_bytes_per_launch": fb,
         "write_bytes_per_launch": wb,
