@@ -1,0 +1,315 @@
+/*
+ * oracle/sas_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement of the reference NumPy backend's offline oxygen-18 transport step with
+ * StorAge-selection (SAS) functions, deterministic solver (RoGeR,
+ * roger/core/transport.py:949-991 `svat_transport_model_deterministic`, without write_output).
+ * One soil column at a time; age vectors are plain arrays.  It is the checker of the HIP SAS
+ * kernel and the cpu_baseline of the SAS bench; the product never includes or calls it.
+ *
+ * Pinned by tests/golden/sas_<case>.npz, produced by the reference itself
+ * (tests/golden/make_golden_sas.py), replayed in tests/test_oracle_sas.py.
+ *
+ * numpy semantics restated: `cumsum` is a running sum, `sum` over the contiguous age axis is
+ * pairwise (oc_np_sum), `max` propagates NaN, `where` evaluates both branches.
+ * SAS families: uniform (code 1) and power law (6, 61, 62) -- roger/core/sas.py:5-40, 191-240;
+ * the other families of the reference contribute exactly 0 for these codes and are not restated
+ * (SURVEY.md section 8f rank 4).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct oc_sas {
+    int64_t n, ages, substeps;
+    double vsmow, d18O_min, d18O_max;
+    const int32_t *maskCatch;
+    /* age-resolved state, (n, ages): [.., tau] of the reference */
+    double *sa_rz, *msa_rz, *sa_ss, *msa_ss;
+    /* daily fluxes set by the set_forcing hook, (n) */
+    const double *inf_mat_rz, *inf_pf_rz, *inf_pf_ss, *evap_soil, *transp, *q_rz, *q_ss, *cpr_rz, *C_in;
+    /* vs.sas_params_<flux>, (n, 8); order: evap_soil, transp, q_rz, q_ss, cpr_rz */
+    const double *sas_params[5];
+    /* outputs per outgoing flux, same order: tt, mtt (n, ages), TT (n, ages+1), C, C_iso (n) */
+    double *tt[5], *mtt[5], *TT[5], *C[5], *C_iso[5];
+    /* infiltration signals (n): inf_mat_rz, inf_pf_rz, inf_pf_ss */
+    double *C_inf[3], *C_iso_inf[3];
+    /* storages */
+    double *sa_s, *msa_s;                                  /* (n, ages) */
+    double *C_rz, *C_ss, *C_s, *C_iso_rz, *C_iso_ss, *C_iso_s; /* (n) */
+    /* age statistics (n) or NULL: 10/25/50/75/90 percentile and mean of transp, q_ss, rz, ss, s */
+    double *stats[5][6];
+} oc_sas;
+
+/* numpy pairwise add.reduce (see svat_oracle.c) */
+static double np_pairwise(const double *a, int64_t n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+    }
+}
+static double np_sum(const double *a, int64_t n) { return 0.0 + np_pairwise(a, n); }
+static double np_max(const double *a, int64_t n) {
+    double m = a[0];
+    for (int64_t i = 1; i < n; ++i) {
+        if (isnan(a[i])) return a[i];
+        if (a[i] > m) m = a[i];
+    }
+    return m;
+}
+
+/* transport.py:315-340 */
+static double conc_to_delta(const oc_sas *P, double conc) {
+    double d = 1000. * (conc / (P->vsmow * (1. - conc)) - 1.);
+    return ((d < P->d18O_min) || (d > P->d18O_max)) ? NAN : d;
+}
+
+/* SA[0] = 0, SA[1:] = cumsum(sa): transport.py:343-359 */
+static void calc_SA(double *SA, const double *sa, int64_t ages) {
+    SA[0] = 0;
+    double acc = 0;
+    for (int64_t k = 0; k < ages; ++k) {
+        acc = (k == 0) ? sa[0] : acc + sa[k];
+        SA[k + 1] = acc;
+    }
+}
+
+/* Omega(S_T) over the nages points of SA; sas.py.  `p` is the column's 8 parameters (a private
+ * copy: the storage-dependent variants 61/62 rewrite p[1], sas.py:219-226). */
+static void sas_omega(double *Om, const double *SA, int64_t nages, double *p, double mk) {
+    const double code = p[0];
+    const double Smax = np_max(SA, nages);
+    for (int64_t k = 0; k < nages; ++k) Om[k] = 0.0;
+    if (code == 1) { /* uniform, sas.py:5-40 */
+        const double S = Smax * 1.0 * mk;
+        const double lam = 1 / S * 1.0 * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (SA[k] < S ? (SA[k] > 0 ? lam * SA[k] : 0.) : 1.) * 1.0 * mk;
+        Om[nages - 1] = 1 * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    } else if (code == 6 || code == 61 || code == 62) { /* power, sas.py:191-240 */
+        const double S = Smax * mk;
+        double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
+        S_rel = (S_rel < 0 ? 0 : S_rel);
+        S_rel = (S_rel > 1 ? 1 : S_rel);
+        if (code == 61) p[1] = p[3] + ((1 - S_rel) * p[4]);
+        if (code == 62) p[1] = p[3] + (S_rel * p[4]);
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (SA[k] > 0 ? (SA[k] <= S ? pow(SA[k] / S, p[1]) : 1.) : 0.) * 1.0 * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    }
+}
+
+/* backward travel time distribution of one flux: transport.py:362-509.  work: 6 * (ages + 1) doubles */
+static void calc_tt(const oc_sas *P, double *tt, const double *SA, const double *sa, double flux, const double *params,
+                    double mk, double *work) {
+    const int64_t A = P->ages, NA = A + 1, N = P->substeps;
+    double *SAn = work, *san = SAn + NA, *TTn = san + NA, *TTi = TTn + NA, *tti = TTi + NA, *TT = tti + NA;
+    double p[8];
+    memcpy(p, params, sizeof(p));
+    memcpy(SAn, SA, sizeof(double) * NA);
+    memcpy(san, sa, sizeof(double) * A);
+    for (int64_t k = 0; k < NA; ++k) TTn[k] = 0;
+    const double h = 1.0 / (double)N;
+    for (int64_t it = 0; it < N; ++it) {
+        sas_omega(TTi, SAn, NA, p, mk);
+        double acc = 0, cum = 0;
+        for (int64_t k = 0; k < A; ++k) {
+            double d = TTi[k + 1] - TTi[k];
+            double t = (d >= 0 ? d : 0);
+            double q = (flux * t * h > san[k] ? san[k] : flux * t * h);
+            t = (flux * h > 0 ? q / (flux * h) : 0);
+            tti[k] = t;
+            san[k] += -t * flux * h;
+            acc = (k == 0) ? san[0] : acc + san[k];
+            SAn[k + 1] = acc;
+            cum = (k == 0) ? t : cum + t;
+            TTn[k + 1] += cum;
+        }
+    }
+    for (int64_t k = 0; k < NA; ++k) TT[k] = TTn[k] / (double)N;
+    for (int64_t k = 0; k < A; ++k) {
+        double t = TT[k + 1] - TT[k];
+        double q = (flux * t > sa[k] ? sa[k] : flux * t);
+        tt[k] = (flux > 0 ? q / flux : 0);
+    }
+}
+
+/* outgoing flux from `sa`/`msa` (source store); if sa_sink != NULL the water joins the sink store at
+ * the same age with volume-weighted mixing of the isotope signal.
+ * evapotranspiration.py:653-719, 831-901; subsurface_runoff.py:1531-1626, 1753-1820;
+ * capillary_rise.py:404-500 */
+static void outflux(const oc_sas *P, int64_t i, int f, double flux, double *sa, double *msa, double *sa_sink,
+                    double *msa_sink, double mk, double *work) {
+    const int64_t A = P->ages;
+    double *SA = work, *scratch = work + (A + 1);
+    double *tt = P->tt[f] + i * A, *mtt = P->mtt[f] + i * A, *TT = P->TT[f] + i * (A + 1);
+    calc_SA(SA, sa, A);
+    for (int64_t k = 0; k <= A; ++k) SA[k] *= mk;
+    calc_tt(P, tt, SA, sa, flux, P->sas_params[f] + i * 8, mk, scratch);
+    for (int64_t k = 0; k < A; ++k) tt[k] *= mk;
+    {
+        double acc = 0;
+        for (int64_t k = 0; k < A; ++k) {
+            acc = (k == 0) ? tt[0] : acc + tt[k];
+            TT[k + 1] = acc;
+        }
+    }
+    for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0 ? msa[k] : 0) * mk;
+    {   /* calc_conc_iso_flux :512-535 */
+        double *prod = scratch;
+        for (int64_t k = 0; k < A; ++k) prod[k] = mtt[k] * tt[k];
+        const double s = np_sum(tt, A);
+        double conc = (s > 0 ? np_sum(prod, A) / s : NAN);
+        conc = (conc != 0 ? conc : NAN);
+        P->C[f][i] = conc * mk;
+        P->C_iso[f][i] = conc_to_delta(P, P->C[f][i]) * mk;
+    }
+    if (sa_sink) {
+        for (int64_t k = 0; k < A; ++k) {
+            const double add = tt[k] * flux;
+            msa_sink[k] = (add + sa_sink[k] > 0 ? msa_sink[k] * (sa_sink[k] / (add + sa_sink[k])) + mtt[k] * (add / (add + sa_sink[k]))
+                                                : msa_sink[k]) * mk;
+        }
+    }
+    for (int64_t k = 0; k < A; ++k) { /* update_sa :599-619 */
+        double v = sa[k] + -flux * tt[k];
+        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
+        sa[k] = v * mk;
+    }
+    if (sa_sink)
+        for (int64_t k = 0; k < A; ++k) sa_sink[k] += tt[k] * flux * mk;
+    for (int64_t k = 0; k < A; ++k) msa[k] = (sa[k] <= 0 ? 0 : msa[k]) * mk;
+}
+
+/* infiltration into age class 0: infiltration.py:2218-2346 (rz: matrix then preferential flow),
+ * :2441-2512 (ss) */
+static void inflow(const oc_sas *P, int64_t i, int which, double inf, double *sa, double *msa, double mk) {
+    const int64_t A = P->ages;
+    const double C_in = P->C_in[i];
+    P->C_inf[which][i] = (inf > 0 ? C_in : 0) * mk;
+    P->C_iso_inf[which][i] = conc_to_delta(P, P->C_inf[which][i]) * mk;
+    for (int64_t k = 0; k < A; ++k) {
+        const double ttk = (k == 0) ? (inf > 0 ? 1 : 0) * mk : 0.0;
+        const double mttk = (k == 0) ? (inf > 0 ? C_in : 0) * mk : 0.0;
+        msa[k] = (inf * ttk + sa[k] > 0 ? msa[k] * (sa[k] / (ttk * inf + sa[k])) + mttk * ((ttk * inf) / (inf * ttk + sa[k]))
+                                       : msa[k]) * mk;
+    }
+    sa[0] += inf * mk;
+}
+
+/* calc_conc_iso_storage :538-562 */
+static double conc_storage(const double *sa, const double *msa, int64_t A, double *scratch) {
+    for (int64_t k = 0; k < A; ++k) scratch[k] = msa[k] * sa[k];
+    const double s = np_sum(sa, A);
+    return (s > 0 ? np_sum(scratch, A) / s : 0);
+}
+
+/* np.interp(q, cdf, ages 1..A) with the NaN rule of calc_age_percentile, transport.py:9-56 */
+static double age_percentile(const double *cdf, int64_t A, double q) {
+    if (!(np_max(cdf, A) > 0)) return NAN;
+    if (q < cdf[0]) return 1.0;
+    if (q >= cdf[A - 1]) return (double)A;
+    int64_t j = 0;
+    while (j + 1 < A && !(q < cdf[j + 1])) ++j; /* largest j with cdf[j] <= q  (cdf non-decreasing) */
+    const double x0 = cdf[j], x1 = cdf[j + 1];
+    if (x1 == x0) return (double)(j + 1);
+    const double slope = ((double)(j + 2) - (double)(j + 1)) / (x1 - x0);
+    return slope * (q - x0) + (double)(j + 1);
+}
+
+/* ageing by one day: transport.py:682-739 */
+static void ageing(double *sa, double *msa, int64_t A, double *scratch) {
+    double *sam1 = scratch, *msam1 = scratch + A;
+    memcpy(sam1, sa, sizeof(double) * A);
+    memcpy(msam1, msa, sizeof(double) * A);
+    for (int64_t k = 1; k < A; ++k) sa[k] = sam1[k - 1];
+    for (int64_t k = 1; k < A; ++k) msa[k] = msam1[k - 1];
+    msa[0] = 0;
+    {
+        const double tot = sa[A - 1] + sam1[A - 1];
+        double v = (tot > 0 ? msam1[A - 1] * (sam1[A - 1] / tot) + msa[A - 1] * (sa[A - 1] / tot) : 0);
+        msa[A - 1] = isnan(v) ? 0 : v;
+    }
+    sa[0] = 0;
+    sa[A - 1] += sam1[A - 1];
+    sa[A - 1] = (sa[A - 1] < 1e-8 ? 0 : sa[A - 1]);
+    msa[A - 1] = (sa[A - 1] <= 0 ? NAN : msa[A - 1]);
+}
+
+/* one day of svat_transport_model_deterministic for all columns */
+void oc_sas_step(const oc_sas *P) {
+    const int64_t A = P->ages, NA = A + 1;
+    double *work = (double *)malloc(sizeof(double) * (8 * NA + 4));
+    for (int64_t i = 0; i < P->n; ++i) {
+        const double mk = (double)P->maskCatch[i];
+        double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+        inflow(P, i, 0, P->inf_mat_rz[i], sa_rz, msa_rz, mk);
+        inflow(P, i, 1, P->inf_pf_rz[i], sa_rz, msa_rz, mk);
+        outflux(P, i, 0, P->evap_soil[i], sa_rz, msa_rz, NULL, NULL, mk, work);
+        outflux(P, i, 1, P->transp[i], sa_rz, msa_rz, NULL, NULL, mk, work);
+        outflux(P, i, 2, P->q_rz[i], sa_rz, msa_rz, sa_ss, msa_ss, mk, work);
+        inflow(P, i, 2, P->inf_pf_ss[i], sa_ss, msa_ss, mk);
+        outflux(P, i, 3, P->q_ss[i], sa_ss, msa_ss, NULL, NULL, mk, work);
+        outflux(P, i, 4, P->cpr_rz[i], sa_ss, msa_ss, sa_rz, msa_rz, mk, work);
+        /* storages: root_zone.py:189-217, subsoil.py:159-188, soil.py:1036-1090 */
+        for (int64_t k = 0; k < A; ++k) sa_rz[k] = (sa_rz[k] < 1e-8 ? 0 : sa_rz[k]);
+        P->C_rz[i] = conc_storage(sa_rz, msa_rz, A, work) * mk;
+        P->C_iso_rz[i] = conc_to_delta(P, P->C_rz[i]) * mk;
+        for (int64_t k = 0; k < A; ++k) sa_ss[k] = (sa_ss[k] < 1e-8 ? 0 : sa_ss[k]);
+        P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work) * mk;
+        P->C_iso_ss[i] = conc_to_delta(P, P->C_ss[i]) * mk;
+        double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+        for (int64_t k = 0; k < A; ++k) {
+            sa_s[k] = sa_rz[k] + sa_ss[k] * mk;
+            const double tot = sa_rz[k] + sa_ss[k];
+            double v = (tot > 0 ? msa_rz[k] * (sa_rz[k] / tot) + msa_ss[k] * (sa_ss[k] / tot) : 0);
+            msa_s[k] = isnan(v) ? 0 : v;
+        }
+        P->C_s[i] = conc_storage(sa_s, msa_s, A, work) * mk;
+        P->C_iso_s[i] = conc_to_delta(P, P->C_s[i]) * mk;
+        if (P->stats[0][0]) { /* transport.py:59-312 */
+            static const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
+            const double *ttd[2] = {P->tt[1] + i * A, P->tt[3] + i * A};
+            const double *TTd[2] = {P->TT[1] + i * NA + 1, P->TT[3] + i * NA + 1};
+            for (int d = 0; d < 2; ++d) {
+                for (int q = 0; q < 5; ++q) P->stats[d][q][i] = age_percentile(TTd[d], A, Q[q]);
+                for (int64_t k = 0; k < A; ++k) work[k] = (double)(k + 1) * ttd[d][k];
+                P->stats[d][5][i] = (np_sum(ttd[d], A) > 0 ? np_sum(work, A) : NAN);
+            }
+            /* residence time distributions of the storages: RT = SA / max(SA), :155-312 */
+            const double *store[3] = {sa_rz, sa_ss, sa_s};
+            for (int d = 0; d < 3; ++d) {
+                double *RT = work, *rt = work + NA, *prod = rt + A;
+                calc_SA(RT, store[d], A);
+                for (int64_t k = 0; k < NA; ++k) RT[k] *= mk;
+                const double mx = np_max(RT, NA);
+                for (int64_t k = 0; k < NA; ++k) RT[k] = (mx > 0 ? RT[k] / mx : 0);
+                for (int64_t k = 0; k < A; ++k) rt[k] = RT[k + 1] - RT[k];
+                for (int q = 0; q < 5; ++q) {
+                    /* the reference never assigns rt10/rt90 of root zone and subsoil (:181-196, :232-247) */
+                    if (d < 2 && (q == 0 || q == 4)) continue;
+                    P->stats[2 + d][q][i] = age_percentile(RT + 1, A, Q[q]);
+                }
+                for (int64_t k = 0; k < A; ++k) prod[k] = (double)(k + 1) * rt[k];
+                P->stats[2 + d][5][i] = (np_sum(rt, A) > 0 ? np_sum(prod, A) : NAN);
+            }
+        }
+        ageing(sa_rz, msa_rz, A, work);
+        ageing(sa_ss, msa_ss, A, work);
+    }
+    free(work);
+}

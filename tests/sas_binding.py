@@ -1,0 +1,190 @@
+"""ctypes binding of oracle/libsas_oracle.so and golden-file helpers for the SAS / oxygen-18
+transport step -- test infrastructure only; nothing under roger_amd/ imports this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(REPO, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libsas_oracle.so")
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+FLUXES = ("evap_soil", "transp", "q_rz", "q_ss", "cpr_rz")          # order of the outgoing fluxes in the ABI
+INFS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss")
+STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
+STAT_Q = ("10", "25", "50", "75", "90", "avg")
+SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30")
+
+_P = C.POINTER(C.c_double)
+
+
+class OcSas(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("ages", C.c_int64), ("substeps", C.c_int64),
+        ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double),
+        ("maskCatch", C.POINTER(C.c_int32)),
+        ("sa_rz", _P), ("msa_rz", _P), ("sa_ss", _P), ("msa_ss", _P),
+        ("inf_mat_rz", _P), ("inf_pf_rz", _P), ("inf_pf_ss", _P), ("evap_soil", _P), ("transp", _P),
+        ("q_rz", _P), ("q_ss", _P), ("cpr_rz", _P), ("C_in", _P),
+        ("sas_params", _P * 5),
+        ("tt", _P * 5), ("mtt", _P * 5), ("TT", _P * 5), ("C", _P * 5), ("C_iso", _P * 5),
+        ("C_inf", _P * 3), ("C_iso_inf", _P * 3),
+        ("sa_s", _P), ("msa_s", _P),
+        ("C_rz", _P), ("C_ss", _P), ("C_s", _P), ("C_iso_rz", _P), ("C_iso_ss", _P), ("C_iso_s", _P),
+        ("stats", (_P * 6) * 5),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_P)
+
+
+# roger/settings.py: VSMOW_conc18O, d18O_min, d18O_max
+VSMOW = 2005.2e-6
+D18O_MIN = -20.0
+D18O_MAX = 0.0
+
+
+class SasState:
+    """All arrays of one SAS problem: state (sa/msa), daily inputs, outputs.  Used with the oracle
+    (`step_oracle`) and, in the GPU tests, as the host mirror of the HIP context."""
+
+    def __init__(self, n, ages, substeps, age_statistics=False):
+        self.n, self.ages, self.substeps = int(n), int(ages), int(substeps)
+        self.age_statistics = bool(age_statistics)
+        A = self.ages
+        z = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
+        self.maskCatch = np.ones(n, dtype=np.int32)
+        self.state = {k: z(n, A) for k in ("sa_rz", "msa_rz", "sa_ss", "msa_ss")}
+        self.inp = {k: z(n) for k in INFS + FLUXES + ("C_in",)}
+        self.sas = {f: z(n, 8) for f in FLUXES}
+        self.out = {}
+        for f in FLUXES:
+            self.out[f"tt_{f}"] = z(n, A)
+            self.out[f"mtt_{f}"] = z(n, A)
+            self.out[f"TT_{f}"] = z(n, A + 1)
+            self.out[f"C_{f}"] = z(n)
+            self.out[f"C_iso_{f}"] = z(n)
+        for f in INFS:
+            self.out[f"C_{f}"] = z(n)
+            self.out[f"C_iso_{f}"] = z(n)
+        for k in ("sa_s", "msa_s"):
+            self.out[k] = z(n, A)
+        for k in ("C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"):
+            self.out[k] = z(n)
+        if self.age_statistics:
+            for w, p in STAT_TARGETS:
+                for q in STAT_Q:
+                    self.out[f"{p}{q}_{w}"] = z(n)
+
+    def struct(self):
+        s = OcSas(n=self.n, ages=self.ages, substeps=self.substeps, vsmow=VSMOW, d18O_min=D18O_MIN, d18O_max=D18O_MAX)
+        s.maskCatch = self.maskCatch.ctypes.data_as(C.POINTER(C.c_int32))
+        for k, a in self.state.items():
+            setattr(s, k, _ptr(a))
+        for k, a in self.inp.items():
+            setattr(s, k, _ptr(a))
+        for i, f in enumerate(FLUXES):
+            s.sas_params[i] = _ptr(self.sas[f])
+            s.tt[i] = _ptr(self.out[f"tt_{f}"])
+            s.mtt[i] = _ptr(self.out[f"mtt_{f}"])
+            s.TT[i] = _ptr(self.out[f"TT_{f}"])
+            s.C[i] = _ptr(self.out[f"C_{f}"])
+            s.C_iso[i] = _ptr(self.out[f"C_iso_{f}"])
+        for i, f in enumerate(INFS):
+            s.C_inf[i] = _ptr(self.out[f"C_{f}"])
+            s.C_iso_inf[i] = _ptr(self.out[f"C_iso_{f}"])
+        for k in ("sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"):
+            setattr(s, k, _ptr(self.out[k]))
+        if self.age_statistics:
+            for i, (w, p) in enumerate(STAT_TARGETS):
+                for j, q in enumerate(STAT_Q):
+                    s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
+        return s
+
+    def step_oracle(self):
+        lib().oc_sas_step(C.byref(self.struct()))
+
+
+class SasGolden:
+    """One tests/golden/sas_<case>.npz."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+        self.nx, self.ny, self.ndays, self.ages, self.substeps, self.stats = (int(v) for v in self.z["meta"])
+        self.n = self.nx * self.ny
+
+    def day(self, d, var):
+        return self.z[f"d{d:03d}_{var}"]
+
+    def new_state(self):
+        st = SasState(self.n, self.ages, self.substeps, bool(self.stats))
+        st.maskCatch[:] = self.z["maskCatch"]
+        for f in FLUXES:
+            st.sas[f][:] = self.z[f"sas_{f}"]
+        return st
+
+    def load_state(self, st, d):
+        """State at the end of day d (after ageing) = start of day d + 1."""
+        for k in st.state:
+            st.state[k][:] = self.day(d, k)
+
+    def load_inputs(self, st, d):
+        """Daily inputs of day d as the reference's set_forcing hook provides them
+        (benchmarks/SVATOXYGEN18_benchmark.py:384-437)."""
+        z = self.z
+        flat = lambda k: z[f"in_{k}"][:, :, d].reshape(-1)  # noqa: E731
+        st.inp["inf_mat_rz"][:] = flat("inf_mat_rz")
+        st.inp["inf_pf_rz"][:] = (z["in_inf_mp_rz"] + z["in_inf_sc_rz"])[:, :, d].reshape(-1)
+        st.inp["inf_pf_ss"][:] = flat("inf_ss")
+        for f in FLUXES:
+            st.inp[f][:] = flat(f)
+        st.inp["C_in"][:] = self.day(d, "C_in")
+
+
+def compare_sas(got, want, what, rtol=1e-10, atol=1e-12):
+    """NaN-aware comparison (NaN marks 'no signal' in the reference)."""
+    got, want = np.asarray(got), np.asarray(want)
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), f"{what}: NaN pattern differs ({nan_g.sum()} vs {nan_w.sum()})"
+    ok = np.isclose(got, want, rtol=rtol, atol=atol) | nan_w
+    if not ok.all():
+        idx = np.argwhere(~ok)[0]
+        raise AssertionError(f"{what}: {np.count_nonzero(~ok)} mismatches, first at {tuple(idx)}: "
+                             f"{got[tuple(idx)]!r} vs {want[tuple(idx)]!r}")
+
+
+# Day of the first "residue tie" of the free-running oracle against the reference, per golden case.
+# Within a day an emptied age class keeps `sa - flux * (sa / flux)` = a few 1e-16 of either sign (or
+# exactly 0) until the end-of-day snap (`sa < 1e-8 -> 0`); the power-law SAS with k < 1 is infinitely
+# steep at 0, so such a class claims (1e-18)**0.15 ~ 0.2 % of the NEXT flux of the same day without being
+# able to deliver it.  Whether the residue is 0 or 1e-16 depends on the last bit of `pow`, which differs
+# between numpy's AVX-512 pow and libm (and the GPU's ocml pow).  From that day on a trajectory is only
+# reproducible to ~1e-3 mm / 1e-4 permil; the per-day tests from reference states stay at 1e-10.
+FIRST_TIE = {"sas_power_a40": 11}
+
+
+def check_day_loose(g, st, d, tag, atol_mm=2e-2, atol_permil=2e-3):
+    for k in ("sa_rz", "sa_ss"):
+        err = np.abs(st.state[k] - g.day(d, k)).max()
+        assert err < atol_mm, f"{tag} day {d} {k}: {err}"
+    for k in ("C_iso_rz", "C_iso_ss", "C_iso_s", "C_iso_q_ss", "C_iso_transp"):
+        a, b = st.out[k], g.day(d, k)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{tag} day {d} {k}: NaN pattern"
+        if np.isfinite(b).any():
+            err = np.nanmax(np.abs(a - b))
+            assert err < atol_permil, f"{tag} day {d} {k}: {err}"
