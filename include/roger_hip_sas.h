@@ -1,0 +1,111 @@
+/*
+ * include/roger_hip_sas.h -- C ABI of the MI355X-native ("hip") backend for RoGeR's offline
+ * oxygen-18 transport step with StorAge-selection (SAS) functions, deterministic solver.
+ *
+ * Replaces, for `enable_offline_transport and enable_oxygen18 and sas_solver == "deterministic"`,
+ * the body of `svat_transport_model_deterministic` (roger/core/transport.py:949-991), i.e. the
+ * `@roger_kernel`s
+ *   calc_infiltration_rz_transport_iso_kernel      core/infiltration.py:2218-2346
+ *   calc_evaporation_transport_iso_kernel          core/evapotranspiration.py:653-719
+ *   calc_transpiration_transport_iso_kernel        core/evapotranspiration.py:831-901
+ *   calc_percolation_rz_transport_iso_kernel       core/subsurface_runoff.py:1531-1626
+ *   calc_infiltration_ss_transport_iso_kernel      core/infiltration.py:2441-2512
+ *   calc_percolation_ss_transport_iso_kernel       core/subsurface_runoff.py:1753-1820
+ *   calc_capillary_rise_rz_transport_iso_kernel    core/capillary_rise.py:404-500
+ *   calc_root_zone/subsoil/soil_transport_iso_kernel  core/root_zone.py:189-217, subsoil.py:159-188, soil.py:1036-1090
+ *   calculate_age_statistics_*                     core/transport.py:59-312
+ *   calc_ageing_sa_msa_iso_kernel                  core/transport.py:682-739, 780-805
+ * with the helpers calc_SA, calc_tt, calc_mtt, calc_conc_iso_flux, calc_conc_iso_storage,
+ * conc_to_delta, update_sa (transport.py:315-619) and the SAS families of core/sas.py.
+ *
+ * Same conventions as roger_hip.h: plain pointers and sizes, 0 / negative rh_status returns,
+ * rh_sas_last_error for the text, one context = one HIP device + one stream, asynchronous
+ * launches fenced by rh_sas_sync / rh_sas_download.
+ *
+ * Data layout.  All arrays are float64 (maskCatch: int32) over the rank's interior cells in C
+ * order (x, y); age-resolved arrays are (n_cells, ages) / (n_cells, ages + 1) with the age axis
+ * contiguous, exactly the reference's `vs.sa_rz[2:-2, 2:-2, vs.tau, :]` etc., so that one
+ * workgroup streams one column's age vector with unit stride.  Only the prognostic state
+ * (sa_rz, msa_rz, sa_ss, msa_ss) has to live in HBM; the per-flux distributions (tt, mtt, TT),
+ * sa_s and msa_s are diagnostics that are written only when the context was created with
+ * `keep_distributions` (they are 17 more age vectors per column).
+ */
+#ifndef ROGER_HIP_SAS_H
+#define ROGER_HIP_SAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_SAS_MAX_NAGES 4096 /* ages + 1 <= this (benchmark: ages = 1000, SVATOXYGEN18_benchmark.py:28-44) */
+
+typedef struct rh_sas_config {
+    int64_t n_cells;           /* local interior cells (nx * ny of this rank) */
+    int32_t ages;              /* settings.ages; nages = ages + 1 */
+    int32_t substeps;          /* settings.sas_solver_substeps */
+    int32_t device;            /* HIP device ordinal */
+    int32_t forcing_days;      /* number of days of daily input resident on the device (>= 1) */
+    int32_t age_statistics;    /* settings.enable_age_statistics */
+    int32_t keep_distributions;/* also write tt_*, mtt_*, TT_*, sa_s, msa_s (diagnostics) */
+    double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78) */
+} rh_sas_config;
+
+typedef struct rh_sas_ctx rh_sas_ctx;
+
+void rh_sas_default_config(rh_sas_config *cfg);
+int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out);
+void rh_sas_destroy(rh_sas_ctx *ctx);
+const char *rh_sas_last_error(const rh_sas_ctx *ctx); /* ctx may be NULL for rh_sas_create failures */
+int rh_sas_set_stream(rh_sas_ctx *ctx, void *hip_stream);
+int rh_sas_sync(rh_sas_ctx *ctx);
+
+/* ---- array registry ------------------------------------------------------------------------
+ * Names follow the reference variables (roger/variables.py): state `sa_rz msa_rz sa_ss msa_ss`;
+ * daily inputs (forcing_days, n) `inf_mat_rz inf_pf_rz inf_pf_ss evap_soil transp q_rz q_ss cpr_rz
+ * C_in` (what `set_forcing` assigns, benchmarks/SVATOXYGEN18_benchmark.py:384-437); parameters
+ * `maskCatch` (n, int32), `sas_params_<flux>` (n, 8); per-cell results `C_<flux> C_iso_<flux>`,
+ * `C_inf_* C_iso_inf_*`, `C_rz C_ss C_s C_iso_rz C_iso_ss C_iso_s`, the age statistics
+ * `tt{10,25,50,75,90,avg}_{transp,q_ss}`, `rt{..}_{rz,ss,s}`; diagnostics `tt_<flux> mtt_<flux>`
+ * (n, ages), `TT_<flux>` (n, ages + 1), `sa_s msa_s` (n, ages). */
+int rh_sas_num_arrays(void);
+const char *rh_sas_array_name(int array);
+int rh_sas_array_index(const char *name);                  /* -1 if unknown */
+int64_t rh_sas_array_elems(const rh_sas_ctx *ctx, int array); /* elements held by this context (0: not allocated) */
+int rh_sas_array_is_int(int array);
+int rh_sas_upload(rh_sas_ctx *ctx, int array, const void *host, size_t bytes);
+int rh_sas_download(rh_sas_ctx *ctx, int array, void *host, size_t bytes); /* synchronises */
+void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int array);
+
+/* ---- the step --------------------------------------------------------------------------------
+ * Stages of one day, in the order of svat_transport_model_deterministic; `stages` is a bit mask so
+ * that a driver (and the parity tests) can run the reference's kernels one at a time with the
+ * state left in HBM in between.  rh_sas_step == rh_sas_stages(ctx, day, RH_SAS_ALL). */
+enum {
+    RH_SAS_INF_RZ = 1 << 0,   /* infiltration into the root zone (matrix, then preferential flow) */
+    RH_SAS_EVAP = 1 << 1,     /* soil evaporation */
+    RH_SAS_TRANSP = 1 << 2,   /* transpiration */
+    RH_SAS_Q_RZ = 1 << 3,     /* root zone percolation -> subsoil */
+    RH_SAS_INF_SS = 1 << 4,   /* preferential-flow infiltration into the subsoil */
+    RH_SAS_Q_SS = 1 << 5,     /* subsoil percolation */
+    RH_SAS_CPR = 1 << 6,      /* capillary rise subsoil -> root zone */
+    RH_SAS_STORAGE = 1 << 7,  /* root zone / subsoil / soil concentrations (+ age statistics if enabled) */
+    RH_SAS_AGEING = 1 << 8,   /* shift by one age class, merge the oldest */
+    RH_SAS_ALL = (1 << 9) - 1
+};
+/* `day` selects the row of the daily inputs: row (day mod forcing_days). */
+int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages);
+int rh_sas_step(rh_sas_ctx *ctx, int64_t day);
+/* `ndays` whole steps for days day0, day0 + 1, ... enqueued back to back. */
+int rh_sas_run_days(rh_sas_ctx *ctx, int64_t day0, int64_t ndays);
+
+/* HIP-event timing of the step kernel (same protocol as rh_enable_timing / rh_timing_summary). */
+int rh_sas_enable_timing(rh_sas_ctx *ctx, int on);
+int rh_sas_timing_summary(rh_sas_ctx *ctx, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROGER_HIP_SAS_H */

@@ -98,8 +98,155 @@ def load():
     lib.rh_predicate_words.restype = vp
     lib.rh_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.rh_enable_timing.argtypes = [vp, i32]
+    _declare_sas(lib)
     _lib = lib
     return lib
+
+
+class RhSasConfig(C.Structure):
+    _fields_ = [("n_cells", C.c_int64), ("ages", C.c_int32), ("substeps", C.c_int32), ("device", C.c_int32),
+                ("forcing_days", C.c_int32), ("age_statistics", C.c_int32), ("keep_distributions", C.c_int32),
+                ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double)]
+
+
+def _declare_sas(lib):
+    """include/roger_hip_sas.h"""
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    lib.rh_sas_default_config.argtypes = [C.POINTER(RhSasConfig)]
+    lib.rh_sas_default_config.restype = None
+    lib.rh_sas_create.argtypes = [C.POINTER(RhSasConfig), C.POINTER(vp)]
+    lib.rh_sas_destroy.argtypes = [vp]
+    lib.rh_sas_destroy.restype = None
+    lib.rh_sas_last_error.argtypes = [vp]
+    lib.rh_sas_last_error.restype = C.c_char_p
+    lib.rh_sas_set_stream.argtypes = [vp, vp]
+    lib.rh_sas_sync.argtypes = [vp]
+    lib.rh_sas_num_arrays.restype = i32
+    lib.rh_sas_array_name.argtypes = [i32]
+    lib.rh_sas_array_name.restype = C.c_char_p
+    lib.rh_sas_array_index.argtypes = [C.c_char_p]
+    lib.rh_sas_array_elems.argtypes = [vp, i32]
+    lib.rh_sas_array_elems.restype = i64
+    lib.rh_sas_array_is_int.argtypes = [i32]
+    lib.rh_sas_upload.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rh_sas_download.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rh_sas_array_device_ptr.argtypes = [vp, i32]
+    lib.rh_sas_array_device_ptr.restype = vp
+    lib.rh_sas_stages.argtypes = [vp, i64, i32]
+    lib.rh_sas_step.argtypes = [vp, i64]
+    lib.rh_sas_run_days.argtypes = [vp, i64, i64]
+    lib.rh_sas_enable_timing.argtypes = [vp, i32]
+    lib.rh_sas_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+
+
+SAS_DECLARED_SYMBOLS = (
+    "rh_sas_default_config", "rh_sas_create", "rh_sas_destroy", "rh_sas_last_error", "rh_sas_set_stream",
+    "rh_sas_sync", "rh_sas_num_arrays", "rh_sas_array_name", "rh_sas_array_index", "rh_sas_array_elems",
+    "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_array_device_ptr", "rh_sas_stages",
+    "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary",
+)
+
+# stage bits of rh_sas_stages (include/roger_hip_sas.h)
+SAS_STAGES = dict(INF_RZ=1, EVAP=2, TRANSP=4, Q_RZ=8, INF_SS=16, Q_SS=32, CPR=64, STORAGE=128, AGEING=256, ALL=511)
+
+
+class SasContext:
+    """One SAS / oxygen-18 transport problem on the device (rh_sas_ctx).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, n_cells, ages, substeps=1, device=0, forcing_days=1, age_statistics=False,
+                 keep_distributions=False, **settings):
+        lib = load()
+        cfg = RhSasConfig()
+        lib.rh_sas_default_config(C.byref(cfg))
+        cfg.n_cells, cfg.ages, cfg.substeps, cfg.device = int(n_cells), int(ages), int(substeps), int(device)
+        cfg.forcing_days = int(forcing_days)
+        cfg.age_statistics, cfg.keep_distributions = int(bool(age_statistics)), int(bool(keep_distributions))
+        for k, v in settings.items():
+            if k not in ("vsmow", "d18O_min", "d18O_max"):
+                raise AttributeError(f"unknown setting {k}")
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.rh_sas_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise NativeError(f"rh_sas_create failed ({rc}): {lib.rh_sas_last_error(None).decode()}")
+        self._h, self._lib, self.cfg = h, lib, cfg
+        self.n, self.ages, self.substeps, self.forcing_days = cfg.n_cells, cfg.ages, cfg.substeps, cfg.forcing_days
+        self.names = [lib.rh_sas_array_name(i).decode() for i in range(lib.rh_sas_num_arrays())]
+        self._index = {nm: i for i, nm in enumerate(self.names)}
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self._lib.rh_sas_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rh_sas_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def index(self, name):
+        try:
+            return self._index[name]
+        except KeyError:
+            raise KeyError(f"unknown SAS array {name!r}") from None
+
+    def shape(self, name):
+        """Logical shape of an array held by this context."""
+        i = self.index(name)
+        elems = self._lib.rh_sas_array_elems(self._h, i)
+        if elems == 0:
+            raise NativeError(f"array {name} is not held by this context (age_statistics / keep_distributions)")
+        if name in DAILY_INPUTS:
+            return (self.forcing_days, self.n)
+        if elems == self.n:
+            return (self.n,)
+        return (self.n, elems // self.n)
+
+    def dtype(self, name):
+        return np.int32 if self._lib.rh_sas_array_is_int(self.index(name)) else np.float64
+
+    def upload(self, name, host):
+        a = np.ascontiguousarray(host, dtype=self.dtype(name))
+        if a.shape != self.shape(name):
+            raise ValueError(f"{name}: shape {a.shape}, expected {self.shape(name)}")
+        self._check(self._lib.rh_sas_upload(self._h, self.index(name), a.ctypes.data_as(C.c_void_p), a.nbytes),
+                    f"rh_sas_upload({name})")
+
+    def download(self, name):
+        a = np.empty(self.shape(name), dtype=self.dtype(name))
+        self._check(self._lib.rh_sas_download(self._h, self.index(name), a.ctypes.data_as(C.c_void_p), a.nbytes),
+                    f"rh_sas_download({name})")
+        return a
+
+    def device_ptr(self, name):
+        return self._lib.rh_sas_array_device_ptr(self._h, self.index(name))
+
+    def stages(self, day, mask):
+        self._check(self._lib.rh_sas_stages(self._h, int(day), int(mask)), "rh_sas_stages")
+
+    def step(self, day):
+        self._check(self._lib.rh_sas_step(self._h, int(day)), "rh_sas_step")
+
+    def run_days(self, day0, ndays):
+        self._check(self._lib.rh_sas_run_days(self._h, int(day0), int(ndays)), "rh_sas_run_days")
+
+    def sync(self):
+        self._check(self._lib.rh_sas_sync(self._h), "rh_sas_sync")
+
+    def set_stream(self, stream):
+        self._check(self._lib.rh_sas_set_stream(self._h, C.c_void_p(stream)), "rh_sas_set_stream")
+
+    def enable_timing(self, on=True):
+        self._check(self._lib.rh_sas_enable_timing(self._h, int(on)), "rh_sas_enable_timing")
+
+    def timing_summary(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._lib.rh_sas_timing_summary(self._h, C.byref(ms), C.byref(cnt)), "rh_sas_timing_summary")
+        return ms.value, cnt.value
+
+
+DAILY_INPUTS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss", "evap_soil", "transp", "q_rz", "q_ss", "cpr_rz", "C_in")
 
 
 DECLARED_SYMBOLS = (

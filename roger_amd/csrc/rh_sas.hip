@@ -1,0 +1,890 @@
+// rh_sas.hip -- SAS / oxygen-18 transport step (deterministic solver) for gfx950, and its C ABI
+// (include/roger_hip_sas.h).
+//
+// One workgroup per soil column.  The age axis is laid out blocked over the workgroup: thread t
+// owns the E consecutive age classes [t * E, (t + 1) * E) of every age vector in registers, so the
+// whole day -- 2 inflows, 5 outgoing fluxes with `substeps` sub-steps each, storage concentrations,
+// age statistics, ageing -- runs on one read and one write of the four state vectors
+// (sa_rz, msa_rz, sa_ss, msa_ss): 8 * ages * 8 bytes per column and day.  The arithmetic is
+// dominated by the power-law SAS function, 5 * substeps * (ages + 1) `pow` per column and day
+// (3 * 10^4 at ages = 1000), which makes this kernel fp64-ALU bound, not HBM bound.
+//
+// Every formula below is a per-element restatement of the reference's array expressions (file:line
+// in the comments; roger/core/transport.py unless said otherwise) with the reference's operation
+// order; no FMA contraction (-ffp-contract=off).  Two deliberate differences, both at rounding
+// level: prefix sums are block scans instead of sequential `cumsum`s, sums over ages are tree
+// reductions instead of numpy's pairwise sums.  The scan is built so that what the algorithm is
+// sensitive to still holds exactly: cumulative values are non-decreasing for non-negative input and
+// an empty age class contributes an exact 0 to every difference of cumulative values.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "roger_hip.h"
+#include "roger_hip_sas.h"
+
+#define SAS_DEV __device__ __forceinline__
+
+enum SasArr {
+#define RH_SAS_ARRAY(name, kind, when) SA_##name,
+#include "rh_sas_arrays.def"
+#undef RH_SAS_ARRAY
+    SA_COUNT
+};
+enum SasKind { K_AGE, K_NAGE, K_CELL, K_DAILY, K_PARAM, K_MASK };
+enum SasWhen { W_ALWAYS, W_STATS, W_DIAG };
+
+static const char *const SAS_NAMES[] = {
+#define RH_SAS_ARRAY(name, kind, when) #name,
+#include "rh_sas_arrays.def"
+#undef RH_SAS_ARRAY
+};
+static const unsigned char SAS_KIND[] = {
+#define RH_SAS_ARRAY(name, kind, when) K_##kind,
+#include "rh_sas_arrays.def"
+#undef RH_SAS_ARRAY
+};
+static const unsigned char SAS_WHEN[] = {
+#define RH_SAS_ARRAY(name, kind, when) W_##when,
+#include "rh_sas_arrays.def"
+#undef RH_SAS_ARRAY
+};
+
+struct SasArgs {
+    int64_t n;
+    int64_t day_off;  // row of the daily inputs * n
+    int ages, substeps, stages, stats, diag;
+    double vsmow, dmin, dmax;
+    int *unsupported;  // device flag: a column asked for a SAS family this kernel does not implement
+    void *a[SA_COUNT];
+};
+
+// ---------------------------------------------------------------------------------------------
+// workgroup primitives over the blocked age layout
+// ---------------------------------------------------------------------------------------------
+template <int W>
+struct Blk {
+    int tid, lane, wave;
+    unsigned phase;        // alternates the double-buffered LDS scratch; one barrier per use
+    double (*red)[W][8];   // [2][W][8]
+    double (*xch)[W][2];   // [2][W][2]
+};
+
+SAS_DEV double wave_sum(double v) {
+    for (int off = 32; off; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+SAS_DEV double wave_max(double v) {
+    for (int off = 32; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// value of the previous thread (thread 0: `first`), two values per call
+template <int W>
+SAS_DEV void blk_prev2(Blk<W> &B, double a, double b, double a0, double b0, double &pa, double &pb) {
+    pa = __shfl_up(a, 1);
+    pb = __shfl_up(b, 1);
+    if (W > 1) {
+        const int buf = B.phase++ & 1;
+        if (B.lane == 63) {
+            B.xch[buf][B.wave][0] = a;
+            B.xch[buf][B.wave][1] = b;
+        }
+        __syncthreads();
+        if (B.lane == 0 && B.wave > 0) {
+            pa = B.xch[buf][B.wave - 1][0];
+            pb = B.xch[buf][B.wave - 1][1];
+        }
+    }
+    if (B.tid == 0) {
+        pa = a0;
+        pb = b0;
+    }
+}
+
+// sums of N <= 8 per-thread values over the workgroup, result in every thread
+template <int W, int N>
+SAS_DEV void blk_sum(Blk<W> &B, double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+    if (W > 1) {
+        const int buf = B.phase++ & 1;
+        if (B.lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) B.red[buf][B.wave][i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = B.red[buf][0][i];
+            for (int w = 1; w < W; ++w) s = s + B.red[buf][w][i];
+            v[i] = s;
+        }
+    }
+}
+template <int W>
+SAS_DEV double blk_max(Blk<W> &B, double v) {
+    v = wave_max(v);
+    if (W > 1) {
+        const int buf = B.phase++ & 1;
+        if (B.lane == 0) B.red[buf][B.wave][0] = v;
+        __syncthreads();
+        v = B.red[buf][0][0];
+        for (int w = 1; w < W; ++w) v = fmax(v, B.red[buf][w][0]);
+    }
+    return v;
+}
+
+// Cumulative sum over the age axis (calc_SA :343-359, the cumsums of calc_tt :456-468).
+//   hi[j] = cumulative value at the upper edge of the thread's j-th age class
+//   lo    = cumulative value at the lower edge of its first class
+//   *pmax = max over all edges including the leading 0 (`npx.max(SA, axis=-1)`), if asked for
+// Construction: loc = running sum inside the thread, wexc = exclusive wave scan of the thread totals,
+// pw = running sum of the totals of the preceding waves; hi[j] = pw + (wexc + loc[j]), lo = pw + wexc.
+// fl(x + .) is monotone, so hi is non-decreasing in j for non-negative input, hi[j] == hi[j-1] (or lo)
+// exactly where the input is 0, and the maximum over a wave is pw + max(wexc + loc).
+template <int W, int E>
+SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double &lo, double *pmax) {
+    double loc[E];
+    loc[0] = v[0];
+#pragma unroll
+    for (int j = 1; j < E; ++j) loc[j] = loc[j - 1] + v[j];
+    double winc = loc[E - 1];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(winc, d);
+        if (B.lane >= d) winc = t + winc;
+    }
+    double wexc = __shfl_up(winc, 1);
+    if (B.lane == 0) wexc = 0.0;
+    double u[E];
+    double umax = wexc;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        u[j] = wexc + loc[j];
+        umax = fmax(umax, u[j]);
+    }
+    if (W == 1) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) hi[j] = u[j];
+        lo = wexc;
+        if (pmax) *pmax = fmax(0.0, wave_max(umax));
+        return;
+    }
+    if (pmax) umax = wave_max(umax);
+    const int buf = B.phase++ & 1;
+    if (B.lane == 63) {
+        B.red[buf][B.wave][0] = winc;
+        B.red[buf][B.wave][1] = umax;
+    }
+    __syncthreads();
+    double pw = 0.0, mine = 0.0, S = 0.0;
+    for (int w = 0; w < W; ++w) {
+        if (w == B.wave) mine = pw;
+        if (pmax) S = fmax(S, pw + B.red[buf][w][1]);
+        pw = pw + B.red[buf][w][0];
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) hi[j] = mine + u[j];
+    lo = mine + wexc;
+    if (pmax) *pmax = S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-column physics
+// ---------------------------------------------------------------------------------------------
+// conc_to_delta :328-340
+SAS_DEV double conc_to_delta(const SasArgs &P, double conc) {
+    const double d = 1000. * (conc / (P.vsmow * (1. - conc)) - 1.);
+    return ((d < P.dmin) || (d > P.dmax)) ? NAN : d;
+}
+
+template <int E>
+struct Dist {  // what the age statistics need of one flux
+    double tt[E], TT_hi[E], TT_lo;
+};
+
+// Backward travel time distribution of one outgoing flux, calc_tt :362-509, with the SAS families
+// `uniform` (code 1, core/sas.py:5-40) and `power` (codes 6, 61, 62, core/sas.py:191-240).
+// The reference adds the masked results of all six families; for these codes the other four
+// contribute exact zeros.
+template <int W, int E>
+SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
+                     double (&tt)[E]) {
+    const int A = P.ages;
+    const double h = 1 / (double)P.substeps;
+    const double fh = flux * h;
+    if (!(fh > 0)) {
+        // :440-443: tti = where(flux * h > 0, ., 0) in every sub-step -> TT = 0 -> tt = 0 (:496-499);
+        // the SAS evaluation cannot change that, skip it
+#pragma unroll
+        for (int j = 0; j < E; ++j) tt[j] = 0.0;
+        return;
+    }
+    const double code = p[0];
+    const bool uniform = (code == 1), power = (code == 6 || code == 61 || code == 62);
+    if (!uniform && !power && B.tid == 0) *P.unsupported = 1;
+    double san[E], TTn_hi[E], TTn_lo = 0.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        san[j] = sa[j];
+        TTn_hi[j] = 0.0;
+    }
+    for (int it = 0; it < P.substeps; ++it) {
+        double SA_hi[E], SA_lo, Smax;
+        blk_cumsum<W, E>(B, san, SA_hi, SA_lo, &Smax);
+        if (it == 0) {  // the first sub-step sees SA = calc_SA(sa) * maskCatch, the later ones cumsum(san) (:456-459)
+#pragma unroll
+            for (int j = 0; j < E; ++j) SA_hi[j] *= mk;
+            Smax *= mk;
+        }
+        double Om[E];
+        if (uniform) {
+            const double S = Smax * 1.0 * mk;
+            const double lam = 1 / S * 1.0 * mk;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                double o = (SA_hi[j] < S ? (SA_hi[j] > 0 ? lam * SA_hi[j] : 0.) : 1.) * 1.0 * mk;
+                if (base + j == A - 1) o = 1 * mk;  // Omega[..., -1] = 1, sas.py:30-33
+                Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
+        } else if (power) {
+            const double S = Smax * mk;
+            double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
+            S_rel = (S_rel < 0 ? 0 : S_rel);
+            S_rel = (S_rel > 1 ? 1 : S_rel);
+            double k = p[1];
+            if (code == 61) k = p[3] + ((1 - S_rel) * p[4]);
+            if (code == 62) k = p[3] + (S_rel * p[4]);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double x = SA_hi[j];
+                const double o = (x > 0 ? (x <= S ? pow(x / S, k) : 1.) : 0.) * 1.0 * mk;
+                Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) Om[j] = 0.0;
+        }
+        double Om_lo, unused;
+        blk_prev2<W>(B, Om[E - 1], 0.0, 0.0, 0.0, Om_lo, unused);  // Omega(SA[0] = 0) = 0 for both families
+        double tti[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double d = Om[j] - (j == 0 ? Om_lo : Om[j - 1]);
+            double t = (d >= 0 ? d : 0);                                       // :430-433
+            const double q = (flux * t * h > san[j] ? san[j] : flux * t * h);   // :435-438
+            t = q / fh;                                                         // :440-443 (fh > 0 here)
+            san[j] = san[j] + -t * flux * h;                                    // :445-448
+            tti[j] = t;
+        }
+        double c_hi[E], c_lo;
+        blk_cumsum<W, E>(B, tti, c_hi, c_lo, nullptr);
+#pragma unroll
+        for (int j = 0; j < E; ++j) TTn_hi[j] += c_hi[j];  // :465-468
+        TTn_lo += c_lo;
+    }
+    const double N = (double)P.substeps;
+    const double TT_lo = TTn_lo / N;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const double t = TTn_hi[j] / N - (j == 0 ? TT_lo : TTn_hi[j - 1] / N);  // :482-490
+        const double q = (flux * t > sa[j] ? sa[j] : flux * t);                   // :493-496
+        tt[j] = (flux > 0 ? q / flux : 0);                                        // :497-499
+    }
+}
+
+// One outgoing flux: SA, tt, TT, mtt, C, C_iso, the sink's isotope mixing, update_sa.
+// calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
+// calc_percolation_rz/ss_transport_iso_kernel (core/subsurface_runoff.py:1531-1626, 1753-1820),
+// calc_capillary_rise_rz_transport_iso_kernel (core/capillary_rise.py:404-500).
+template <int W, int E, bool SINK, bool KEEP>
+SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&sa)[E], double (&msa)[E], double (&sa_sink)[E],
+                     double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
+    const int A = P.ages;
+    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
+    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
+    double tt[E];
+    calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
+    double mtt[E], s[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        tt[j] *= mk;
+        mtt[j] = (tt[j] > 0 ? msa[j] : 0) * mk;  // calc_mtt :565-596 with alpha = 1
+        s[0] += mtt[j] * tt[j];
+        s[1] += tt[j];
+    }
+    if (P.diag || (KEEP && P.stats)) {  // TT[1:] = cumsum(tt)
+        double TT_hi[E], TT_lo;
+        blk_cumsum<W, E>(B, tt, TT_hi, TT_lo, nullptr);
+        if (KEEP) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                keep.tt[j] = tt[j];
+                keep.TT_hi[j] = TT_hi[j];
+            }
+            keep.TT_lo = TT_lo;
+        }
+        if (P.diag) {
+            double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
+            double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
+            double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
+            if (B.tid == 0) o_TT[0] = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (base + j < A) {
+                    o_tt[base + j] = tt[j];
+                    o_mtt[base + j] = mtt[j];
+                    o_TT[base + j + 1] = TT_hi[j];
+                }
+        }
+    }
+    blk_sum<W, 2>(B, s);
+    if (B.tid == 0) {  // calc_conc_iso_flux :512-535
+        double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
+        conc = (conc != 0 ? conc : NAN);
+        const double C = conc * mk;
+        ((double *)P.a[SA_C_evap_soil + f])[cell] = C;
+        ((double *)P.a[SA_C_iso_evap_soil + f])[cell] = conc_to_delta(P, C) * mk;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (SINK) {
+            const double add = tt[j] * flux;
+            msa_sink[j] = (add + sa_sink[j] > 0
+                               ? msa_sink[j] * (sa_sink[j] / (add + sa_sink[j])) + mtt[j] * (add / (add + sa_sink[j]))
+                               : msa_sink[j]) * mk;
+        }
+        double v = sa[j] + -flux * tt[j];  // update_sa :599-619
+        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
+        sa[j] = v * mk;
+        if (SINK) sa_sink[j] += tt[j] * flux * mk;
+        msa[j] = (sa[j] <= 0 ? 0 : msa[j]) * mk;
+    }
+}
+
+// Infiltration into age class 0: calc_infiltration_rz_transport_iso_kernel (core/infiltration.py:2218-2346)
+// and calc_infiltration_ss_transport_iso_kernel (:2441-2512).  which: 0 matrix -> rz, 1 pf -> rz, 2 pf -> ss.
+template <int W, int E>
+SAS_DEV void inflow(Blk<W> &B, const SasArgs &P, int64_t cell, int which, double (&sa)[E], double (&msa)[E], double mk, int base) {
+    const double inf = ((const double *)P.a[SA_inf_mat_rz + which])[P.day_off + cell];
+    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
+    if (B.tid == 0) {
+        const double C = (inf > 0 ? C_in : 0) * mk;
+        ((double *)P.a[SA_C_inf_mat_rz + which])[cell] = C;
+        ((double *)P.a[SA_C_iso_inf_mat_rz + which])[cell] = conc_to_delta(P, C) * mk;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool first = (base + j == 0);
+        const double ttk = first ? (inf > 0 ? 1 : 0) * mk : 0.0;
+        const double mttk = first ? (inf > 0 ? C_in : 0) * mk : 0.0;
+        msa[j] = (inf * ttk + sa[j] > 0 ? msa[j] * (sa[j] / (ttk * inf + sa[j])) + mttk * ((ttk * inf) / (inf * ttk + sa[j]))
+                                       : msa[j]) * mk;
+        if (first) sa[j] += inf * mk;
+    }
+}
+
+// calc_age_percentile :9-56 for the five percentiles at once + the mean age.
+//   cdf_hi / cdf_lo: cumulative distribution at the upper edges of the thread's classes / lower edge of its first
+//   dens: the distribution itself.  dst: arrays of the 6 statistics; skip10_90: leave rt10 / rt90 unassigned.
+template <int W, int E>
+SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&cdf_hi)[E], double cdf_lo,
+                       const double (&dens)[E], int first_arr, bool skip10_90) {
+    const int A = P.ages;
+    const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    double mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+        if (base + j < A) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) v[q] += (cdf_hi[j] <= Q[q]) ? 1.0 : 0.0;
+            v[5] += dens[j];
+            v[6] += (double)(base + j + 1) * dens[j];
+            mx = fmax(mx, cdf_hi[j]);
+        }
+    blk_sum<W, 7>(B, v);
+    mx = blk_max<W>(B, mx);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        if (skip10_90 && (q == 0 || q == 4)) continue;
+        double *dst = (double *)P.a[first_arr + q] + cell;
+        const int cnt = (int)v[q];  // number of classes with cdf <= q; the crossing is in class `cnt`
+        if (!(mx > 0)) {
+            if (B.tid == 0) *dst = NAN;
+        } else if (cnt <= 0) {
+            if (B.tid == 0) *dst = 1.0;
+        } else if (cnt >= A) {
+            if (B.tid == 0) *dst = (double)A;
+        } else if (cnt >= base && cnt < base + E) {
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (base + j == cnt) {
+                    const double x1 = cdf_hi[j], x0 = (j == 0 ? cdf_lo : cdf_hi[j > 0 ? j - 1 : 0]);
+                    const double y0 = (double)cnt, y1 = (double)(cnt + 1);  // ages are 1-based
+                    const double slope = (y1 - y0) / (x1 - x0);
+                    *dst = (x1 == x0) ? y0 : slope * (Q[q] - x0) + y0;
+                }
+        }
+    }
+    if (B.tid == 0) ((double *)P.a[first_arr + 5])[cell] = (v[5] > 0 ? v[6] : NAN);
+}
+
+template <int W, int E>
+SAS_DEV void residence_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&sa)[E], double mk, int first_arr,
+                             bool skip10_90) {
+    // RT = SA / max(SA), rt = diff(RT): calculate_age_statistics_root_zone/subsoil/soil :155-312
+    double SA_hi[E], SA_lo, mx;
+    blk_cumsum<W, E>(B, sa, SA_hi, SA_lo, &mx);
+    mx *= mk;
+    double RT_hi[E], rt[E];
+    const double RT_lo = (mx > 0 ? (SA_lo * mk) / mx : 0);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        RT_hi[j] = (mx > 0 ? (SA_hi[j] * mk) / mx : 0);
+        rt[j] = RT_hi[j] - (j == 0 ? RT_lo : RT_hi[j > 0 ? j - 1 : 0]);
+    }
+    age_stats<W, E>(B, P, cell, base, RT_hi, RT_lo, rt, first_arr, skip10_90);
+}
+
+// Ageing by one day: calc_ageing_sa_msa_iso_kernel :780-805 -> calc_ageing_msa_iso :682-739.
+template <int W, int E>
+SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E]) {
+    double p_sa, p_msa;
+    blk_prev2<W>(B, sa[E - 1], msa[E - 1], 0.0, 0.0, p_sa, p_msa);
+    double n_sa[E], n_msa[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = base + j;
+        n_sa[j] = (j == 0 ? p_sa : sa[j > 0 ? j - 1 : 0]);
+        n_msa[j] = (j == 0 ? p_msa : msa[j > 0 ? j - 1 : 0]);
+        if (k == 0) {
+            n_sa[j] = 0;
+            n_msa[j] = 0;
+        }
+        if (k == A - 1) {  // merge the oldest water
+            const double sam1 = sa[j], msam1 = msa[j];
+            const double tot = n_sa[j] + sam1;
+            const double v = (tot > 0 ? msam1 * (sam1 / tot) + n_msa[j] * (n_sa[j] / tot) : 0);
+            n_msa[j] = (v != v) ? 0 : v;
+            n_sa[j] += sam1;
+            n_sa[j] = (n_sa[j] < 1e-8 ? 0 : n_sa[j]);
+            n_msa[j] = (n_sa[j] <= 0 ? NAN : n_msa[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        sa[j] = n_sa[j];
+        msa[j] = n_msa[j];
+    }
+}
+
+// tt / TT of one flux back from the diagnostics arrays (age statistics in a launch of their own)
+template <int E>
+SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> &D) {
+    const int A = P.ages;
+    const double *g_tt = (const double *)P.a[SA_tt_evap_soil + f] + cell * A;
+    const double *g_TT = (const double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool in = base + j < A;
+        D.tt[j] = in ? g_tt[base + j] : 0.0;
+        D.TT_hi[j] = g_TT[in ? base + j + 1 : A];
+    }
+    D.TT_lo = g_TT[base < A ? base : A];
+}
+
+template <int W, int E>
+__global__ __launch_bounds__(W * 64) void k_sas(const SasArgs P) {
+    __shared__ double s_red[2][W][8];
+    __shared__ double s_xch[2][W][2];
+    Blk<W> B;
+    B.tid = threadIdx.x;
+    B.lane = threadIdx.x & 63;
+    B.wave = threadIdx.x >> 6;
+    B.phase = 0;
+    B.red = s_red;
+    B.xch = s_xch;
+    const int64_t cell = blockIdx.x;
+    const int A = P.ages;
+    const int base = B.tid * E;
+    const double mk = (double)((const int *)P.a[SA_maskCatch])[cell];
+
+    double sa_rz[E], msa_rz[E], sa_ss[E], msa_ss[E];
+    {
+        const double *g0 = (const double *)P.a[SA_sa_rz] + cell * A, *g1 = (const double *)P.a[SA_msa_rz] + cell * A;
+        const double *g2 = (const double *)P.a[SA_sa_ss] + cell * A, *g3 = (const double *)P.a[SA_msa_ss] + cell * A;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool in = base + j < A;
+            sa_rz[j] = in ? g0[base + j] : 0.0;
+            msa_rz[j] = in ? g1[base + j] : 0.0;
+            sa_ss[j] = in ? g2[base + j] : 0.0;
+            msa_ss[j] = in ? g3[base + j] : 0.0;
+        }
+    }
+    Dist<E> d_transp, d_q_ss;
+    bool have_transp = false, have_q_ss = false;
+    const bool stats = P.stats && (P.stages & RH_SAS_STORAGE);
+
+    // order of svat_transport_model_deterministic :949-991
+    if (P.stages & RH_SAS_INF_RZ) {
+        inflow<W, E>(B, P, cell, 0, sa_rz, msa_rz, mk, base);
+        inflow<W, E>(B, P, cell, 1, sa_rz, msa_rz, mk, base);
+    }
+    if (P.stages & RH_SAS_EVAP) outflux<W, E, false, false>(B, P, cell, 0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+    if (P.stages & RH_SAS_TRANSP) {
+        outflux<W, E, false, true>(B, P, cell, 1, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+        have_transp = true;
+    }
+    if (P.stages & RH_SAS_Q_RZ) outflux<W, E, true, false>(B, P, cell, 2, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
+    if (P.stages & RH_SAS_INF_SS) inflow<W, E>(B, P, cell, 2, sa_ss, msa_ss, mk, base);
+    if (P.stages & RH_SAS_Q_SS) {
+        outflux<W, E, false, true>(B, P, cell, 3, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
+        have_q_ss = true;
+    }
+    if (P.stages & RH_SAS_CPR) outflux<W, E, true, false>(B, P, cell, 4, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
+
+    if (P.stages & RH_SAS_STORAGE) {
+        // calc_root_zone_transport_iso_kernel (core/root_zone.py:189-217), calc_subsoil_transport_iso_kernel
+        // (core/subsoil.py:159-188), calculate_soil_transport_iso_kernel (core/soil.py:1036-1090)
+        double sa_s[E], msa_s[E];
+        double s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            sa_rz[j] = (sa_rz[j] < 1e-8 ? 0 : sa_rz[j]);
+            sa_ss[j] = (sa_ss[j] < 1e-8 ? 0 : sa_ss[j]);
+            sa_s[j] = sa_rz[j] + sa_ss[j] * mk;
+            const double tot = sa_rz[j] + sa_ss[j];
+            const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
+            msa_s[j] = (v != v) ? 0 : v;
+            s[0] += msa_rz[j] * sa_rz[j];
+            s[1] += sa_rz[j];
+            s[2] += msa_ss[j] * sa_ss[j];
+            s[3] += sa_ss[j];
+            s[4] += msa_s[j] * sa_s[j];
+            s[5] += sa_s[j];
+        }
+        blk_sum<W, 6>(B, s);
+        if (B.tid == 0) {  // calc_conc_iso_storage :538-562
+            for (int k = 0; k < 3; ++k) {
+                const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0) * mk;
+                ((double *)P.a[SA_C_rz + k])[cell] = C;
+                ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+            }
+        }
+        if (P.diag) {
+            double *o0 = (double *)P.a[SA_sa_s] + cell * A, *o1 = (double *)P.a[SA_msa_s] + cell * A;
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (base + j < A) {
+                    o0[base + j] = sa_s[j];
+                    o1[base + j] = msa_s[j];
+                }
+        }
+        if (stats) {  // calculate_age_statistics_* :59-312
+            // stages run one launch at a time: the distributions come back from the diagnostics arrays
+            if (!have_transp) load_dist<E>(P, cell, base, 1, d_transp);
+            if (!have_q_ss) load_dist<E>(P, cell, base, 3, d_q_ss);
+            age_stats<W, E>(B, P, cell, base, d_transp.TT_hi, d_transp.TT_lo, d_transp.tt, SA_tt10_transp, false);
+            age_stats<W, E>(B, P, cell, base, d_q_ss.TT_hi, d_q_ss.TT_lo, d_q_ss.tt, SA_tt10_q_ss, false);
+            // the reference never assigns rt10 / rt90 of root zone and subsoil (:181-196, :232-247)
+            residence_stats<W, E>(B, P, cell, base, sa_rz, mk, SA_rt10_rz, true);
+            residence_stats<W, E>(B, P, cell, base, sa_ss, mk, SA_rt10_ss, true);
+            residence_stats<W, E>(B, P, cell, base, sa_s, mk, SA_rt10_s, false);
+        }
+    }
+
+    if (P.stages & RH_SAS_AGEING) {
+        ageing<W, E>(B, A, base, sa_rz, msa_rz);
+        ageing<W, E>(B, A, base, sa_ss, msa_ss);
+    }
+
+    {
+        double *g0 = (double *)P.a[SA_sa_rz] + cell * A, *g1 = (double *)P.a[SA_msa_rz] + cell * A;
+        double *g2 = (double *)P.a[SA_sa_ss] + cell * A, *g3 = (double *)P.a[SA_msa_ss] + cell * A;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (base + j < A) {
+                g0[base + j] = sa_rz[j];
+                g1[base + j] = msa_rz[j];
+                g2[base + j] = sa_ss[j];
+                g3[base + j] = msa_ss[j];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: context and C ABI
+// ---------------------------------------------------------------------------------------------
+struct rh_sas_ctx {
+    rh_sas_config cfg;
+    hipStream_t stream;
+    bool own_stream;
+    void *arr[SA_COUNT];
+    int64_t elems[SA_COUNT];
+    int *unsupported;
+    bool timing;
+    std::vector<hipEvent_t> events;
+    size_t ev_used;
+    std::string err;
+};
+static std::string g_sas_create_err;
+
+static int sfail(rh_sas_ctx *ctx, int code, const std::string &msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_sas_create_err = msg;
+    return code;
+}
+#define SHIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) return sfail(ctx, RH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int64_t sas_elems(const rh_sas_config &c, int a) {
+    const int when = SAS_WHEN[a];
+    if (when == W_STATS && !c.age_statistics) return 0;
+    if (when == W_DIAG && !c.keep_distributions) return 0;
+    switch (SAS_KIND[a]) {
+    case K_AGE: return c.n_cells * c.ages;
+    case K_NAGE: return c.n_cells * (c.ages + 1);
+    case K_CELL: return c.n_cells;
+    case K_DAILY: return c.n_cells * c.forcing_days;
+    case K_PARAM: return c.n_cells * 8;
+    case K_MASK: return c.n_cells;
+    }
+    return 0;
+}
+
+template <int W, int E>
+static void launch_sas(rh_sas_ctx *ctx, const SasArgs &args) {
+    hipLaunchKernelGGL((k_sas<W, E>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
+}
+
+extern "C" {
+
+void rh_sas_default_config(rh_sas_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->n_cells = 1;
+    cfg->ages = 1000;         // benchmarks/SVATOXYGEN18_benchmark.py:28-44
+    cfg->substeps = 1;        // settings.sas_solver_substeps default, roger/settings.py:120
+    cfg->forcing_days = 1;
+    cfg->vsmow = 2005.2e-6;   // roger/settings.py:76-78
+    cfg->d18O_min = -20;
+    cfg->d18O_max = 0;
+}
+
+const char *rh_sas_last_error(const rh_sas_ctx *ctx) { return ctx ? ctx->err.c_str() : g_sas_create_err.c_str(); }
+int rh_sas_num_arrays(void) { return SA_COUNT; }
+const char *rh_sas_array_name(int a) { return (a >= 0 && a < SA_COUNT) ? SAS_NAMES[a] : nullptr; }
+int rh_sas_array_is_int(int a) { return (a >= 0 && a < SA_COUNT) ? (SAS_KIND[a] == K_MASK) : -1; }
+int rh_sas_array_index(const char *name) {
+    if (!name) return -1;
+    for (int a = 0; a < SA_COUNT; ++a)
+        if (std::strcmp(SAS_NAMES[a], name) == 0) return a;
+    return -1;
+}
+int64_t rh_sas_array_elems(const rh_sas_ctx *ctx, int a) { return (ctx && a >= 0 && a < SA_COUNT) ? ctx->elems[a] : 0; }
+
+int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
+    if (!cfg || !out) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: null argument");
+    if (cfg->n_cells <= 0 || cfg->n_cells > 0x7fffffffLL) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: n_cells out of range");
+    if (cfg->ages < 2 || cfg->ages + 1 > RH_SAS_MAX_NAGES)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: ages must be in [2, RH_SAS_MAX_NAGES - 1]");
+    if (cfg->substeps < 1 || cfg->forcing_days < 1) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: substeps and forcing_days must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: device ordinal out of range");
+    SHIPCHK(nullptr, hipSetDevice(cfg->device));
+    rh_sas_ctx *ctx = new (std::nothrow) rh_sas_ctx();
+    if (!ctx) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: out of host memory");
+    ctx->cfg = *cfg;
+    ctx->stream = nullptr;
+    ctx->own_stream = false;
+    ctx->unsupported = nullptr;
+    ctx->timing = false;
+    ctx->ev_used = 0;
+    for (int a = 0; a < SA_COUNT; ++a) {
+        ctx->arr[a] = nullptr;
+        ctx->elems[a] = 0;
+    }
+    auto bail = [&](hipError_t e, const char *what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        rh_sas_destroy(ctx);
+        return sfail(nullptr, RH_ERR_HIP, msg);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
+    ctx->own_stream = true;
+    for (int a = 0; a < SA_COUNT; ++a) {
+        const int64_t ne = sas_elems(*cfg, a);
+        if (!ne) continue;
+        const size_t bytes = (size_t)ne * (SAS_KIND[a] == K_MASK ? sizeof(int32_t) : sizeof(double));
+        if ((e = hipMalloc(&ctx->arr[a], bytes)) != hipSuccess) return bail(e, "hipMalloc(SAS array)");
+        if ((e = hipMemsetAsync(ctx->arr[a], 0, bytes, ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+        ctx->elems[a] = ne;
+    }
+    if ((e = hipMalloc((void **)&ctx->unsupported, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemsetAsync(ctx->unsupported, 0, sizeof(int), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    {   // maskCatch defaults to 1 (roger/variables.py)
+        std::vector<int32_t> ones((size_t)cfg->n_cells, 1);
+        if ((e = hipMemcpyAsync(ctx->arr[SA_maskCatch], ones.data(), ones.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return bail(e, "hipMemcpy(maskCatch)");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    }
+    *out = ctx;
+    return RH_OK;
+}
+
+void rh_sas_destroy(rh_sas_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) (void)hipEventDestroy(ev);
+    for (int a = 0; a < SA_COUNT; ++a)
+        if (ctx->arr[a]) (void)hipFree(ctx->arr[a]);
+    if (ctx->unsupported) (void)hipFree(ctx->unsupported);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rh_sas_set_stream(rh_sas_ctx *ctx, void *hip_stream) {
+    if (!ctx) return RH_ERR_ARG;
+    SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) SHIPCHK(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return RH_OK;
+}
+
+int rh_sas_sync(rh_sas_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    int bad = 0;
+    SHIPCHK(ctx, hipMemcpyAsync(&bad, ctx->unsupported, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad)
+        return sfail(ctx, RH_ERR_STATE,
+                     "a column selects a SAS family other than uniform (1) or power (6, 61, 62): not implemented by the hip backend");
+    return RH_OK;
+}
+
+static int sas_check(rh_sas_ctx *ctx, int a, size_t bytes, const void *host, const char *who) {
+    if (!ctx) return RH_ERR_ARG;
+    if (a < 0 || a >= SA_COUNT) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": unknown array id");
+    if (!ctx->arr[a]) return sfail(ctx, RH_ERR_STATE, std::string(who) + ": array " + SAS_NAMES[a] + " is not held by this context (age_statistics / keep_distributions)");
+    const size_t want = (size_t)ctx->elems[a] * (SAS_KIND[a] == K_MASK ? sizeof(int32_t) : sizeof(double));
+    if (bytes != want) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": size mismatch for array " + SAS_NAMES[a]);
+    if (!host) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": null host pointer");
+    return RH_OK;
+}
+
+int rh_sas_upload(rh_sas_ctx *ctx, int a, const void *host, size_t bytes) {
+    const int rc = sas_check(ctx, a, bytes, host, "rh_sas_upload");
+    if (rc) return rc;
+    SHIPCHK(ctx, hipMemcpyAsync(ctx->arr[a], host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+
+int rh_sas_download(rh_sas_ctx *ctx, int a, void *host, size_t bytes) {
+    const int rc = sas_check(ctx, a, bytes, host, "rh_sas_download");
+    if (rc) return rc;
+    SHIPCHK(ctx, hipMemcpyAsync(host, ctx->arr[a], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return rh_sas_sync(ctx);
+}
+
+void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int a) { return (ctx && a >= 0 && a < SA_COUNT) ? ctx->arr[a] : nullptr; }
+
+int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
+    if (!ctx) return RH_ERR_ARG;
+    if (day < 0) return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: negative day");
+    if ((stages & ~RH_SAS_ALL) || !stages) return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: bad stage mask");
+    const rh_sas_config &c = ctx->cfg;
+    if ((stages & RH_SAS_STORAGE) && c.age_statistics && !c.keep_distributions &&
+        (!(stages & RH_SAS_TRANSP) || !(stages & RH_SAS_Q_SS)))
+        return sfail(ctx, RH_ERR_STATE,
+                     "rh_sas_stages: age statistics need the transpiration and percolation stages in the same launch, or keep_distributions");
+    SasArgs args;
+    args.n = c.n_cells;
+    args.day_off = (day % c.forcing_days) * c.n_cells;
+    args.ages = c.ages;
+    args.substeps = c.substeps;
+    args.stages = stages;
+    args.stats = c.age_statistics ? 1 : 0;
+    args.diag = c.keep_distributions ? 1 : 0;
+    args.vsmow = c.vsmow;
+    args.dmin = c.d18O_min;
+    args.dmax = c.d18O_max;
+    args.unsupported = ctx->unsupported;
+    for (int a = 0; a < SA_COUNT; ++a) args.a[a] = ctx->arr[a];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->timing) {
+        if (ctx->ev_used + 2 > ctx->events.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t ev;
+                SHIPCHK(ctx, hipEventCreate(&ev));
+                ctx->events.push_back(ev);
+            }
+        }
+        ev0 = ctx->events[ctx->ev_used];
+        ev1 = ctx->events[ctx->ev_used + 1];
+        ctx->ev_used += 2;
+        SHIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+    }
+    // smallest workgroup whose blocked layout covers the ages + 1 edges: waves x classes per thread
+    const int nages = c.ages + 1;
+    if (nages <= 64) launch_sas<1, 1>(ctx, args);
+    else if (nages <= 128) launch_sas<1, 2>(ctx, args);
+    else if (nages <= 256) launch_sas<1, 4>(ctx, args);
+    else if (nages <= 512) launch_sas<2, 4>(ctx, args);
+    else if (nages <= 1024) launch_sas<4, 4>(ctx, args);
+    else if (nages <= 2048) launch_sas<8, 4>(ctx, args);
+    else launch_sas<16, 4>(ctx, args);
+    SHIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
+    return RH_OK;
+}
+
+int rh_sas_step(rh_sas_ctx *ctx, int64_t day) { return rh_sas_stages(ctx, day, RH_SAS_ALL); }
+
+int rh_sas_run_days(rh_sas_ctx *ctx, int64_t day0, int64_t ndays) {
+    if (!ctx) return RH_ERR_ARG;
+    if (ndays < 0) return sfail(ctx, RH_ERR_ARG, "rh_sas_run_days: negative ndays");
+    for (int64_t d = 0; d < ndays; ++d) {
+        const int rc = rh_sas_stages(ctx, day0 + d, RH_SAS_ALL);
+        if (rc) return rc;
+    }
+    return RH_OK;
+}
+
+int rh_sas_enable_timing(rh_sas_ctx *ctx, int on) {
+    if (!ctx) return RH_ERR_ARG;
+    ctx->timing = on != 0;
+    ctx->ev_used = 0;
+    return RH_OK;
+}
+
+int rh_sas_timing_summary(rh_sas_ctx *ctx, double *total_ms, int64_t *launches) {
+    if (!ctx || !total_ms || !launches) return RH_ERR_ARG;
+    SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+        float ms = 0;
+        SHIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)(ctx->ev_used / 2);
+    return RH_OK;
+}
+
+}  // extern "C"

@@ -9,8 +9,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    txt = open(os.path.join(REPO, "include", "roger_hip.h")).read()
+def _declared_functions(header="roger_hip.h"):
+    txt = open(os.path.join(REPO, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(rh_\w+)\s*\(", txt)))
 
@@ -27,6 +27,28 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the binding declares the same set
     assert sorted(_native.DECLARED_SYMBOLS) == declared
+    # include/roger_hip_sas.h
+    declared_sas = _declared_functions("roger_hip_sas.h")
+    assert len(declared_sas) >= 19
+    missing = [f for f in declared_sas if not hasattr(lib, f)]
+    assert not missing, missing
+    assert sorted(_native.SAS_DECLARED_SYMBOLS) == declared_sas
+
+
+def test_sas_array_registry_matches_def():
+    from roger_amd import _native
+
+    txt = open(os.path.join(REPO, "include", "rh_sas_arrays.def")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    arrays = re.findall(r"RH_SAS_ARRAY\((\w+),\s*(\w+),\s*(\w+)\)", txt)
+    lib = _native.load()
+    assert lib.rh_sas_num_arrays() == len(arrays)
+    for i, (name, kind, _when) in enumerate(arrays):
+        assert lib.rh_sas_array_name(i).decode() == name
+        assert lib.rh_sas_array_index(name.encode()) == i
+        assert bool(lib.rh_sas_array_is_int(i)) == (kind == "MASK")
+    assert lib.rh_sas_array_index(b"no_such_array") == -1
+    assert set(_native.DAILY_INPUTS) == {n for n, k, _ in arrays if k == "DAILY"}
 
 
 def test_plane_registry_matches_fields_def():
@@ -69,3 +91,5 @@ def test_no_gpu_means_loud_failure():
 
     with pytest.raises(_native.NativeError, match="no CPU fallback"):
         _native.Context(2, 2)
+    with pytest.raises(_native.NativeError, match="no CPU fallback"):
+        _native.SasContext(4, 40)
