@@ -67,6 +67,120 @@ def cpu_baseline(n_cells, steps, forcing):
     return n_cells * steps / dt, dt
 
 
+SAS_S_RZ, SAS_S_SS = 90.0, 260.0   # initial root zone / subsoil storage in mm (uniform benchmark soil)
+
+
+def cpu_baseline_sas(n_cells, ndays, ages, substeps, daily):
+    """Oracle (oracle/sas_oracle.c) on the host: first n_cells columns, first ndays days of the same inputs."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import sas_binding as sb
+    from roger_amd import sas as rsas
+
+    st = sb.SasState(n_cells, ages, substeps, age_statistics=True)
+    for key, S in (("rz", SAS_S_RZ), ("ss", SAS_S_SS)):
+        sa, msa = rsas.initial_age_state([S] * n_cells, ages)
+        st.state[f"sa_{key}"][:] = sa
+        st.state[f"msa_{key}"][:] = msa
+    for f, p in rsas.benchmark_sas_params(n_cells).items():
+        st.sas[f][:] = p
+    t0 = time.perf_counter()
+    for d in range(ndays):
+        for k in st.inp:
+            st.inp[k][:] = daily[k][d, :n_cells]
+        st.step_oracle()
+    dt = time.perf_counter() - t0
+    return n_cells * ndays / dt, dt
+
+
+def bench_sas(args, torch, dist, rank, local_rank, world, device):
+    """BASELINE configs[2]: SVATOXYGEN18_benchmark, nx*ny columns per GPU, ages = 1000, 6 sub-steps, power-law
+    SAS with the benchmark's exponents, age statistics on.  One step = one day of every column (rh_sas_step)."""
+    from roger_amd import sas as rsas
+
+    nx, ny = args.size
+    n = nx * ny
+    ndays_resident = 8
+    daily = rsas.synthetic_daily_inputs(n, ndays_resident, seed=42 + rank)
+    ctx = rsas.create_sas(n, args.ages, args.substeps, SAS_S_RZ, SAS_S_SS, daily=daily, device=local_rank, age_statistics=True)
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    ctx.run_days(0, args.warmup)
+    ctx.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    ctx.run_days(args.warmup, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.timing_summary()
+    ctx.enable_timing(False)
+    ctx.sync()   # raises if a column asked for an unsupported SAS family
+    d18O = ctx.download("C_iso_q_ss")[:4]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        algo = 8 * args.ages * 8           # read + write of sa_rz, msa_rz, sa_ss, msa_ss (SURVEY 8d: 64 000 B at ages = 1000)
+        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = algo * n / k_avg_s / 1e9
+        pows = 5 * args.substeps * (args.ages + 1)
+        out = {
+            "metric": "cell-timesteps/sec on SVATOXYGEN18_benchmark grid",
+            "value": world * n * args.steps / elapsed,
+            "unit": "cell-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SVATOXYGEN18_benchmark (offline oxygen-18 transport, deterministic SAS solver) nx*ny={n} per GPU, "
+                            f"ages={args.ages}, sas_solver_substeps={args.substeps}, power-law SAS (benchmark exponents), "
+                            "age statistics on, synthetic daily fluxes (seed 42); one step = one day",
+                "cells_per_gpu": n,
+                "decomposition": f"({world},1) along x, no exchange",
+                "d18O_q_ss_sample": [None if x != x else float(x) for x in d18O],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_sas",
+                "note": f"algorithmic bytes = state read + written once per day; the kernel is fp64-ALU bound by "
+                        f"<= {pows} pow per column-day (fluxes that are 0 on a day are skipped), see DESIGN.md",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo * n,
+                "avg_kernel_ms": k_avg_s * 1e3,
+                "launches_timed": launches,
+            },
+        }
+        if not args.no_cpu_baseline:
+            cells = max(8, min(n, int(args.cpu_cells) // 25))
+            days = min(ndays_resident, args.steps + args.warmup, 4)
+            v, secs = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily)
+            out["cpu_baseline"] = {
+                "value": v,
+                "unit": "cell-timesteps/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"oracle/sas_oracle.c, {cells} columns x first {days} days of the same inputs, {secs:.1f} s on one host core",
+            }
+        print(json.dumps(out))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,8 +188,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, nargs=2, default=(1000, 1000), metavar=("NX", "NY"))
     ap.add_argument("--params", choices=("uniform", "hetero"), default="uniform")
-    ap.add_argument("--model", choices=("svat", "oned"), default="svat",
-                    help="svat: SVAT_benchmark (BASELINE configs[1]); oned: oneD_benchmark (lateral subsurface flow)")
+    ap.add_argument("--model", choices=("svat", "oned", "sas"), default="svat",
+                    help="svat: SVAT_benchmark (BASELINE configs[1]); oned: oneD_benchmark (lateral subsurface flow); "
+                         "sas: SVATOXYGEN18_benchmark (configs[2]: offline oxygen-18 transport, one step = one day)")
+    ap.add_argument("--ages", type=int, default=1000, help="sas: age classes (benchmark: 1000)")
+    ap.add_argument("--substeps", type=int, default=6, help="sas: sas_solver_substeps (benchmark: 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=100000)
     args = ap.parse_args()
@@ -94,6 +211,12 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+
+    if args.model == "sas":
+        bench_sas(args, torch, dist, rank, local_rank, world, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from roger_amd.distributed import HipPhases, PhasedStepper
     from roger_amd.forcing import combo_forcing

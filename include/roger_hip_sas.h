@@ -77,6 +77,11 @@ int64_t rh_sas_array_elems(const rh_sas_ctx *ctx, int array); /* elements held b
 int rh_sas_array_is_int(int array);
 int rh_sas_upload(rh_sas_ctx *ctx, int array, const void *host, size_t bytes);
 int rh_sas_download(rh_sas_ctx *ctx, int array, void *host, size_t bytes); /* synchronises */
+/* The same for the rows [first_cell, first_cell + n_cells) of a per-cell array (not for the DAILY inputs):
+ * lets a driver stream a state that is larger than it wants to stage on the host (32 GB at 10^6 columns
+ * x 1000 ages). */
+int rh_sas_upload_cells(rh_sas_ctx *ctx, int array, int64_t first_cell, int64_t n_cells, const void *host, size_t bytes);
+int rh_sas_download_cells(rh_sas_ctx *ctx, int array, int64_t first_cell, int64_t n_cells, void *host, size_t bytes);
 void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int array);
 
 /* ---- the step --------------------------------------------------------------------------------
@@ -104,6 +109,10 @@ int rh_sas_run_days(rh_sas_ctx *ctx, int64_t day0, int64_t ndays);
 /* HIP-event timing of the step kernel (same protocol as rh_enable_timing / rh_timing_summary). */
 int rh_sas_enable_timing(rh_sas_ctx *ctx, int on);
 int rh_sas_timing_summary(rh_sas_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* Diagnostic: the kernel's x**k routine (power-law SAS function, core/sas.py:228-231) on n host values,
+ * 0 < x <= 1; lets the tests bound its error against the host's pow directly.  Uses the current device. */
+int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n);
 
 #ifdef __cplusplus
 }

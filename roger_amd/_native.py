@@ -130,11 +130,14 @@ def _declare_sas(lib):
     lib.rh_sas_array_is_int.argtypes = [i32]
     lib.rh_sas_upload.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rh_sas_download.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.rh_sas_upload_cells.argtypes = [vp, i32, i64, i64, vp, C.c_size_t]
+    lib.rh_sas_download_cells.argtypes = [vp, i32, i64, i64, vp, C.c_size_t]
     lib.rh_sas_array_device_ptr.argtypes = [vp, i32]
     lib.rh_sas_array_device_ptr.restype = vp
     lib.rh_sas_stages.argtypes = [vp, i64, i32]
     lib.rh_sas_step.argtypes = [vp, i64]
     lib.rh_sas_run_days.argtypes = [vp, i64, i64]
+    lib.rh_sas_selftest_pow.argtypes = [vp, vp, vp, i64]
     lib.rh_sas_enable_timing.argtypes = [vp, i32]
     lib.rh_sas_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 
@@ -142,8 +145,8 @@ def _declare_sas(lib):
 SAS_DECLARED_SYMBOLS = (
     "rh_sas_default_config", "rh_sas_create", "rh_sas_destroy", "rh_sas_last_error", "rh_sas_set_stream",
     "rh_sas_sync", "rh_sas_num_arrays", "rh_sas_array_name", "rh_sas_array_index", "rh_sas_array_elems",
-    "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_array_device_ptr", "rh_sas_stages",
-    "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary",
+    "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_upload_cells", "rh_sas_download_cells", "rh_sas_array_device_ptr", "rh_sas_stages",
+    "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary", "rh_sas_selftest_pow",
 )
 
 # stage bits of rh_sas_stages (include/roger_hip_sas.h)
@@ -219,6 +222,20 @@ class SasContext:
                     f"rh_sas_download({name})")
         return a
 
+    def upload_cells(self, name, first_cell, host):
+        """Rows [first_cell, first_cell + len(host)) of a per-cell array."""
+        a = np.ascontiguousarray(host, dtype=self.dtype(name))
+        if a.shape[1:] != self.shape(name)[1:]:
+            raise ValueError(f"{name}: row shape {a.shape[1:]}, expected {self.shape(name)[1:]}")
+        self._check(self._lib.rh_sas_upload_cells(self._h, self.index(name), int(first_cell), a.shape[0],
+                                                  a.ctypes.data_as(C.c_void_p), a.nbytes), f"rh_sas_upload_cells({name})")
+
+    def download_cells(self, name, first_cell, n_cells):
+        a = np.empty((int(n_cells),) + self.shape(name)[1:], dtype=self.dtype(name))
+        self._check(self._lib.rh_sas_download_cells(self._h, self.index(name), int(first_cell), a.shape[0],
+                                                    a.ctypes.data_as(C.c_void_p), a.nbytes), f"rh_sas_download_cells({name})")
+        return a
+
     def device_ptr(self, name):
         return self._lib.rh_sas_array_device_ptr(self._h, self.index(name))
 
@@ -244,6 +261,18 @@ class SasContext:
         ms, cnt = C.c_double(), C.c_int64()
         self._check(self._lib.rh_sas_timing_summary(self._h, C.byref(ms), C.byref(cnt)), "rh_sas_timing_summary")
         return ms.value, cnt.value
+
+
+def sas_selftest_pow(x, k):
+    """x ** k by the SAS kernel's own routine (rh_sas_selftest_pow)."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    k = np.ascontiguousarray(np.broadcast_to(k, x.shape), dtype=np.float64)
+    out = np.empty_like(x)
+    rc = lib.rh_sas_selftest_pow(x.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), x.size)
+    if rc != 0:
+        raise NativeError(f"rh_sas_selftest_pow failed ({rc})")
+    return out
 
 
 DAILY_INPUTS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss", "evap_soil", "transp", "q_rz", "q_ss", "cpr_rz", "C_in")

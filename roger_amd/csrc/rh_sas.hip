@@ -29,6 +29,76 @@
 
 #define SAS_DEV __device__ __forceinline__
 
+// (SA / S) ** k of the power-law SAS function, the hot spot of the kernel: 5 * substeps * (ages + 1)
+// evaluations per column and day.  The device library's general pow() costs ~230 VALU instructions
+// here (measured: 2/3 of the kernel's instruction stream).  The argument range is narrow -- 0 < SA <= S,
+// k finite -- so (SA / S)**k = 2**(k * (log2 SA - log2 S)) is evaluated directly in ~50 instructions,
+// and the division goes away as well (log2 S is computed once per sub-step):
+//   sas_log2:  x = m * 2**e, m in [sqrt(1/2), sqrt(2));  s = (m - 1) / (m + 1);
+//              ln m = s * (2 + z * (2/3 + 2/5 z + ... + 2/19 z**8)), z = s*s <= 0.02944 (next term < 2.4e-17 rel.)
+//   sas_exp2:  y = n + r, |r| <= 1/2;  2**r = exp(r ln 2) by its Taylor series to degree 13 (remainder < 4e-18);
+//              result = ldexp(., n)
+// Error: the rounding of the logarithms dominates, ~|log2 SA| * 2**-53 * k * ln 2 relative, i.e. < 1e-14 * k for
+// SA / S > 1e-21; SA == S gives exactly 1 (Omega(S) = 1).  RH_SAS_POW=0 selects the library pow(SA / S, k).
+#ifndef RH_SAS_POW
+#define RH_SAS_POW 3
+#endif
+// Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
+// operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
+__constant__ double SAS_LOG_C[9] = {2.0 / 19.0, 2.0 / 17.0, 2.0 / 15.0, 2.0 / 13.0, 2.0 / 11.0, 2.0 / 9.0, 2.0 / 7.0, 2.0 / 5.0, 2.0 / 3.0};
+__constant__ double SAS_EXP_C[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                                     1.0 / 40320.0,      1.0 / 5040.0,      1.0 / 720.0,      1.0 / 120.0,     1.0 / 24.0,
+                                     1.0 / 6.0,          0.5};
+struct PowConsts {
+    double lc[9], ec[12];
+};
+SAS_DEV PowConsts load_pow_consts() {
+    PowConsts c;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.lc[i] = SAS_LOG_C[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.ec[i] = SAS_EXP_C[i];
+    return c;
+}
+SAS_DEV double sas_log2(const PowConsts &C, double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0, d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-d, s, f), r, s);
+    const double z = s * s;
+    double p = C.lc[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) p = __builtin_fma(p, z, C.lc[i]);
+    const double lnm = s * __builtin_fma(p, z, 2.0);
+    return __builtin_fma(lnm, 1.44269504088896340736, (double)e);
+}
+// 2**y.  No range clamp is needed: v_cvt_i32_f64 saturates and v_ldexp_f64 under/overflows to 0 / inf.
+SAS_DEV double sas_exp2(const PowConsts &C, double y) {
+    const double n = __builtin_rint(y);
+    const double w = (y - n) * 0.69314718055994530942;
+    double q = C.ec[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) q = __builtin_fma(q, w, C.ec[i]);
+    q = __builtin_fma(q, w, 1.0);
+    q = __builtin_fma(q, w, 1.0);
+    return ldexp(q, (int)n);
+}
+// (x / S) ** k for 0 < x <= S; log2S = sas_log2(S)
+SAS_DEV double sas_pow_ratio(const PowConsts &C, double x, double S, double log2S, double k) {
+#if RH_SAS_POW == 0
+    return pow(x / S, k);
+#else
+    return sas_exp2(C, k * (sas_log2(C, x) - log2S));
+#endif
+}
+
 enum SasArr {
 #define RH_SAS_ARRAY(name, kind, when) SA_##name,
 #include "rh_sas_arrays.def"
@@ -74,20 +144,54 @@ struct Blk {
     double (*xch)[W][2];   // [2][W][2]
 };
 
-SAS_DEV double wave_sum(double v) {
-    for (int off = 32; off; off >>= 1) v = v + __shfl_xor(v, off);
+// Cross-lane moves as DPP (data-parallel primitive) modifiers on VALU moves instead of LDS-crossbar
+// shuffles: a DPP move costs one VALU issue, a ds_bpermute a round trip through the LDS pipeline, and
+// the scans below are dependent chains of them.  gfx9 controls: row_shr:n = 0x110 + n (shift inside a
+// row of 16 lanes), wave_shr:1 = 0x138, row_bcast:15 = 0x142 (lane 15 of a row to the next row),
+// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3).  Lanes without a source keep `ident`.
+template <int CTRL, int ROW_MASK>
+SAS_DEV double dpp_move(double ident, double v) {
+    const unsigned long long iv = __double_as_longlong(ident), sv = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)iv, (int)(unsigned)sv, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(iv >> 32), (int)(unsigned)(sv >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// value of the previous lane; lane 0 gets `first`
+SAS_DEV double lane_prev(double v, double first) { return dpp_move<0x138, 0xf>(first, v); }
+// inclusive prefix sum over the 64 lanes (earlier lanes + own)
+SAS_DEV double wave_scan_sum(double v) {
+    v = dpp_move<0x111, 0xf>(0.0, v) + v;
+    v = dpp_move<0x112, 0xf>(0.0, v) + v;
+    v = dpp_move<0x114, 0xf>(0.0, v) + v;
+    v = dpp_move<0x118, 0xf>(0.0, v) + v;
+    v = dpp_move<0x142, 0xa>(0.0, v) + v;
+    v = dpp_move<0x143, 0xc>(0.0, v) + v;
     return v;
 }
+SAS_DEV double lane63(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// max over the 64 lanes, in every lane
 SAS_DEV double wave_max(double v) {
-    for (int off = 32; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    const double ninf = -INFINITY;
+    v = fmax(dpp_move<0x111, 0xf>(ninf, v), v);
+    v = fmax(dpp_move<0x112, 0xf>(ninf, v), v);
+    v = fmax(dpp_move<0x114, 0xf>(ninf, v), v);
+    v = fmax(dpp_move<0x118, 0xf>(ninf, v), v);
+    v = fmax(dpp_move<0x142, 0xa>(ninf, v), v);
+    v = fmax(dpp_move<0x143, 0xc>(ninf, v), v);
+    return lane63(v);
 }
+// sum over the 64 lanes, in every lane
+SAS_DEV double wave_sum(double v) { return lane63(wave_scan_sum(v)); }
 
 // value of the previous thread (thread 0: `first`), two values per call
 template <int W>
 SAS_DEV void blk_prev2(Blk<W> &B, double a, double b, double a0, double b0, double &pa, double &pb) {
-    pa = __shfl_up(a, 1);
-    pb = __shfl_up(b, 1);
+    pa = lane_prev(a, a0);
+    pb = lane_prev(b, b0);
     if (W > 1) {
         const int buf = B.phase++ & 1;
         if (B.lane == 63) {
@@ -153,14 +257,8 @@ SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double
     loc[0] = v[0];
 #pragma unroll
     for (int j = 1; j < E; ++j) loc[j] = loc[j - 1] + v[j];
-    double winc = loc[E - 1];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(winc, d);
-        if (B.lane >= d) winc = t + winc;
-    }
-    double wexc = __shfl_up(winc, 1);
-    if (B.lane == 0) wexc = 0.0;
+    const double winc = wave_scan_sum(loc[E - 1]);
+    const double wexc = lane_prev(winc, 0.0);
     double u[E];
     double umax = wexc;
 #pragma unroll
@@ -227,6 +325,7 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
     }
     const double code = p[0];
     const bool uniform = (code == 1), power = (code == 6 || code == 61 || code == 62);
+    const PowConsts C = load_pow_consts();
     if (!uniform && !power && B.tid == 0) *P.unsupported = 1;
     double san[E], TTn_hi[E], TTn_lo = 0.0;
 #pragma unroll
@@ -254,16 +353,22 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
             }
         } else if (power) {
             const double S = Smax * mk;
-            double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
-            S_rel = (S_rel < 0 ? 0 : S_rel);
-            S_rel = (S_rel > 1 ? 1 : S_rel);
             double k = p[1];
-            if (code == 61) k = p[3] + ((1 - S_rel) * p[4]);
-            if (code == 62) k = p[3] + (S_rel * p[4]);
+            if (code != 6) {  // storage-dependent exponent, sas.py:205-226
+                double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
+                S_rel = (S_rel < 0 ? 0 : S_rel);
+                S_rel = (S_rel > 1 ? 1 : S_rel);
+                if (code == 61) k = p[3] + ((1 - S_rel) * p[4]);
+                if (code == 62) k = p[3] + (S_rel * p[4]);
+            }
+            const double log2S = sas_log2(C, S);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const double x = SA_hi[j];
-                const double o = (x > 0 ? (x <= S ? pow(x / S, k) : 1.) : 0.) * 1.0 * mk;
+                // evaluated for every class and selected afterwards: straight-line code lets the E independent
+                // evaluations interleave (a NaN from x <= 0 is discarded by the select)
+                const double v = sas_pow_ratio(C, x, S, log2S, k);
+                const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
                 Om[j] = (S <= 0 ? 0 : o) * mk;
             }
         } else {
@@ -499,8 +604,17 @@ SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> 
     D.TT_lo = g_TT[base < A ? base : A];
 }
 
+// RH_SAS_WAVES > 0: register budget for that many waves per SIMD (experiments; 0 = compiler's choice)
+#ifndef RH_SAS_WAVES
+#define RH_SAS_WAVES 3
+#endif
+#if RH_SAS_WAVES > 0
+#define SAS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RH_SAS_WAVES, RH_SAS_WAVES)))
+#else
+#define SAS_OCCUPANCY
+#endif
 template <int W, int E>
-__global__ __launch_bounds__(W * 64) void k_sas(const SasArgs P) {
+__global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     Blk<W> B;
@@ -617,6 +731,12 @@ __global__ __launch_bounds__(W * 64) void k_sas(const SasArgs P) {
                 g3[base + j] = msa_ss[j];
             }
     }
+}
+
+__global__ void k_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const PowConsts C = load_pow_consts();
+    if (i < n) out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -802,6 +922,37 @@ int rh_sas_download(rh_sas_ctx *ctx, int a, void *host, size_t bytes) {
     return rh_sas_sync(ctx);
 }
 
+static int sas_check_cells(rh_sas_ctx *ctx, int a, int64_t first, int64_t cnt, size_t bytes, const void *host, const char *who,
+                           size_t *offset) {
+    if (!ctx) return RH_ERR_ARG;
+    if (a < 0 || a >= SA_COUNT) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": unknown array id");
+    if (!ctx->arr[a]) return sfail(ctx, RH_ERR_STATE, std::string(who) + ": array " + SAS_NAMES[a] + " is not held by this context");
+    if (SAS_KIND[a] == K_DAILY) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": daily inputs are (forcing_days, n_cells); use the whole-array call");
+    if (first < 0 || cnt <= 0 || first + cnt > ctx->cfg.n_cells) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": cell range out of bounds");
+    const size_t row = (size_t)(ctx->elems[a] / ctx->cfg.n_cells) * (SAS_KIND[a] == K_MASK ? sizeof(int32_t) : sizeof(double));
+    if (bytes != row * (size_t)cnt) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": size mismatch for array " + SAS_NAMES[a]);
+    if (!host) return sfail(ctx, RH_ERR_ARG, std::string(who) + ": null host pointer");
+    *offset = row * (size_t)first;
+    return RH_OK;
+}
+
+int rh_sas_upload_cells(rh_sas_ctx *ctx, int a, int64_t first_cell, int64_t n_cells, const void *host, size_t bytes) {
+    size_t off;
+    const int rc = sas_check_cells(ctx, a, first_cell, n_cells, bytes, host, "rh_sas_upload_cells", &off);
+    if (rc) return rc;
+    SHIPCHK(ctx, hipMemcpyAsync((char *)ctx->arr[a] + off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+
+int rh_sas_download_cells(rh_sas_ctx *ctx, int a, int64_t first_cell, int64_t n_cells, void *host, size_t bytes) {
+    size_t off;
+    const int rc = sas_check_cells(ctx, a, first_cell, n_cells, bytes, host, "rh_sas_download_cells", &off);
+    if (rc) return rc;
+    SHIPCHK(ctx, hipMemcpyAsync(host, (const char *)ctx->arr[a] + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return rh_sas_sync(ctx);
+}
+
 void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int a) { return (ctx && a >= 0 && a < SA_COUNT) ? ctx->arr[a] : nullptr; }
 
 int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
@@ -864,6 +1015,24 @@ int rh_sas_run_days(rh_sas_ctx *ctx, int64_t day0, int64_t ndays) {
         if (rc) return rc;
     }
     return RH_OK;
+}
+
+int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
+    if (!x || !k || !out || n <= 0) return RH_ERR_ARG;
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)) != hipSuccess) return RH_ERR_HIP;
+    int rc = RH_OK;
+    if (hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, k, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = RH_ERR_HIP;
+    if (rc == RH_OK) {
+        hipLaunchKernelGGL(k_selftest_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = RH_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int rh_sas_enable_timing(rh_sas_ctx *ctx, int on) {

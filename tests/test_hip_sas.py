@@ -233,3 +233,21 @@ def test_unsupported_family_is_reported():
     with pytest.raises(_native.NativeError, match="SAS family"):
         ctx.sync()
     ctx.close()
+
+
+def test_power_function_accuracy():
+    """The kernel's own x**k (2**(k * log2 x), rh_sas.hip:sas_pow) against the host's pow over the argument range of
+    the power-law SAS function: relative error < 2e-14 * max(1, k) for x down to 1e-21, exact 1 at x == 1."""
+    from roger_amd import _native
+
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-21, 0, 200_000), rng.uniform(0.5, 1.0, 100_000), [1.0, 0.5, 1e-300, 5e-324]])
+    k = np.concatenate([rng.uniform(0.05, 3.0, 300_000), [0.7, 1.0, 0.2, 0.2]])
+    got = _native.sas_selftest_pow(x, k)
+    want = np.power(x, k)
+    rel = np.abs(got - want) / want
+    assert rel[:-2].max() < 2e-14 * 3, rel[:-2].max()
+    assert np.median(rel[:-2]) < 1e-15
+    assert rel[-2:].max() < 1e-12          # 1e-300 and the smallest denormal
+    assert got[-4] == 1.0 and (_native.sas_selftest_pow(np.ones(8), np.linspace(0.1, 5, 8)) == 1.0).all()
+    assert (_native.sas_selftest_pow(np.array([1e-300, 1e-10]), np.array([50.0, 0.0])) == np.array([0.0, 1.0])).all()

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Small fixed SAS workload for rocprofv3 runs: n columns x 1000 ages, a few days.
+usage: python3 tools/sas_workload.py [n_cells] [days]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from roger_amd import sas as rsas  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+days = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+daily = rsas.synthetic_daily_inputs(n, 8, seed=42)
+ctx = rsas.create_sas(n, 1000, 6, 90.0, 260.0, daily=daily, age_statistics=True)
+ctx.run_days(0, days)
+ctx.sync()
+print("d18O q_ss", ctx.download("C_iso_q_ss")[:3])
+ctx.close()
