@@ -323,15 +323,15 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
         for (int j = 0; j < E; ++j) tt[j] = 0.0;
         return;
     }
-    const double code = p[0];
+    const double code = p[0], p1 = p[1], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6];  // read once: the loop below stores nothing, but the compiler cannot know
     const bool uniform = (code == 1), power = (code == 6 || code == 61 || code == 62);
     const PowConsts C = load_pow_consts();
     if (!uniform && !power && B.tid == 0) *P.unsupported = 1;
-    double san[E], TTn_hi[E], TTn_lo = 0.0;
+    double san[E], ttn[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         san[j] = sa[j];
-        TTn_hi[j] = 0.0;
+        ttn[j] = 0.0;
     }
     for (int it = 0; it < P.substeps; ++it) {
         double SA_hi[E], SA_lo, Smax;
@@ -353,13 +353,13 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
             }
         } else if (power) {
             const double S = Smax * mk;
-            double k = p[1];
+            double k = p1;
             if (code != 6) {  // storage-dependent exponent, sas.py:205-226
-                double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
+                double S_rel = (S - p5) / (p6 - p5) * mk;
                 S_rel = (S_rel < 0 ? 0 : S_rel);
                 S_rel = (S_rel > 1 ? 1 : S_rel);
-                if (code == 61) k = p[3] + ((1 - S_rel) * p[4]);
-                if (code == 62) k = p[3] + (S_rel * p[4]);
+                if (code == 61) k = p3 + ((1 - S_rel) * p4);
+                if (code == 62) k = p3 + (S_rel * p4);
             }
             const double log2S = sas_log2(C, S);
 #pragma unroll
@@ -387,17 +387,17 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
             san[j] = san[j] + -t * flux * h;                                    // :445-448
             tti[j] = t;
         }
-        double c_hi[E], c_lo;
-        blk_cumsum<W, E>(B, tti, c_hi, c_lo, nullptr);
+        // :461-468.  The reference accumulates TTn += cumsum(tti) and takes diff(TTn / N) afterwards (:482-490);
+        // diff(cumsum(.)) is the identity, so the sub-step distributions are accumulated directly (the
+        // reference's own `ttn`).  Differs from the round trip through the cumulative sums by ~1e-16 absolute
+        // and saves one block scan per sub-step.
 #pragma unroll
-        for (int j = 0; j < E; ++j) TTn_hi[j] += c_hi[j];  // :465-468
-        TTn_lo += c_lo;
+        for (int j = 0; j < E; ++j) ttn[j] += tti[j];
     }
     const double N = (double)P.substeps;
-    const double TT_lo = TTn_lo / N;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const double t = TTn_hi[j] / N - (j == 0 ? TT_lo : TTn_hi[j - 1] / N);  // :482-490
+        const double t = ttn[j] / N;                                              // :482-490
         const double q = (flux * t > sa[j] ? sa[j] : flux * t);                   // :493-496
         tt[j] = (flux > 0 ? q / flux : 0);                                        // :497-499
     }
