@@ -130,6 +130,15 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = algo * n / k_avg_s / 1e9
         pows = 5 * args.substeps * (args.ages + 1)
+        traffic, traffic_note = None, ""
+        tf = os.path.join(REPO, "profiles", "traffic_sas.json")
+        if os.path.exists(tf) and args.ages == 1000:
+            try:
+                rec = json.load(open(tf))
+                traffic = rec["bytes_per_cell"] * n   # same kernel, one workgroup per column: linear in the column count
+                traffic_note = f"; traffic = PMC bytes per column measured at {rec['n_cells']} columns x this launch's columns"
+            except Exception:
+                traffic = None
         out = {
             "metric": "cell-timesteps/sec on SVATOXYGEN18_benchmark grid",
             "value": world * n * args.steps / elapsed,
@@ -155,12 +164,12 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
                 "bound": "hbm",
                 "kernel": "k_sas",
                 "note": f"algorithmic bytes = state read + written once per day; the kernel is fp64-ALU bound by "
-                        f"<= {pows} pow per column-day (fluxes that are 0 on a day are skipped), see DESIGN.md",
+                        f"<= {pows} pow per column-day (fluxes that are 0 on a day are skipped), see DESIGN.md" + traffic_note,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo * n,
                 "avg_kernel_ms": k_avg_s * 1e3,
                 "launches_timed": launches,

@@ -25,19 +25,21 @@ def per_kernel(dirname, counter):
     return rows
 
 
-def main(fetch_dir, write_dir, n_cells, out):
+def main(fetch_dir, write_dir, n_cells, out, kernel="k_step<false", calib_cells=None):
+    """kernel: substring of the kernel name to report; calib_cells: cells of the context the calibration copy ran
+    on (default: n_cells)."""
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     key = lambda d, sub: next(k for k in d if sub in k)  # noqa: E731
     avg = lambda v: sum(v) / len(v)  # noqa: E731
-    known = CALIB_PLANES * n_cells * 8
+    known = CALIB_PLANES * (calib_cells or n_cells) * 8
     f_cal, w_cal = avg(fetch[key(fetch, "k_calib_copy")]) * 1024, avg(write[key(write, "k_calib_copy")]) * 1024
     f_scale, w_scale = known / f_cal, known / w_cal
-    ks_f = fetch[key(fetch, "k_step<false")]
-    ks_w = write[key(write, "k_step<false")]
+    ks_f = fetch[key(fetch, kernel)]
+    ks_w = write[key(write, kernel)]
     fb, wb = avg(ks_f) * 1024 * f_scale, avg(ks_w) * 1024 * w_scale
     rec = {
         "n_cells": n_cells,
-        "kernel": "k_step<false, false>",
+        "kernel": key(fetch, kernel),
         "hbm_bytes_per_launch": fb + wb,
         "fetch_bytes_per_launch": fb,
         "write_bytes_per_launch": wb,
@@ -55,4 +57,5 @@ def main(fetch_dir, write_dir, n_cells, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], *(sys.argv[5:6] or ["k_step<false"]),
+         *([int(sys.argv[6])] if len(sys.argv) > 6 else []))

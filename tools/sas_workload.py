@@ -5,7 +5,16 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from roger_amd import _native as N  # noqa: E402
 from roger_amd import sas as rsas  # noqa: E402
+
+if os.environ.get("RH_PMC_CALIB"):   # calibration copy of known size first (tools/pmc_summarise.py)
+    scratch = N.Context(1000, 1000)
+    first = next(i for i, (_, is_int) in enumerate(scratch.planes) if not is_int)
+    for _ in range(5):
+        scratch.calibrate_copy(first, first + 100, 96)
+    scratch.sync()
+    scratch.close()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 days = int(sys.argv[2]) if len(sys.argv) > 2 else 4
