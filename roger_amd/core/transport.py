@@ -1,0 +1,54 @@
+"""Offline transport on the hip backend, mirroring the entry points of roger/core/transport.py that a setup
+script and `RogerSetup.step` use: `delta_to_conc`, `conc_to_delta` (host helpers for the user hooks) and
+`calculate_storage_selection` (the native SAS step).
+"""
+import numpy as np
+
+from .. import _native
+from ..routines import roger_routine
+from ..variables import SAS_FLUXES, SAS_STAT_TARGETS
+
+
+def delta_to_conc(state, delta_iso):
+    """roger/core/transport.py:315-325 (oxygen-18)."""
+    v = state.settings.VSMOW_conc18O
+    delta_iso = np.asarray(delta_iso, dtype=np.float64)
+    return v * (delta_iso / 1000. + 1.) / (1. + (delta_iso / 1000. + 1.) * v)
+
+
+def conc_to_delta(state, conc):
+    """roger/core/transport.py:328-340 (oxygen-18)."""
+    st = state.settings
+    conc = np.asarray(conc, dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = 1000. * (conc / (st.VSMOW_conc18O * (1. - conc)) - 1.)
+        return np.where((d < st.d18O_min) | (d > st.d18O_max), np.nan, d)
+
+
+def _written_by_step(settings):
+    names = ["sa_rz", "msa_rz", "sa_ss", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"]
+    for f in SAS_FLUXES:
+        names += [f"tt_{f}", f"mtt_{f}", f"TT_{f}", f"C_{f}", f"C_iso_{f}"]
+    for f in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
+        names += [f"C_{f}", f"C_iso_{f}"]
+    if settings.enable_age_statistics:
+        names += [f"{p}{q}_{w}" for w, p in SAS_STAT_TARGETS for q in ("10", "25", "50", "75", "90", "avg")]
+    return names
+
+
+@roger_routine
+def calculate_storage_selection(state):
+    """roger/core/transport.py:3136 for `enable_oxygen18 and sas_solver == "deterministic"`:
+    svat_transport_model_deterministic (:949-991) as one native launch (rh_sas_step).  What the user's
+    set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
+    `vs.<name>` is read."""
+    vs = state.variables
+    sas = state.sas_context
+    if sas is None:
+        raise RuntimeError("calculate_storage_selection needs settings.enable_offline_transport")
+    vs.flush_to_device()
+    sas.step(0)
+    vs.mark_device_newer(_written_by_step(state.settings))
+
+
+SAS_STAGES = _native.SAS_STAGES

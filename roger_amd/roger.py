@@ -119,24 +119,38 @@ class RogerSetup(metaclass=abc.ABCMeta):
             distributed.validate_decomposition(state.settings.nx, state.settings.ny, rs.num_proc,
                                                rs.num_proc[0] * rs.num_proc[1])
             state.initialize_variables()
+            offline = state.settings.enable_offline_transport
             self.set_grid(state)
             self.set_topography(state)
             self.set_look_up_tables(state)
-            self._upload_luts()
+            if not offline:
+                self._upload_luts()
             self.set_parameters_setup(state)
-            surface.calculate_parameters(state)
-            soil.calculate_parameters(state)
+            if not offline:   # the parameter / initial-condition kernels are skipped for offline transport:
+                surface.calculate_parameters(state)   # roger/core/surface.py:391,425, soil.py:731,1002
+                soil.calculate_parameters(state)
             self.set_initial_conditions_setup(state)
             self.set_initial_conditions(state)
-            surface.calculate_initial_conditions(state)
-            soil.calculate_initial_conditions(state)
+            if not offline:
+                surface.calculate_initial_conditions(state)
+                soil.calculate_initial_conditions(state)
             self.set_diagnostics(state)
             self.set_boundary_conditions_setup(state)
             self.set_boundary_conditions(state)
             self.set_forcing_setup(state)
         self._setup_done = True
-        with state.settings.unlock():
-            state.settings.warmup_done = True
+        if not state.settings.enable_offline_transport:   # roger/roger.py:324-327
+            with state.settings.unlock():
+                state.settings.warmup_done = True
+
+    def warmup(self, repeat=1):
+        """roger/roger.py:491-521.  The transport warm-up (repeated runs + soil.rescale_SA) is not part of the native
+        path; without it the model starts from the initial conditions of the setup script."""
+        if self.state.settings.enable_offline_transport and repeat > 0:
+            raise NotImplementedError("warmup(repeat > 0) needs soil.rescale_SA, which the hip backend does not implement; "
+                                      "call warmup(repeat=0) to start from the initial conditions")
+        with self.state.settings.unlock():
+            self.state.settings.warmup_done = True
 
     def _upload_luts(self):
         vs = self.state.variables
@@ -148,6 +162,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
     @roger_routine
     def step(self, state):
         self._ensure_setup_done()
+        if state.settings.enable_offline_transport:
+            return self._step_offline_transport(state)
         with state.timers["main"]:
             with state.timers["read data"]:
                 self.read_data(state)
@@ -166,6 +182,32 @@ class RogerSetup(metaclass=abc.ABCMeta):
             state.backend_context.sync()
             logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
 
+    def _step_offline_transport(self, state):
+        """roger/roger.py:466-485: the offline-transport branch of step()."""
+        from .core import transport
+
+        vs = state.variables
+        with state.timers["main"]:
+            with vs.unlock():
+                vs.itt = vs.itt + 1   # skip first iteration which contains initial values
+                if state.settings.sas_solver == "deterministic":
+                    vs.time = vs.time + vs.dt_secs
+            with state.timers["main transport"]:
+                with state.timers["read data"]:
+                    self.read_data(state)
+                with state.timers["boundary conditions"]:
+                    self.set_boundary_conditions(state)
+                with state.timers["forcing"]:
+                    self.set_forcing(state)
+                with state.timers["time-variant parameters"]:
+                    self.set_parameters(state)
+                with state.timers["StorAge selection"]:
+                    transport.calculate_storage_selection(state)
+        self.after_timestep(state)
+        if rs.profile_mode:
+            state.sas_context.sync()
+            logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
+
     def run(self, show_progress_bar=None):
         """roger/roger.py:523-580"""
         self._ensure_setup_done()
@@ -174,7 +216,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
         start_time = vs.time
         while vs.time - start_time < runlen:
             self.step(self.state)
-        self.state.backend_context.sync()
+        (self.state.sas_context or self.state.backend_context).sync()
 
     # -- fast path --------------------------------------------------------------------------------
     def enable_device_hooks(self):

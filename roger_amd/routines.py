@@ -84,7 +84,9 @@ def roger_kernel(function=None, *, static_args=()):
         def wrapper(*args, **kwargs):
             state = _find_state(args, kwargs)
             native = NATIVE_KERNELS.get(fn.__name__)
-            if native is not None and state is not None:
+            # the native substitutes are the SVAT / oneD kernels; in an offline-transport run a kernel of that
+            # name is the transport model's own (models/svat_oxygen18: tau -> taum1 of the snow signal) and runs on the host
+            if native is not None and state is not None and not state.settings.enable_offline_transport:
                 return run_native(state, *native)
             if state is not None and state._variables is not None:
                 with state.variables.unlock():

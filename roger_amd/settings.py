@@ -23,6 +23,9 @@ SETTINGS = {
     "dz": Setting(1, int, "Vertical grid spacing"),
     "nitt": Setting(1, int, "Number of total iterations"),
     "nitt_forc": Setting(1, int, "Number of total iterations of forcing"),
+    "ages": Setting(1, int, "Number of water ages"),
+    "nages": Setting(2, int, "Number of water ages to calculate cumulated distributions"),
+    "nsas": Setting(8, int, "Number of entries per grid cell containing SAS parameters"),
     "runlen": Setting(0.0, float, "Length of simulation in seconds"),
     "runlen_warmup": Setting(0.0, float, "Length of warmup simulation in seconds"),
     "x_origin": Setting(0, float, "Grid origin in x-direction"),
@@ -51,6 +54,20 @@ SETTINGS = {
     "transp_water_stress": Setting(0.75, float, "fraction of fine pore storage in -"),
     "atol": Setting(1e-2, float, "absolute tolerance of solutions"),
     "rtol": Setting(1e-2, float, "relative tolerance of solutions"),
+    # offline transport (roger/settings.py:76-78, 102-120)
+    "VSMOW_conc18O": Setting(2005.2e-6, float, "oxygen-18 abundancy ratios according to VSMOW in -"),
+    "d18O_min": Setting(-20, float, "potentially lowest oxygen-18 value in per mille"),
+    "d18O_max": Setting(0, float, "potentially greatest oxygen-18 value in per mille"),
+    "enable_bromide": Setting(False, bool, "enable bromide"),
+    "enable_chloride": Setting(False, bool, "enable enable_chloride"),
+    "enable_oxygen18": Setting(False, bool, "enable oxygen-18"),
+    "enable_deuterium": Setting(False, bool, "enable deuterium"),
+    "enable_nitrate": Setting(False, bool, "enable nitrate"),
+    "enable_virtualtracer": Setting(False, bool, "enable virtual tracer"),
+    "tm_structure": Setting("UNNAMED", str, "transport model structure"),
+    "enable_age_statistics": Setting(False, bool, "enable calculation of age statistics"),
+    "sas_solver": Setting(None, optional(str), "numerical solver scheme for StorAge selection"),
+    "sas_solver_substeps": Setting(1, int, "substeps to solver for StorAge selection numerically"),
     # process switches: only the SVAT path is implemented natively; the others must stay off
     "enable_distributed_input": Setting(False, bool, "enable distributed input"),
     "enable_film_flow": Setting(False, bool, "enable film flow process"),
@@ -71,8 +88,9 @@ SETTINGS = {
 
 _UNSUPPORTED_SWITCHES = (
     "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
-    "enable_net_irrigation", "enable_soil_compaction", "enable_offline_transport", "enable_groundwater_boundary",
+    "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
+    "enable_bromide", "enable_chloride", "enable_deuterium", "enable_nitrate", "enable_virtualtracer",
 )
 
 
@@ -82,6 +100,17 @@ def check_setting_conflicts(settings):
         if getattr(settings, name):
             raise NotImplementedError(
                 f"settings.{name}=True is outside the hot path of the hip backend (SURVEY.md section 8: out of scope)")
+    if settings.enable_offline_transport:
+        # the native transport path: oxygen-18 with the deterministic SAS solver
+        if not settings.enable_oxygen18:
+            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18 "
+                                      "(settings.enable_oxygen18 must be True)")
+        if settings.sas_solver != "deterministic":
+            raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
+                                      '"deterministic" SAS solver (Euler / RK4 are out of scope, SURVEY.md section 8)')
+        if settings.nages != settings.ages + 1:
+            raise ValueError("settings.nages must be settings.ages + 1")
+        return
     if not settings.enable_adaptive_time_stepping:
         raise NotImplementedError("the hip backend implements the adaptive time stepping of the SVAT benchmarks "
                                   "(settings.enable_adaptive_time_stepping must be True)")

@@ -94,14 +94,37 @@ class RogerSettings(Lockable):
         return self
 
 
-class RogerVariables(Lockable):
-    """roger/state.py:189-257 over a `_native.Context`."""
+class HostScalars:
+    """Stand-in for the arena context in offline-transport runs, where the time-stepping scalars (itt, time, dt,
+    dt_secs) are plain host values (the transport step has no device-side bookkeeping)."""
 
-    def __init__(self, var_meta, dimensions, ctx):
+    def __init__(self):
+        self._s = _native.RhScalars()
+        self._s.dt, self._s.dt_secs, self._s.sanity_ok = 1.0, 3600, 1
+
+    def get_scalars(self):
+        return self._s
+
+    def set_scalars(self, s):
+        self._s = s
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class RogerVariables(Lockable):
+    """roger/state.py:189-257 over a `_native.Context` (SVAT / oneD) or a `_native.SasContext` (offline
+    transport)."""
+
+    def __init__(self, var_meta, dimensions, ctx, sas_ctx=None):
         d = object.__setattr__
         d(self, "__metadata__", var_meta)
         d(self, "__dimensions__", dimensions)
         d(self, "_ctx", ctx)
+        d(self, "_sas", sas_ctx)
         d(self, "_host", {})
         d(self, "_host_dirty", set())
         d(self, "_device_newer", set())
@@ -175,7 +198,7 @@ class RogerVariables(Lockable):
             arr.flags.writeable = False
         self._host[key] = arr
         self._device_newer.discard(key)
-        if var.plane is not None:
+        if var.plane is not None or var.sas is not None:
             self._host_dirty.add(key)
         elif key in ("prec_day", "ta_day", "pet_day"):
             object.__setattr__(self, "_forcing_dirty", True)
@@ -214,6 +237,23 @@ class RogerVariables(Lockable):
     def _download(self, key):
         host = self._host[key].copy()
         nxl, nyl = host.shape[0] - 4, host.shape[1] - 4
+        var = self.__metadata__[key]
+        if var.sas is not None:
+            dev = self._sas.download(var.sas)
+            if var.sas in _native.DAILY_INPUTS:
+                dev = dev[0]
+            dev = dev.reshape((nxl, nyl) + dev.shape[1:]).astype(host.dtype)
+            if "timesteps" in var.dims:
+                # the device holds time level tau; after the step tau and taum1 agree (after_substep_iso,
+                # roger/core/transport.py:3421-3521)
+                host[2:-2, 2:-2, 0] = dev
+                host[2:-2, 2:-2, 1] = dev
+            else:
+                host[2:-2, 2:-2] = dev
+            host.flags.writeable = False
+            self._host[key] = host
+            self._device_newer.discard(key)
+            return
         for suffix, lvl in self._levels(key):
             flat = self._ctx.download(key + suffix).reshape(nxl, nyl)
             if lvl is None:
@@ -228,6 +268,14 @@ class RogerVariables(Lockable):
         """Upload everything assigned on the host since the last native call."""
         for key in sorted(self._host_dirty):
             host = self._host[key]
+            var = self.__metadata__[key]
+            if var.sas is not None:
+                a = host[2:-2, 2:-2]
+                if "timesteps" in var.dims:
+                    a = a[:, :, 1]
+                a = np.ascontiguousarray(a).reshape((a.shape[0] * a.shape[1],) + a.shape[2:])
+                self._sas.upload(var.sas, a[None, :] if var.sas in _native.DAILY_INPUTS else a)
+                continue
             for suffix, lvl in self._levels(key):
                 self._ctx.upload(key + suffix, host[2:-2, 2:-2] if lvl is None else host[2:-2, 2:-2, lvl])
         self._host_dirty.clear()
@@ -248,6 +296,7 @@ class RogerVariables(Lockable):
         """After a native call: `names` (or every arena variable) changed on the device."""
         if names is None:
             names = [k for k, v in self.__metadata__.items() if v.plane is not None]
+        names = [k for k in names if k in self.__metadata__]
         self._device_newer.update(names)
         object.__setattr__(self, "_scalars", None)
 
@@ -280,13 +329,25 @@ class RogerState:
 
         if self._variables is not None:
             raise RuntimeError("Variables are already initialized.")
-        if self._var_meta is None:
-            self._var_meta = var_mod.build_variables()
         s = self._settings
         px, py = rs.num_proc
         import os
 
         device = int(os.environ.get("LOCAL_RANK", "0"))
+        if s.enable_offline_transport:
+            # offline oxygen-18 transport: the state lives in a SAS context (include/roger_hip_sas.h); the reference's
+            # variables tt_*, mtt_*, TT_*, sa_s, msa_s are exposed, hence keep_distributions
+            if self._var_meta is None:
+                self._var_meta = var_mod.build_transport_variables(s)
+            self._sas_ctx = _native.SasContext(
+                (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,
+                age_statistics=s.enable_age_statistics, keep_distributions=True, vsmow=s.VSMOW_conc18O,
+                d18O_min=s.d18O_min, d18O_max=s.d18O_max)
+            self._ctx = HostScalars()
+            self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)
+            return
+        if self._var_meta is None:
+            self._var_meta = var_mod.build_variables()
         consts = {k: getattr(s, k) for k in (
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min", "clay_max",
             "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max", "a_bc", "b_bc",
@@ -317,3 +378,8 @@ class RogerState:
     @property
     def backend_context(self):
         return self._ctx
+
+    @property
+    def sas_context(self):
+        """The `_native.SasContext` of an offline-transport run (None otherwise)."""
+        return getattr(self, "_sas_ctx", None)

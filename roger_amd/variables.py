@@ -6,10 +6,11 @@ from . import _native
 
 
 class Variable:
-    def __init__(self, name, dims, units="", long_description="", dtype=None, initial=None, plane=None):
+    def __init__(self, name, dims, units="", long_description="", dtype=None, initial=None, plane=None, sas=None):
         self.name, self.dims, self.units, self.long_description = name, dims, units, long_description
         self.dtype, self.initial = dtype, initial
         self.plane = plane  # name of the device plane backing it (None: host-only variable)
+        self.sas = sas      # name of the array of the SAS context backing it (offline transport)
         self.active = True
 
 
@@ -20,6 +21,7 @@ GHOST_DIMENSIONS = ("x", "y")
 # roger/variables.py:101-131
 DIM_TO_SHAPE_VAR = {
     "x": "nx", "y": "ny", "t_forc": "nitt_forc", "timesteps": 2, "timesteps_day": 6 * 24,
+    "t": "nitt", "ages": "ages", "nages": "nages", "n_sas_params": "nsas",
     "n_lu": 25, "n_sealing": 101, "n_slope": 10000, "n_params2": 2, "n_params7": 7, "n_params9": 9, "n_params13": 13,
 }
 
@@ -105,6 +107,66 @@ def build_variables():
     for name in ("prec_day", "ta_day", "pet_day"):
         V[name] = Variable(name, CATCH_GRID + ("timesteps_day",))
     V.update(_arena_variables())
+    return V
+
+
+SAS_FLUXES = ("evap_soil", "transp", "q_rz", "q_ss", "cpr_rz")
+SAS_STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
+
+
+def build_transport_variables(settings):
+    """Registry of the offline oxygen-18 transport model (roger/variables.py, the variables that are `active`
+    for enable_offline_transport & enable_oxygen18 and that the deterministic path touches).  Variables with
+    `sas=` live in the SAS context on the device; the others are host-only (time series read by the user's
+    set_forcing hook, storages, snow signal)."""
+    V = {}
+    i64 = np.int64
+    for name, initial in (("tau", 1), ("taup1", 2), ("taum1", 0), ("time", 0), ("itt", 0), ("dt_secs", 3600),
+                          ("time_for_diag", 0), ("itt_substep", 0)):
+        V[name] = Variable(name, None, dtype=i64, initial=initial)
+    V["dt"] = Variable("dt", None, initial=1)
+    V["x"] = Variable("x", ("x",))
+    V["y"] = Variable("y", ("y",))
+    V["ages"] = Variable("ages", ("ages",))
+    V["nages"] = Variable("nages", ("nages",))
+    AG, NAG = ("ages",), ("nages",)
+    V["maskCatch"] = Variable("maskCatch", CATCH_GRID, dtype=np.bool_, initial=True, sas="maskCatch")
+    for st in ("rz", "ss"):
+        V[f"sa_{st}"] = Variable(f"sa_{st}", CATCH_GRID + TIMESTEPS + AG, sas=f"sa_{st}")
+        V[f"msa_{st}"] = Variable(f"msa_{st}", CATCH_GRID + TIMESTEPS + AG, sas=f"msa_{st}")
+    V["sa_s"] = Variable("sa_s", CATCH_GRID + TIMESTEPS + AG, sas="sa_s")
+    V["msa_s"] = Variable("msa_s", CATCH_GRID + TIMESTEPS + AG, sas="msa_s")
+    for st in ("rz", "ss", "s"):
+        V[f"SA_{st}"] = Variable(f"SA_{st}", CATCH_GRID + TIMESTEPS + NAG)       # host-only diagnostic
+        V[f"csa_{st}"] = Variable(f"csa_{st}", CATCH_GRID + TIMESTEPS + AG)      # host-only diagnostic
+        V[f"C_{st}"] = Variable(f"C_{st}", CATCH_GRID + TIMESTEPS, sas=f"C_{st}")
+        V[f"C_iso_{st}"] = Variable(f"C_iso_{st}", CATCH_GRID + TIMESTEPS, sas=f"C_iso_{st}")
+        V[f"S_{st}"] = Variable(f"S_{st}", CATCH_GRID + TIMESTEPS)
+    for f in SAS_FLUXES:
+        V[f] = Variable(f, CATCH_GRID, sas=f)
+        V[f"sas_params_{f}"] = Variable(f"sas_params_{f}", CATCH_GRID + ("n_sas_params",), sas=f"sas_params_{f}")
+        V[f"tt_{f}"] = Variable(f"tt_{f}", CATCH_GRID + AG, sas=f"tt_{f}")
+        V[f"mtt_{f}"] = Variable(f"mtt_{f}", CATCH_GRID + AG, sas=f"mtt_{f}")
+        V[f"TT_{f}"] = Variable(f"TT_{f}", CATCH_GRID + NAG, sas=f"TT_{f}")
+        V[f"C_{f}"] = Variable(f"C_{f}", CATCH_GRID, sas=f"C_{f}")
+        V[f"C_iso_{f}"] = Variable(f"C_iso_{f}", CATCH_GRID, sas=f"C_iso_{f}")
+    for f in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
+        V[f] = Variable(f, CATCH_GRID, sas=f)
+        V[f"C_{f}"] = Variable(f"C_{f}", CATCH_GRID, sas=f"C_{f}")
+        V[f"C_iso_{f}"] = Variable(f"C_iso_{f}", CATCH_GRID, sas=f"C_iso_{f}")
+    V["C_in"] = Variable("C_in", CATCH_GRID, sas="C_in")
+    V["C_iso_in"] = Variable("C_iso_in", CATCH_GRID)
+    for name in ("prec", "S_snow", "C_snow", "C_iso_snow"):
+        V[name] = Variable(name, CATCH_GRID + TIMESTEPS)
+    for name in ("S_pwp_rz", "S_pwp_ss", "S_sat_rz", "S_sat_ss", "S_rz_init", "S_ss_init"):
+        V[name] = Variable(name, CATCH_GRID)
+    for name in ("PREC_DIST_DAILY", "INF_MAT_RZ", "INF_PF_RZ", "INF_PF_SS", "TRANSP", "EVAP_SOIL", "CPR_RZ", "Q_RZ", "Q_SS",
+                 "S_RZ", "S_SS", "S_S", "S_SNOW", "C_IN", "C_ISO_IN"):
+        V[name] = Variable(name, CATCH_GRID + ("t",))
+    if settings.enable_age_statistics:
+        for w, p in SAS_STAT_TARGETS:
+            for q in ("10", "25", "50", "75", "90", "avg"):
+                V[f"{p}{q}_{w}"] = Variable(f"{p}{q}_{w}", CATCH_GRID, sas=f"{p}{q}_{w}")
     return V
 
 

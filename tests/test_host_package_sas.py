@@ -1,0 +1,84 @@
+"""The host package's offline-transport flow (RogerSetup.setup / step, RogerVariables synchronisation,
+core.transport) with the oracle-backed SasContext stand-in: the very setup class that produced the SAS golden
+vectors through the reference (tests/sas_scripts.py) runs through roger_amd and reproduces them."""
+import numpy as np
+import pytest
+
+import sas_binding as sb
+from sas_scripts import make_transport_model
+from test_oracle_sas import compare_msa
+
+
+def golden_inputs(g):
+    svat = {k[3:]: g.z[k] for k in g.z.files if k.startswith("in_")}
+    sas = {f: g.z[f"sas_{f}"].reshape(g.nx, g.ny, 8) for f in sb.FLUXES}
+    return svat, sas
+
+
+def interior(a, lvl=None):
+    a = np.asarray(a)[2:-2, 2:-2]
+    if lvl is not None:
+        a = a[:, :, lvl]
+    return a.reshape((-1,) + a.shape[2:])
+
+
+def run_and_compare(g, model, first_tie=None):
+    model.setup()
+    model.warmup(repeat=0)
+    vs = model.state.variables
+    for d in range(1, g.ndays + 1):
+        model.step(model.state)
+        assert vs.itt == d and vs.time == d * 86400
+        if first_tie is not None and d >= first_tie:
+            continue
+        for k in ("sa_rz", "sa_ss"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(d, k), f"day {d} {k}")
+            compare_msa(interior(getattr(vs, "m" + k), 1), g.day(d, "m" + k), g.day(d, k), f"day {d} m{k}")
+            sb.compare_sas(interior(getattr(vs, k), 0), g.day(d, k), f"day {d} {k}[taum1]")
+        for f in sb.FLUXES:
+            for pre in ("tt", "TT", "C", "C_iso"):
+                sb.compare_sas(interior(getattr(vs, f"{pre}_{f}")), g.day(d, f"{pre}_{f}"), f"day {d} {pre}_{f}")
+        for k in ("C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(d, k), f"day {d} {k}")
+        for k in ("C_in", "C_iso_in", "C_inf_mat_rz", "C_iso_inf_pf_ss"):
+            sb.compare_sas(interior(getattr(vs, k)), g.day(d, k), f"day {d} {k}")
+        for k in ("C_snow", "C_iso_snow"):      # host-side hook arithmetic (set_forcing / after_timestep)
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(d, k), f"day {d} {k}")
+        if g.stats:
+            for w, p in sb.STAT_TARGETS:
+                for q in sb.STAT_Q:
+                    sb.compare_sas(interior(getattr(vs, f"{p}{q}_{w}")), g.day(d, f"{p}{q}_{w}"), f"day {d} {p}{q}_{w}", rtol=1e-9)
+
+
+@pytest.fixture
+def oracle_sas(monkeypatch):
+    from oracle_sas_context import OracleSasContext
+    from roger_amd import _native
+
+    monkeypatch.setattr(_native, "SasContext", OracleSasContext)
+
+
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70"])
+def test_transport_setup_through_host_package(oracle_sas, case):
+    g = sb.SasGolden(case)
+    svat, sas = golden_inputs(g)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats))
+    run_and_compare(g, model, first_tie=sb.FIRST_TIE.get(case))
+
+
+def test_transport_settings_are_checked(oracle_sas):
+    g = sb.SasGolden("sas_stats_a30")
+    svat, sas = golden_inputs(g)
+    with pytest.raises(NotImplementedError, match="deterministic"):
+        make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
+            override=dict(sas_solver="RK4")).setup()
+    with pytest.raises(NotImplementedError, match="oxygen-18"):
+        make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
+            override=dict(enable_oxygen18=False)).setup()
+    m = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False)
+    m.setup()
+    with pytest.raises(NotImplementedError, match="rescale_SA"):
+        m.warmup(repeat=1)
+    with pytest.raises(ValueError, match="unexpected shape"):
+        with m.state.variables.unlock():
+            m.state.variables.sa_rz = np.zeros((3, 3))
