@@ -497,6 +497,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // ---------------------------------------------------------------------------------------------
 #define LD(name) rh_ld(a, RH_P_##name, i, c.name);
 #define ST(name) rh_st(a, RH_P_##name, i, c.name);
+#define ROT(name) rh_st(a, RH_P_##name##_m1, i, c.name);  // tau -> taum1 copy of after_timestep, done early
 
 // THE hot kernel.  Loads every plane the step reads once, runs the whole step in registers,
 // stores every plane the step assigns once.
@@ -505,7 +506,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // routine is the first to mention are requested before the current routine computes, so their
 // latency hides behind its arithmetic.
 #define RH_LOADS(seq, rt) RH_SEQ_##seq##_LOAD_##rt(LD)
-#define RH_STORES(seq, rt) RH_SEQ_##seq##_STORE_##rt(ST)
+#define RH_STORES(seq, rt) RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)
 #if RH_STEP_PREFETCH
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
     RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)                                \

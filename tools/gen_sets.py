@@ -129,6 +129,11 @@ def analyse(funcs):
 # per SIMD, one computing while the other waits on memory):
 #   LOAD_<rt>  = mention(rt) minus everything mentioned by earlier stages (already in registers)
 #   STORE_<rt> = write(rt)   minus everything written again by a later stage
+#   ROT_<rt>   = the tau -> taum1 copies of after_timestep (`h_rotate`: c.X_m1 = c.X) that can be done right
+#                after this stage: X has its final value (no later stage assigns it) and nobody reads the old
+#                X_m1 any more.  The copy is a store of the register holding X into the X_m1 plane, so X's
+#                live range ends here instead of at the end of the kernel (the 30 rotated values were the
+#                kernel's spills).  X_m1 then leaves the after_timestep stage's store set.
 _COMMON_HEAD = ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_infiltration"]
 SEQUENCES = {
     "step": ["rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff", "rt_capillary_rise", "rt_storage",
@@ -146,11 +151,18 @@ SEQUENCE_CHECK = {"step": "rt_step", "step_monthly": "rt_step_monthly", "step_la
                   "step_lateral_monthly": "rt_step_lateral_monthly"}
 
 
+def rotation_pairs(funcs):
+    """[(X_m1, X)] of h_rotate."""
+    return re.findall(r"\bc\.(\w+_m1)\s*=\s*c\.(\w+)\s*;", funcs["h_rotate"]["body"])
+
+
 def main():
     src = strip_comments(open(SRC).read())
     fields = field_names()
     order = {n: i for i, n in enumerate(fields)}
-    sets = analyse(parse_functions(src))
+    funcs = parse_functions(src)
+    sets = analyse(funcs)
+    pairs = rotation_pairs(funcs)
     lines = ["// GENERATED by tools/gen_sets.py from rh_physics.h -- do not edit.", "#pragma once", ""]
     for name in sorted(sets):
         mention, write = sets[name]
@@ -166,11 +178,26 @@ def main():
     for seq, stages in SEQUENCES.items():
         resident, all_m, all_w = set(), set(), set()
         lines.append(f"// sequence {seq}: " + " -> ".join(stages))
+        # where each rotation can happen: after the last stage that assigns X or mentions X_m1 (the final
+        # after_timestep stage, which holds the copies themselves, does not count), not before X is loaded
+        last = len(stages) - 1
+        rot_at = {}
+        for xm1, x in pairs:
+            r = -1
+            for i, rt in enumerate(stages[:last]):
+                mention, write = sets[rt]
+                if x in write or xm1 in mention:
+                    r = i
+            first = next((i for i, rt in enumerate(stages) if x in sets[rt][0]), last)
+            rot_at[(xm1, x)] = max(r, first)
+        moved = {xm1 for (xm1, x), r in rot_at.items() if r < last}
         for i, rt in enumerate(stages):
             mention, write = sets[rt]
             later_w = set().union(*[sets[r][1] for r in stages[i + 1:]]) if i + 1 < len(stages) else set()
             ld = sorted(mention - resident, key=order.get)
-            st = sorted(write - later_w, key=order.get)
+            st = sorted((write - later_w) - (moved if i == last else set()), key=order.get)
+            rot = sorted([x for (xm1, x), r in rot_at.items() if r == i and i < last], key=order.get)
+            lines.append(f"#define RH_SEQ_{seq}_ROT_{rt}(X) " + " ".join(f"X({n})" for n in rot))
             resident |= mention
             all_m |= mention
             all_w |= write
