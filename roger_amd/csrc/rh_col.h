@@ -80,12 +80,21 @@ struct StepCtx {
     int cond_time;
     int64_t dt_secs_prelim;
     int64_t itt_day;
+    int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 0: k_select did
 };
 
 // predicate bit positions, word 0 (start of step) and word 1 (after prec/ta selection)
 enum {
     PB_SWE_NOT_LE0 = 0, PB_SWE_GT0, PB_SWETOP_NOT_LE0, PB_SWETOP_GT0, PB_P_NOT_LE0, PB_P_GT0, PB_P_GT_HPI,
     PB_P_NOT_LE_HPI, PB_TA_NOT_GT, PB_TA_GT, PB_PGT0_TALE, PB_NOT_PLE0_TALE
+};
+// Summary bits a column contributes at the END of a step (fused kernel epilogue) from which the NEXT step's
+// predicate words 0 and 1 are derived without another pass over the columns (shared forcing): bits 0..3 are
+// word 0's column bits; the *_KEEP / P_* bits are word 1's column terms for a step that keeps prec/ta
+// (sel_p < 0); swe and prec double as next step's swe[taum1] and prec[taum1].
+enum {
+    QB_SWE_NOT_LE0 = 0, QB_SWE_GT0, QB_SWETOP_NOT_LE0, QB_SWETOP_GT0, QB_RAIN_KEEP, QB_SNOWMELT_KEEP, QB_P_NOT_LE0,
+    QB_NOT_PGT0_TALE, QB_P_EQ0, QB_P_NE0
 };
 enum {
     PC_RAIN = 0, PC_SNOWMELT, PC_PREC_NOT_LE0, PC_NOT_PGT0_TALE, PC_SWEM1_GT0, PC_SWE_NOT_LE0, PC_P_EQ0, PC_PM1_NE0,

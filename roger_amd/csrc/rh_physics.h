@@ -585,20 +585,38 @@ RH_DEV void h_inf_finish(Col &c, double mk) {
 }
 
 // calculate_infiltration :2148-2193; X.cond1..5 are the host-side `if cond.any()` branches
-RH_DEV void rt_infiltration(Col &c, const Consts &K, const StepCtx &X) {
+// calculate_infiltration (infiltration.py:2148-2193) in five parts; the fused kernel runs them as separate
+// pipeline stages (each loads the planes it is the first to mention), the per-routine entry point as one call
+RH_DEV int h_inf_substeps(double dt) { return (int)rint(dt / (1.0 / 5)); }  // :513, npx.round = half-to-even
+RH_DEV void rt_inf_events(Col &c, const Consts &K, const StepCtx &X) {
     const double mk = (double)c.maskCatch;
-    const double dt = X.dt;
-    const int substeps = (int)rint(dt / (1.0 / 5));  // :513, npx.round = half-to-even
     if (X.cond1) h_event_start(c, mk);
     if (X.cond2) h_pause_start(c, mk);
     if (X.cond3) h_pause_end(c, mk);
-    if (X.cond5) c.t_event_csum += dt;
-    h_green_ampt(c, dt, mk);
-    h_inf_mat(c, dt, mk);
-    h_inf_mp(c, K, dt, substeps, mk);
-    h_inf_sc(c, K, dt, substeps, mk);
+    if (X.cond5) c.t_event_csum += X.dt;
+}
+RH_DEV void rt_inf_matrix(Col &c, const Consts &K, const StepCtx &X) {
+    const double mk = (double)c.maskCatch;
+    h_green_ampt(c, X.dt, mk);
+    h_inf_mat(c, X.dt, mk);
+}
+RH_DEV void rt_inf_macropores(Col &c, const Consts &K, const StepCtx &X) {
+    h_inf_mp(c, K, X.dt, h_inf_substeps(X.dt), (double)c.maskCatch);
+}
+RH_DEV void rt_inf_cracks(Col &c, const Consts &K, const StepCtx &X) {
+    h_inf_sc(c, K, X.dt, h_inf_substeps(X.dt), (double)c.maskCatch);
+}
+RH_DEV void rt_inf_finish(Col &c, const Consts &K, const StepCtx &X) {
+    const double mk = (double)c.maskCatch;
     h_inf_finish(c, mk);
     if (X.cond4) h_event_end(c, mk);
+}
+RH_DEV void rt_infiltration(Col &c, const Consts &K, const StepCtx &X) {
+    rt_inf_events(c, K, X);
+    rt_inf_matrix(c, K, X);
+    rt_inf_macropores(c, K, X);
+    rt_inf_cracks(c, K, X);
+    rt_inf_finish(c, K, X);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1148,6 +1166,13 @@ RH_DEV void rt_select_prec_ta(Col &c, const StepCtx &X, double prec_v, double ta
         c.ta = ta_v;
     }
 }
+// the same selection inside the fused kernel (summary path, shared forcing: the selected values are uniform)
+RH_DEV void rt_select_prec(Col &c, const StepCtx &X) {
+    if (X.apply_sel && X.sel_p >= 0) {
+        c.prec = X.prec_sel;
+        c.ta = X.ta_sel;
+    }
+}
 // pet/ta for the final step class (cond6..cond11) and the residual PET, :262-376
 RH_DEV void rt_select_pet(Col &c, const StepCtx &X, double pet_v, double ta_v) {
     if (X.sel_w >= 0) {
@@ -1182,6 +1207,7 @@ RH_DEV bool rt_step_core_lateral(Col &c, const Consts &K, const StepCtx &X) {   
     return rt_num_error_lateral(c, K);
 }
 RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
+    rt_select_prec(c, X);
     rt_select_pet(c, X, pet_v, ta_v);
     const bool bad = rt_step_core(c, K, X);
     rt_after_timestep(c);
@@ -1189,6 +1215,7 @@ RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, dou
 }
 // first step of a month: `set_parameters` re-derives the surface parameters (svat.py:115-120)
 RH_DEV bool rt_step_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
+    rt_select_prec(c, X);
     rt_select_pet(c, X, pet_v, ta_v);
     rt_params_surface(c, L, X);
     const bool bad = rt_step_core(c, K, X);
@@ -1196,12 +1223,14 @@ RH_DEV bool rt_step_monthly(Col &c, const Consts &K, const StepCtx &X, const Lut
     return bad;
 }
 RH_DEV bool rt_step_lateral(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
+    rt_select_prec(c, X);
     rt_select_pet(c, X, pet_v, ta_v);
     const bool bad = rt_step_core_lateral(c, K, X);
     rt_after_timestep_oned(c);
     return bad;
 }
 RH_DEV bool rt_step_lateral_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
+    rt_select_prec(c, X);
     rt_select_pet(c, X, pet_v, ta_v);
     rt_params_surface(c, L, X);
     const bool bad = rt_step_core_lateral(c, K, X);

@@ -47,6 +47,10 @@ struct DevState {
     // costs ~100 us per pass: one address sustains ~90 atomics/us)
     unsigned long long bflags[2][RH_PRED_BLOCKS];
     int pred_blocks;               // workgroups launched for k_pred1 / k_select
+    // summary path: one word per wavefront of the fused kernel (QB_* bits of its columns at the end of the step),
+    // OR-reduced by k_ctrl at the start of the next step
+    unsigned long long *sflags;
+    int sflag_blocks;
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
     const double *forc_cell[3];        // per-cell forcing (n, 144) or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
@@ -75,6 +79,8 @@ struct rh_ctx {
     void *series_buf;
     double *mlms_buf;
     bool per_cell;
+    bool summary_valid;   // D->sflags describe the columns as they are in the arena now
+    unsigned long long *sflags_buf;
     int pred_blocks;
     bool forcing_set;
     bool timing;
@@ -111,11 +117,25 @@ RH_DEV void block_or_store(unsigned long long *slot, unsigned long long bits) {
         *slot = b;
     }
 }
+// OR over the wavefront, one plain store per wave: no barrier, so a wave that is done retires at once (the fused
+// kernel's waves finish at different times; a closing barrier would hold their registers until the slowest is done)
+RH_DEV void wave_or_store(unsigned long long *wave_slots, unsigned long long bits) {
+    for (int off = 32; off; off >>= 1) bits |= __shfl_xor(bits, off);
+    if ((threadIdx.x & 63) == 0) wave_slots[threadIdx.x >> 6] = bits;
+}
 // OR-reduce the per-workgroup words (one workgroup of RH_BLOCK threads); result valid in thread 0.
 RH_DEV unsigned long long reduce_bflags(const unsigned long long *bf, int nblk) {
     __shared__ unsigned long long wv[RH_BLOCK / 64];
     unsigned long long b = 0;
-    for (int k = threadIdx.x; k < nblk; k += RH_BLOCK) b |= bf[k];
+    // eight independent loads in flight per thread: a single workgroup reading tens of thousands of words one
+    // dependent load at a time is latency-bound (25 us for 15 000 words)
+    int k = threadIdx.x;
+    for (; k + 7 * RH_BLOCK < nblk; k += 8 * RH_BLOCK) {
+        const unsigned long long v0 = bf[k], v1 = bf[k + RH_BLOCK], v2 = bf[k + 2 * RH_BLOCK], v3 = bf[k + 3 * RH_BLOCK];
+        const unsigned long long v4 = bf[k + 4 * RH_BLOCK], v5 = bf[k + 5 * RH_BLOCK], v6 = bf[k + 6 * RH_BLOCK], v7 = bf[k + 7 * RH_BLOCK];
+        b |= ((v0 | v1) | (v2 | v3)) | ((v4 | v5) | (v6 | v7));
+    }
+    for (; k < nblk; k += RH_BLOCK) b |= bf[k];
     for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
     if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = b;
     __syncthreads();
@@ -237,25 +257,28 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
     block_or_store(&D->bflags[0][blockIdx.x], b);
 }
 
-// word 0 = OR of the workgroup words of k_pred1 and the predicates of the shared forcing series
-RH_DEV void finish_word0(DevState *D) {
+// word 0 = OR of the workgroup words of k_pred1 (or, summary path, of the fused kernel's summary words: their
+// bits 0..3 are word 0's column bits) and the predicates of the shared forcing series.  Returns the OR of the
+// workgroup words in thread 0.
+RH_DEV unsigned long long finish_word0(DevState *D, const unsigned long long *flags, int nflags, unsigned long long cell_mask) {
     unsigned long long fb = 0;
     if (!D->per_cell && threadIdx.x < RH_SLOTS_PER_DAY) fb = forcing_bits(D->forc[0][threadIdx.x], D->forc[1][threadIdx.x], D->K);
     __shared__ unsigned long long fw[RH_BLOCK / 64];
     for (int off = 32; off; off >>= 1) fb |= __shfl_xor(fb, off);
     if ((threadIdx.x & 63) == 0) fw[threadIdx.x >> 6] = fb;
-    const unsigned long long cells = reduce_bflags(D->bflags[0], D->pred_blocks);  // contains __syncthreads
+    const unsigned long long cells = reduce_bflags(flags, nflags);  // contains __syncthreads
     if (threadIdx.x == 0) {
-        unsigned long long w = cells;
+        unsigned long long w = cells & cell_mask;
         for (int k = 0; k < RH_BLOCK / 64; ++k) w |= fw[k];
         D->words[0] = w;
     }
     __threadfence();
     __syncthreads();
+    return cells;
 }
 __global__ __launch_bounds__(RH_BLOCK) void k_reduce(DevState *D, int which) {
     if (which == 0) {
-        finish_word0(D);
+        finish_word0(D, D->bflags[0], D->pred_blocks, ~0ull);
     } else {
         const unsigned long long w = reduce_bflags(D->bflags[1], D->pred_blocks);
         if (threadIdx.x == 0) D->words[1] = w;
@@ -269,9 +292,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_reduce(DevState *D, int which) {
 // Lane j of a 16-lane group owns one r_j; six groups = six sums.
 RH_DEV double np_tree8(const double *r) { return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])); }
 
-__global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int do_reduce) {
-    if (do_hooks) hooks_set_forcing(D);   // rh_run_steps: the user hooks ride along
-    if (do_reduce) finish_word0(D);       // single GPU: no exchange between k_pred1 and here
+RH_DEV void agg_body(DevState *D) {
     __shared__ double f[3][RH_SLOTS_PER_DAY];   // prec, ta, pet of the day
     __shared__ double part[6][16];
     const int tid = threadIdx.x;
@@ -349,6 +370,11 @@ __global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int
         }
     }
 }
+__global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int do_reduce) {
+    if (do_hooks) hooks_set_forcing(D);   // rh_run_steps: the user hooks ride along
+    if (do_reduce) finish_word0(D, D->bflags[0], D->pred_blocks, ~0ull);  // single GPU: no exchange between k_pred1 and here
+    agg_body(D);
+}
 
 // Per-cell forcing only: aggregates of every column's own 144-slot series, once per step, into
 // nine SoA planes (so the per-column kernels stay free of the 144-element loops).
@@ -411,13 +437,19 @@ RH_DEV void infiltration_conds(DevState *D, unsigned long long w) {
 }
 
 // adaptive_time_stepping.py:192-373, scalar part
+RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel);
 __global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce, int do_finish) {
     unsigned long long w = 0;
     if (do_reduce) w = reduce_bflags(D->bflags[1], D->pred_blocks);
     if (threadIdx.x != 0) return;
     if (!do_reduce) w = D->words[1];
+    scalars_body(D, w, do_finish, 0);
+}
+// one thread
+RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel) {
     rh_scalars &S = D->S;
     StepCtx &X = D->X;
+    X.apply_sel = apply_sel;
     const bool ev_start = bit(w, PC_RAIN) || bit(w, PC_SNOWMELT);
     const bool ev_end = !bit(w, PC_PREC_NOT_LE0) || !bit(w, PC_NOT_PGT0_TALE) || (bit(w, PC_SWEM1_GT0) && !bit(w, PC_SWE_NOT_LE0));
     int64_t dts = X.dt_secs_prelim;
@@ -465,6 +497,104 @@ __global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce
     }
 }
 
+// ---- summary path (shared forcing): the whole control part of a step in ONE single-workgroup kernel ----------
+// Word 1 of this step from the summary bits the fused kernel left at the end of the previous step and the
+// (uniform) selected prec / ta; same terms as k_select evaluates per column.
+RH_DEV unsigned long long derive_word1(unsigned long long s, const StepCtx &X, const Consts &K) {
+    unsigned long long w = 0;
+    if (X.sel_p >= 0) {
+        const double P = X.prec_sel, T = X.ta_sel;
+        const bool warm = T > K.ta_fm;
+        w |= ((P > 0) && warm) ? BIT(PC_RAIN) : 0;
+        w |= ((bit(s, QB_SWE_GT0) || bit(s, QB_SWETOP_GT0)) && warm) ? BIT(PC_SNOWMELT) : 0;
+        w |= !(P <= 0) ? BIT(PC_PREC_NOT_LE0) : 0;
+        w |= !((P > 0) && (T <= K.ta_fm)) ? BIT(PC_NOT_PGT0_TALE) : 0;
+        w |= (P == 0) ? BIT(PC_P_EQ0) : 0;
+        w |= (P != 0) ? BIT(PC_P_NE0) : 0;
+    } else {
+        w |= bit(s, QB_RAIN_KEEP) ? BIT(PC_RAIN) : 0;
+        w |= bit(s, QB_SNOWMELT_KEEP) ? BIT(PC_SNOWMELT) : 0;
+        w |= bit(s, QB_P_NOT_LE0) ? BIT(PC_PREC_NOT_LE0) : 0;
+        w |= bit(s, QB_NOT_PGT0_TALE) ? BIT(PC_NOT_PGT0_TALE) : 0;
+        w |= bit(s, QB_P_EQ0) ? BIT(PC_P_EQ0) : 0;
+        w |= bit(s, QB_P_NE0) ? BIT(PC_P_NE0) : 0;
+    }
+    w |= bit(s, QB_SWE_GT0) ? BIT(PC_SWEM1_GT0) : 0;       // swe[taum1] of this step = swe the last step left
+    w |= bit(s, QB_SWE_NOT_LE0) ? BIT(PC_SWE_NOT_LE0) : 0;
+    w |= bit(s, QB_P_NE0) ? BIT(PC_PM1_NE0) : 0;           // prec[taum1] likewise
+    w |= bit(s, QB_P_EQ0) ? BIT(PC_PM1_EQ0) : 0;
+    return w;
+}
+// Summary bits of one column (values as they stand in the arena at the start of the next step), in two halves
+// so that the fused kernel can sample prec / ta and swe / swe_top where each pair is final: the prec/ta half
+// (bit 63 carries `warm` to the second half), then the snow half.
+#define QB_WARM_TMP 63
+RH_DEV unsigned long long summary_bits_pt(double prec, double ta, const Consts &K) {
+    unsigned long long b = 0;
+    const bool warm = ta > K.ta_fm;
+    b |= warm ? BIT(QB_WARM_TMP) : 0;
+    b |= ((prec > 0) && warm) ? BIT(QB_RAIN_KEEP) : 0;
+    b |= !(prec <= 0) ? BIT(QB_P_NOT_LE0) : 0;
+    b |= !((prec > 0) && (ta <= K.ta_fm)) ? BIT(QB_NOT_PGT0_TALE) : 0;
+    b |= (prec == 0) ? BIT(QB_P_EQ0) : 0;
+    b |= (prec != 0) ? BIT(QB_P_NE0) : 0;
+    return b;
+}
+RH_DEV unsigned long long summary_bits_sw(unsigned long long b, double swe, double swe_top) {
+    const bool warm = bit(b, QB_WARM_TMP);
+    b &= ~BIT(QB_WARM_TMP);
+    b |= !(swe <= 0) ? BIT(QB_SWE_NOT_LE0) : 0;
+    b |= (swe > 0) ? BIT(QB_SWE_GT0) : 0;
+    b |= !(swe_top <= 0) ? BIT(QB_SWETOP_NOT_LE0) : 0;
+    b |= (swe_top > 0) ? BIT(QB_SWETOP_GT0) : 0;
+    b |= (((swe > 0) || (swe_top > 0)) && warm) ? BIT(QB_SNOWMELT_KEEP) : 0;
+    return b;
+}
+RH_DEV unsigned long long summary_bits(double swe, double swe_top, double prec, double ta, const Consts &K) {
+    return summary_bits_sw(summary_bits_pt(prec, ta, K), swe, swe_top);
+}
+// from_word3 != 0: the summary was reduced (and exchanged between ranks) before, it sits in words[3]
+__global__ __launch_bounds__(RH_BLOCK) void k_ctrl(DevState *D, int do_hooks, int from_word3) {
+    if (do_hooks) hooks_set_forcing(D);
+    __shared__ unsigned long long s_sum;
+    unsigned long long cells;
+    if (from_word3) {
+        if (threadIdx.x == 0) D->bflags[0][0] = D->words[3];
+        __threadfence();
+        __syncthreads();
+        cells = finish_word0(D, D->bflags[0], 1, 0xFull);
+    } else {
+        cells = finish_word0(D, D->sflags, D->sflag_blocks, 0xFull);
+    }
+    if (threadIdx.x == 0) s_sum = cells;
+    __syncthreads();
+    agg_body(D);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) scalars_body(D, derive_word1(s_sum, D->X, D->K), 1, 1);
+}
+// summary words straight from the arena (first step, or after the host changed planes); same workgroup -> column
+// mapping as the fused kernel
+__global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    unsigned long long b = 0;
+    if (i < a.n) {
+        double swe, swe_top, prec, ta;
+        rh_ld(a, RH_P_swe, i, swe);
+        rh_ld(a, RH_P_swe_top, i, swe_top);
+        rh_ld(a, RH_P_prec, i, prec);
+        rh_ld(a, RH_P_ta, i, ta);
+        b = summary_bits(swe, swe_top, prec, ta, D->K);
+    }
+    wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], b);
+}
+// multi-GPU: OR of the summary words into words[3] for the exchange
+__global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks) {
+    if (do_hooks) hooks_set_forcing(D);
+    const unsigned long long w = reduce_bflags(D->sflags, D->sflag_blocks);
+    if (threadIdx.x == 0) D->words[3] = w;
+}
+
 __global__ void k_advance(DevState *D) {  // roger.py:449-450
     D->S.itt += 1;
     D->S.time += D->S.dt_secs;
@@ -509,17 +639,28 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 #define RH_STORES(seq, rt) RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)
 #if RH_STEP_PREFETCH
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
-    RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)                                \
+    RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)  \
+    rt_select_prec(c, X); RH_STORES(seq, rt_select_prec)                                                 \
     rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
+    q = summary_bits_pt(c.prec, c.ta, K);                                                                \
     MON_RUN                                                                                              \
     RH_LOADS(seq, rt_evapotranspiration)                                                                 \
     rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
     RH_LOADS(seq, rt_snow)                                                                               \
     rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)                                   \
-    RH_LOADS(seq, rt_infiltration)                                                                       \
+    RH_LOADS(seq, rt_inf_events)                                                                         \
     rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
+    q = summary_bits_sw(q, c.swe, c.swe_top);                                                            \
+    RH_LOADS(seq, rt_inf_matrix)                                                                         \
+    rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
+    RH_LOADS(seq, rt_inf_macropores)                                                                     \
+    rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                                                \
+    RH_LOADS(seq, rt_inf_cracks)                                                                         \
+    rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)                                        \
+    RH_LOADS(seq, rt_inf_finish)                                                                         \
+    rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
     RH_LOADS(seq, sub_rt)                                                                                \
-    rt_infiltration(c, K, X); RH_STORES(seq, rt_infiltration)                                            \
+    rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
     RH_LOADS(seq, rt_capillary_rise)                                                                     \
     sub_call; RH_STORES(seq, sub_rt)                                                                     \
     RH_LOADS(seq, rt_storage)                                                                            \
@@ -531,13 +672,32 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     at_call; RH_STORES(seq, at_rt)
 #else
 #define RH_STAGE(seq, rt, call) RH_LOADS(seq, rt) call; RH_STORES(seq, rt)
+#ifdef RH_NO_SELSTAGE  // timing experiments only
+#define RH_DBG_SEL(x)
+#else
+#define RH_DBG_SEL(x) x
+#endif
+#ifdef RH_NO_SUMMARY
+#define RH_DBG_SUM(x)
+#else
+#define RH_DBG_SUM(x) x
+#endif
+// q_pt / q_sw: the column's summary values for the next step's predicates, sampled where they are final
+// (tools/gen_sets.py asserts that no later stage assigns them)
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
+    RH_DBG_SEL(RH_STAGE(seq, rt_select_prec, rt_select_prec(c, X)))                                      \
     RH_STAGE(seq, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))                                       \
+    RH_DBG_SUM(q = summary_bits_pt(c.prec, c.ta, K);)                                                    \
     MON_LOADS MON_RUN                                                                                    \
     RH_STAGE(seq, rt_interception, rt_interception(c, K))                                                \
     RH_STAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                    \
     RH_STAGE(seq, rt_snow, rt_snow(c, K, X))                                                             \
-    RH_STAGE(seq, rt_infiltration, rt_infiltration(c, K, X))                                             \
+    RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top);)                                                \
+    RH_STAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                 \
+    RH_STAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                 \
+    RH_STAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                         \
+    RH_STAGE(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                                 \
+    RH_STAGE(seq, rt_inf_finish, rt_inf_finish(c, K, X))                                                 \
     RH_STAGE(seq, sub_rt, sub_call)                                                                      \
     RH_STAGE(seq, rt_capillary_rise, rt_capillary_rise(c, X))                                            \
     RH_STAGE(seq, rt_storage, rt_storage(c, X))                                                          \
@@ -550,11 +710,12 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     // device-driven stepping launches both variants; the one that does not apply exits at once
     if (guarded && (D->monthly != 0) != MONTHLY) return;
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    if (i >= a.n) return;
+    unsigned long long q = 0;   // summary bits of this column for the next step's predicates
+    bool bad = false;
+    if (i < a.n) {
     const Consts K = D->K;
     const StepCtx X = D->X;
     Col c;
-    bool bad = false;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     if (D->per_cell && X.sel_w >= 0) {
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
@@ -576,7 +737,9 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
         RH_STEP_BODY(step, , , , rt_subsurface_runoff, rt_subsurface_runoff(c, X), rt_num_error, rt_num_error(c, K),
                      rt_after_timestep, rt_after_timestep(c))
     }
+    }
     if (bad) atomicOr(&D->words[2], 1ull);
+    wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], q);
 }
 
 #define RH_CELL_KERNEL(kname, rt, call)                                       \
@@ -726,7 +889,12 @@ static int fail(rh_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RH_BLOCK - 1) / RH_BLOCK); }
-#define LAUNCH_CELLS(ctx, kern) hipLaunchKernelGGL(kern, dim3(grid_for((ctx)->n)), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev)
+// any per-column kernel other than the fused step may change what the summary words describe
+#define LAUNCH_CELLS(ctx, kern)                                                                                          \
+    do {                                                                                                                 \
+        (ctx)->summary_valid = false;                                                                                    \
+        hipLaunchKernelGGL(kern, dim3(grid_for((ctx)->n)), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
+    } while (0)
 #define LAUNCH_ONE(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, (ctx)->stream, __VA_ARGS__)
 #define LAUNCH_WG(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(RH_BLOCK), 0, (ctx)->stream, __VA_ARGS__)
 #define CHECK_LAUNCH(ctx) HIPCHK(ctx, hipGetLastError())
@@ -799,6 +967,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->agg_cell_buf = nullptr;
     ctx->series_buf = nullptr;
     ctx->mlms_buf = nullptr;
+    ctx->sflags_buf = nullptr;
     ctx->per_cell = false;
     const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256;
     ctx->arena.stride = stride;
@@ -838,6 +1007,15 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     if ((e = hipMemcpyAsync(&ctx->dev->S, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(scalars)");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // K, S are stack locals
+    {
+        const int nb = (int)grid_for(ctx->n) * (RH_BLOCK / 64);
+        if ((e = hipMalloc((void **)&ctx->sflags_buf, (size_t)nb * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(sflags)");
+        if ((e = hipMemsetAsync(ctx->sflags_buf, 0, (size_t)nb * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+        if ((e = hipMemcpyAsync(&ctx->dev->sflags, &ctx->sflags_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return bail(e, "hipMemcpy(sflags)");
+        if ((e = hipMemcpyAsync(&ctx->dev->sflag_blocks, &nb, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return bail(e, "hipMemcpy(sflag_blocks)");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // nb is a stack local
+    }
+    ctx->summary_valid = false;
     ctx->pred_blocks = (int)(grid_for(ctx->n) < RH_PRED_BLOCKS ? grid_for(ctx->n) : RH_PRED_BLOCKS);
     if ((e = hipMemcpyAsync(&ctx->dev->pred_blocks, &ctx->pred_blocks, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(pred_blocks)");
@@ -859,6 +1037,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->agg_cell_buf) (void)hipFree(ctx->agg_cell_buf);
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
     if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
+    if (ctx->sflags_buf) (void)hipFree(ctx->sflags_buf);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -896,6 +1075,7 @@ int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes) {
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_upload: null host pointer");
     HIPCHK(ctx, hipMemcpyAsync(ctx->arena.base + (size_t)plane * ctx->arena.stride, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be a temporary
+    ctx->summary_valid = false;
     return RH_OK;
 }
 
@@ -911,6 +1091,7 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
 
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
     if (!ctx || plane < 0 || plane >= RH_NPLANES) return nullptr;
+    ctx->summary_valid = false;  // the caller may write through the pointer
     return ctx->arena.base + (size_t)plane * ctx->arena.stride;
 }
 
@@ -1065,7 +1246,11 @@ int rh_after_timestep(rh_ctx *ctx) {
     return RH_OK;
 }
 
-#define LAUNCH_PRED(ctx, kern) hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev)
+#define LAUNCH_PRED(ctx, kern)                                                                                           \
+    do {                                                                                                                 \
+        (ctx)->summary_valid = false;                                                                                    \
+        hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
+    } while (0)
 
 static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
     if (ctx->timing) {
@@ -1098,6 +1283,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used + 1], ctx->stream));
         ctx->ev_used += 2;
     }
+    ctx->summary_valid = true;  // the fused kernel leaves the summary words of the state it wrote
     return RH_OK;
 }
 
@@ -1116,6 +1302,7 @@ int rh_step_phase2(rh_ctx *ctx) {
     LAUNCH_PRED(ctx, k_select);
     LAUNCH_WG(ctx, k_reduce, ctx->dev, 1);
     CHECK_LAUNCH(ctx);
+    ctx->summary_valid = false;  // k_select rewrote prec / ta
     return RH_OK;
 }
 int rh_step_phase3(rh_ctx *ctx, int monthly) {
@@ -1129,6 +1316,15 @@ int rh_step_phase3(rh_ctx *ctx, int monthly) {
 // single GPU: the same step with the reductions folded into the single-workgroup kernels
 static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
+    if (!ctx->per_cell) {
+        // summary path: the previous fused kernel left what the predicates need; one control kernel, one fused kernel
+        if (!ctx->summary_valid) LAUNCH_CELLS(ctx, k_summary);
+        LAUNCH_WG(ctx, k_ctrl, ctx->dev, hooks, 0);
+        int rc = launch_fused_kernel(ctx, monthly);
+        if (rc) return rc;
+        CHECK_LAUNCH(ctx);
+        return RH_OK;
+    }
     LAUNCH_PRED(ctx, k_pred1);
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
     if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
@@ -1214,6 +1410,7 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) 
         return RH_ERR_ARG;
     for (int p = 0; p < nplanes; ++p)
         if (PLANE_IS_INT[src_plane0 + p] || PLANE_IS_INT[dst_plane0 + p]) return fail(ctx, RH_ERR_ARG, "calibration planes must be float64");
+    ctx->summary_valid = false;
     hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
     return RH_OK;

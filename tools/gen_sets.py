@@ -134,18 +134,21 @@ def analyse(funcs):
 #                X_m1 any more.  The copy is a store of the register holding X into the X_m1 plane, so X's
 #                live range ends here instead of at the end of the kernel (the 30 rotated values were the
 #                kernel's spills).  X_m1 then leaves the after_timestep stage's store set.
-_COMMON_HEAD = ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_infiltration"]
+_COMMON_HEAD = ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_inf_events", "rt_inf_matrix", "rt_inf_macropores",
+                "rt_inf_cracks", "rt_inf_finish"]
 SEQUENCES = {
-    "step": ["rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff", "rt_capillary_rise", "rt_storage",
+    "step": ["rt_select_prec", "rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff", "rt_capillary_rise", "rt_storage",
                                                 "rt_num_error", "rt_after_timestep"],
-    "step_monthly": ["rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
+    "step_monthly": ["rt_select_prec", "rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
         "rt_subsurface_runoff", "rt_capillary_rise", "rt_storage", "rt_num_error", "rt_after_timestep"],
-    "step_lateral": ["rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff_lateral", "rt_capillary_rise",
+    "step_lateral": ["rt_select_prec", "rt_select_pet"] + _COMMON_HEAD + ["rt_subsurface_runoff_lateral", "rt_capillary_rise",
                                                         "rt_storage", "rt_num_error_lateral", "rt_after_timestep_oned"],
-    "step_lateral_monthly": ["rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
+    "step_lateral_monthly": ["rt_select_prec", "rt_select_pet", "rt_params_surface"] + _COMMON_HEAD + [
         "rt_subsurface_runoff_lateral", "rt_capillary_rise", "rt_storage", "rt_num_error_lateral",
         "rt_after_timestep_oned"],
 }
+# stages before which long-lived, momentarily unused planes are evicted from registers (see main())
+EVICT_BEFORE = set(filter(None, os.environ.get("RH_EVICT", "").split(",")))
 # each sequence must cover exactly what the corresponding single-function routine does
 SEQUENCE_CHECK = {"step": "rt_step", "step_monthly": "rt_step_monthly", "step_lateral": "rt_step_lateral",
                   "step_lateral_monthly": "rt_step_lateral_monthly"}
@@ -191,18 +194,43 @@ def main():
             first = next((i for i, rt in enumerate(stages) if x in sets[rt][0]), last)
             rot_at[(xm1, x)] = max(r, first)
         moved = {xm1 for (xm1, x), r in rot_at.items() if r < last}
+        rot_need = {}   # stage -> fields whose register value the ROT of that stage stores
+        for (xm1, x), r in rot_at.items():
+            if r < last:
+                rot_need.setdefault(r, set()).add(x)
+        # Eviction before the register-heavy stages (EVICT_BEFORE): a plane that is resident, not touched by the
+        # heavy stage and needed again later is dropped (stored first if its register holds a value memory does
+        # not have yet) and re-loaded at its next mention.  Costs 8 bytes of traffic per plane and column, frees
+        # two VGPRs through the stage where the compiler would otherwise spill.
+        recs, dirty = [], set()
         for i, rt in enumerate(stages):
             mention, write = sets[rt]
+            need = mention | rot_need.get(i, set())
+            if rt in EVICT_BEFORE and i > 0:
+                later = set().union(*[sets[r][0] | rot_need.get(j, set())
+                                      for j, r in enumerate(stages) if j > i])
+                ev = {f for f in resident if f not in need and f in later}
+                recs[-1]["st"] |= ev & dirty
+                dirty -= ev
+                resident -= ev
             later_w = set().union(*[sets[r][1] for r in stages[i + 1:]]) if i + 1 < len(stages) else set()
-            ld = sorted(mention - resident, key=order.get)
-            st = sorted((write - later_w) - (moved if i == last else set()), key=order.get)
-            rot = sorted([x for (xm1, x), r in rot_at.items() if r == i and i < last], key=order.get)
-            lines.append(f"#define RH_SEQ_{seq}_ROT_{rt}(X) " + " ".join(f"X({n})" for n in rot))
-            resident |= mention
+            ld = need - resident
+            st = (write - later_w) - (moved if i == last else set())
+            resident |= need
+            dirty = (dirty | write) - st
             all_m |= mention
             all_w |= write
-            lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in ld))
-            lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in st))
+            recs.append(dict(rt=rt, ld=ld, st=set(st), rot=rot_need.get(i, set())))
+        for rec in recs:
+            rt = rec["rt"]
+            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st")):
+                lines.append(f"#define RH_SEQ_{seq}_{kind}_{rt}(X) " + " ".join(f"X({n})" for n in sorted(rec[key], key=order.get)))
+        # the fused kernel samples the summary bits of the next step's predicates (roger_hip.hip, k_step): prec and ta
+        # after rt_select_pet, swe and swe_top after rt_snow -- nothing later may assign them
+        for fld, after in (("prec", "rt_select_pet"), ("ta", "rt_select_pet"), ("swe", "rt_snow"), ("swe_top", "rt_snow")):
+            late = [rt for rt in stages[stages.index(after) + 1:] if fld in sets[rt][1]]
+            if late:
+                sys.exit(f"sequence {seq}: {fld} is assigned after {after} by {late}; move the summary sampling")
         ref_m, ref_w = sets[SEQUENCE_CHECK[seq]]
         if all_m != ref_m or all_w != ref_w:
             sys.exit(f"sequence {seq} does not match {SEQUENCE_CHECK[seq]}")
