@@ -168,6 +168,17 @@ int rh_step_phase1(rh_ctx *ctx);
 int rh_step_phase2(rh_ctx *ctx);
 int rh_step_phase3(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-side month-change flag */
 int rh_svat_step(rh_ctx *ctx, int monthly);
+/* The same step with ONE exchange (shared forcing only).  The fused kernel leaves, per wavefront, a summary word of
+ * its columns' end-of-step state from which both predicate words of the next step follow (the start-of-step snow
+ * predicates directly; the event predicates together with the selected prec / ta, which are uniform when the
+ * forcing is shared):
+ *   rh_step_summary: [device-side hooks if a forcing series is set,] OR of the summary words -> words[3]
+ *                    (after a host-side change of the planes the summary is rebuilt from the arena first)
+ *   -- all-reduce words[3] over the ranks (rh_predicates_expand / _compress with word = 3) --
+ *   rh_step_finish:  control kernel (dt, selection, event bookkeeping) + the fused per-cell kernel
+ * rh_run_steps and rh_svat_step use this path without the exchange.  Returns RH_ERR_STATE with per-cell forcing. */
+int rh_step_summary(rh_ctx *ctx);
+int rh_step_finish(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-side month-change flag */
 /* Device-side `set_forcing` + `set_parameters` hooks (needs rh_set_forcing_series); runs before
  * phase 1. */
 int rh_hooks_phase(rh_ctx *ctx);

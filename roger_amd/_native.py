@@ -40,6 +40,7 @@ _ENTRY_POINTS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
     "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core", "rh_params_lateral",
+    "rh_step_summary",
 )
 
 
@@ -88,6 +89,7 @@ def load():
     for name in _ENTRY_POINTS:
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
+    lib.rh_step_finish.argtypes = [vp, i32]
     lib.rh_svat_step.argtypes = [vp, i32]
     lib.rh_run_steps.argtypes = [vp, i64]
     lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
@@ -287,6 +289,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
+    "rh_step_summary", "rh_step_finish",
 )
 
 
@@ -408,6 +411,9 @@ class Context:
     def step_phase3(self, monthly=False):
         # monthly: False/True, or -1 to use the month-change flag computed on the device
         self._check(self._lib.rh_step_phase3(self._h, int(monthly)), "rh_step_phase3")
+
+    def step_finish(self, monthly=-1):
+        self._check(self._lib.rh_step_finish(self._h, int(monthly)), "rh_step_finish")
 
     def sync(self):
         self.call("rh_sync")

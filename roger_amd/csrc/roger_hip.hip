@@ -1335,6 +1335,27 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
+int rh_step_summary(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
+    if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_summary: the summary path needs forcing shared by all columns; use rh_step_phase1/2/3");
+    if (!ctx->summary_valid) {
+        LAUNCH_CELLS(ctx, k_summary);
+        ctx->summary_valid = true;
+    }
+    LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+int rh_step_finish(rh_ctx *ctx, int monthly) {
+    if (!ctx) return RH_ERR_ARG;
+    if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_finish: the summary path needs forcing shared by all columns");
+    LAUNCH_WG(ctx, k_ctrl, ctx->dev, 0, 1);
+    int rc = launch_fused_kernel(ctx, monthly);
+    if (rc) return rc;
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
 int rh_svat_step(rh_ctx *ctx, int monthly) {
     if (!ctx) return RH_ERR_ARG;
     return step_fused_launches(ctx, monthly, 0);

@@ -57,21 +57,30 @@ class PhasedStepper:
     (HipPhases below) and the CPU test double used by the gloo tests both provide them.
     """
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, always_exchange=False):
         self.backend = backend
         self.group = group
+        self.always_exchange = always_exchange   # tests: go through the exchange buffers also with one rank
 
     def _exchange(self, word):
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not (multi or self.always_exchange):
             return  # single rank: the local predicate words already are the global ones
         buf = self.backend.predicate_buffer(word)
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+        if multi:
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
         self.backend.load_predicates(word, buf)
 
     def step(self):
         b = self.backend
+        if getattr(b, "one_exchange", False):
+            # summary path (shared forcing): both predicate words follow from one summary word, include/roger_hip.h
+            b.summary_phase()
+            self._exchange(3)
+            b.finish_phase()
+            return
         b.hooks_phase()
         b.phase1()
         self._exchange(0)
@@ -89,12 +98,19 @@ class HipPhases:
     the context's device and all launches go to torch's current stream so that the RCCL
     all-reduce is stream-ordered with the kernels."""
 
-    def __init__(self, ctx, device):
+    def __init__(self, ctx, device, one_exchange=True):
         import torch
 
         self.ctx = ctx
-        self.buf = [torch.zeros(64, dtype=torch.int32, device=device) for _ in range(2)]
+        self.one_exchange = one_exchange   # False: the three-phase protocol (needed with per-cell forcing)
+        self.buf = {w: torch.zeros(64, dtype=torch.int32, device=device) for w in (0, 1, 3)}
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def summary_phase(self):
+        self.ctx.call("rh_step_summary")   # device-side hooks included
+
+    def finish_phase(self):
+        self.ctx.step_finish(-1)
 
     def hooks_phase(self):
         self.ctx.call("rh_hooks_phase")

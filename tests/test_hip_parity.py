@@ -284,13 +284,17 @@ def test_phased_stepper_single_rank(native):
     from roger_amd.distributed import HipPhases, PhasedStepper
 
     g, names, forcing = load_case("svat_hetero_combo")
-    a, b = _ctx(native, g, names), _ctx(native, g, names)
-    a.set_forcing_series(forcing)
-    b.set_forcing_series(forcing)
+    a, b, c = _ctx(native, g, names), _ctx(native, g, names), _ctx(native, g, names)
+    for ctx in (a, b, c):
+        ctx.set_forcing_series(forcing)
+    dev = torch.device("cuda", 0)
     a.run_steps(120)
-    PhasedStepper(HipPhases(b, torch.device("cuda", 0))).run(120)
+    # always_exchange: spread / fold the predicate words through the exchange buffers although there is no peer
+    PhasedStepper(HipPhases(b, dev), always_exchange=True).run(120)                       # one exchange per step
+    PhasedStepper(HipPhases(c, dev, one_exchange=False), always_exchange=True).run(120)   # three-phase protocol
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(H.scalars_to_row(a.get_scalars()), H.scalars_to_row(b.get_scalars()))
-    np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(b, names))
-    a.close()
-    b.close()
+    for other in (b, c):
+        np.testing.assert_array_equal(H.scalars_to_row(a.get_scalars()), H.scalars_to_row(other.get_scalars()))
+        np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(other, names))
+    for ctx in (a, b, c):
+        ctx.close()
