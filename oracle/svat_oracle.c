@@ -176,6 +176,13 @@ static adt_sel adt_select_flags(uint64_t w, const oc_scalars *s) {
     return r;
 }
 
+/* which prec/ta selection wins for predicate word 0 (the last one applied, lines 128-189): -1 none, 0 daily,
+ * 1 hourly, 2 ten minutes -- for test doubles that derive word 1 from summary bits */
+int oc_adt_sel_p(uint64_t word0, const oc_scalars *s) {
+    adt_sel f = adt_select_flags(word0, s);
+    return f.sel_10min ? 2 : (f.sel_hourly ? 1 : (f.sel_daily ? 0 : -1));
+}
+
 /* per-cell aggregates {prec, ta, pet} x {daily, hourly, 10 min}, lines 384-437 */
 static double *adt_aggregates(int64_t n, const double *prec_day, const double *ta_day, const double *pet_day,
                               int64_t fstride, int64_t itd) {

@@ -35,7 +35,7 @@ class OracleContext:
         self.day = None
         self.series = None
         self.monthly = False
-        self.words = [0, 0]
+        self.words = [0, 0, 0, 0]
 
     def close(self):
         pass
@@ -162,6 +162,52 @@ class OracleContext:
         self.phase2()
         self.step_phase3(monthly)
 
+    # one-exchange step (summary protocol of include/roger_hip.h: rh_step_summary / rh_step_finish)
+    QB = dict(SWE_NOT_LE0=0, SWE_GT0=1, SWETOP_NOT_LE0=2, SWETOP_GT0=3, RAIN_KEEP=4, SNOWMELT_KEEP=5, P_NOT_LE0=6,
+              NOT_PGT0_TALE=7, P_EQ0=8, P_NE0=9)
+
+    def summary_word(self):
+        """OR over the local columns of the summary bits (what the fused kernel's waves store at the end of a step)."""
+        P, ta_fm = self.st.planes, self.st.settings.ta_fm
+        swe, top, prec, ta = P["swe"], P["swe_top"], P["prec"], P["ta"]
+        warm = ta > ta_fm
+        terms = dict(SWE_NOT_LE0=~(swe <= 0), SWE_GT0=swe > 0, SWETOP_NOT_LE0=~(top <= 0), SWETOP_GT0=top > 0,
+                     RAIN_KEEP=(prec > 0) & warm, SNOWMELT_KEEP=((swe > 0) | (top > 0)) & warm, P_NOT_LE0=~(prec <= 0),
+                     NOT_PGT0_TALE=~((prec > 0) & (ta <= ta_fm)), P_EQ0=prec == 0, P_NE0=prec != 0)
+        return sum(int(np.any(v)) << self.QB[k] for k, v in terms.items())
+
+    def finish_from_summary(self, s_word, monthly=-1):
+        """Both predicate words from the (global) summary word, then the rest of the step.  Returns (word0, word1,
+        locally evaluated word1) so that single-domain tests can check the derivation against the direct evaluation."""
+        L = ob.lib()
+        L.oc_adt_pred1.restype = C.c_uint64
+        L.oc_adt_select.restype = C.c_uint64
+        f = self._forc()
+        w0 = (s_word & 0xF) | int(L.oc_adt_pred1(self.st._ptrs, C.c_int64(0), f[0], f[1], f[3], C.byref(self.st.settings)))
+        sel = int(L.oc_adt_sel_p(C.c_uint64(w0), C.byref(self.st.scal)))
+        w1_local = int(L.oc_adt_select(self.st._ptrs, C.c_int64(self.n), *f, C.byref(self.st.scal),
+                                       C.byref(self.st.settings), C.c_uint64(w0)))   # applies the selection to the columns
+        b = lambda name: (s_word >> self.QB[name]) & 1  # noqa: E731
+        w1 = 0
+        if sel >= 0:
+            Pv, Tv, ta_fm = float(self.st.planes["prec"][0]), float(self.st.planes["ta"][0]), self.st.settings.ta_fm
+            warm = Tv > ta_fm
+            w1 |= int((Pv > 0) and warm) << 0
+            w1 |= int((b("SWE_GT0") or b("SWETOP_GT0")) and warm) << 1
+            w1 |= int(not (Pv <= 0)) << 2
+            w1 |= int(not ((Pv > 0) and (Tv <= ta_fm))) << 3
+            w1 |= int(Pv == 0) << 6
+            w1 |= int(Pv != 0) << 8
+        else:
+            w1 |= b("RAIN_KEEP") << 0 | b("SNOWMELT_KEEP") << 1 | b("P_NOT_LE0") << 2 | b("NOT_PGT0_TALE") << 3
+            w1 |= b("P_EQ0") << 6 | b("P_NE0") << 8
+        w1 |= b("SWE_GT0") << 4 | b("SWE_NOT_LE0") << 5 | b("P_NE0") << 7 | b("P_EQ0") << 9
+        m = self.monthly if int(monthly) < 0 else bool(monthly)
+        L.oc_adt_finish(self.st._ptrs, C.c_int64(self.n), *f, C.byref(self.st.scal), C.byref(self.st.settings),
+                        C.c_uint64(w0), C.c_uint64(w1))
+        self._after_adt(m, False, w1)
+        return w0, w1, w1_local
+
     def run_steps(self, nsteps):
         for _ in range(int(nsteps)):
             self._hooks()
@@ -172,8 +218,16 @@ class OraclePhases:
     """PhasedStepper backend over an OracleContext, exchanging the predicate words as 64 int32
     0/1 CPU tensors (what the HIP backend does with device tensors)."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, one_exchange=False):
         self.ctx = ctx
+        self.one_exchange = one_exchange
+
+    def summary_phase(self):
+        self.ctx._hooks()
+        self.ctx.words[3] = self.ctx.summary_word()
+
+    def finish_phase(self):
+        self.ctx.finish_from_summary(self.ctx.words[3], -1)
 
     def hooks_phase(self):
         self.ctx._hooks()

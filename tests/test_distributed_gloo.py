@@ -29,7 +29,7 @@ def test_decomposition_api():
     assert g == (slice(0, 6), slice(0, 10)) and l == (slice(0, 6), slice(0, 10))
 
 
-def _worker(rank, world, port, case, nsteps, out_dir):
+def _worker(rank, world, port, case, nsteps, out_dir, one_exchange=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,7 +50,7 @@ def _worker(rank, world, port, case, nsteps, out_dir):
     ctx.set_scalars(scalars_from_row(g["scal0"]))
     ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
     ctx.set_forcing_series(forcing)
-    PhasedStepper(OC.OraclePhases(ctx)).run(nsteps)
+    PhasedStepper(OC.OraclePhases(ctx, one_exchange=one_exchange)).run(nsteps)
     snap = np.stack([ctx.download(nm).astype(np.float64) for nm in names])
     s = ctx.get_scalars()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), snap=snap, sel=sel,
@@ -58,12 +58,40 @@ def _worker(rank, world, port, case, nsteps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,nsteps", [("svat_hetero_combo", 120), ("svat_hetero_combo", 240)])
-def test_two_ranks_reproduce_single_domain(tmp_path, oracle, case, nsteps):
+def test_summary_derivation_matches_direct_evaluation(oracle):
+    """Single domain: the predicate words derived from the summary word (the one-exchange protocol) equal the ones
+    evaluated column by column, on every step of a trajectory with rain, snow, pauses and all three step classes;
+    the trajectory itself matches the reference."""
+    import oracle_context as OC
+    from golden_util import compare, load_case
+    from hip_util import scalars_from_row
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    nx, ny = (int(v) for v in g["nx_ny"])
+    ctx = OC.OracleContext(nx, ny)
+    for row, nm in zip(g["state0"], names):
+        ctx.upload(nm, row)
+    ctx.set_scalars(scalars_from_row(g["scal0"]))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    ctx.set_forcing_series(forcing)
+    classes = set()
+    for step in range(1, 241):
+        ctx._hooks()
+        w0, w1, w1_direct = ctx.finish_from_summary(ctx.summary_word(), -1)
+        assert w1 == w1_direct, f"step {step}: derived {w1:#x}, direct {w1_direct:#x}"
+        classes.add(int(ctx.get_scalars().dt_secs))
+    assert classes == {600, 3600, 86400}
+    snap = np.stack([ctx.download(nm).astype(np.float64) for nm in names])
+    compare(snap, g["s00240"], names, what="summary protocol, single domain, step 240")
+
+
+@pytest.mark.parametrize("case,nsteps,one_exchange", [("svat_hetero_combo", 120, False), ("svat_hetero_combo", 240, False),
+                                                      ("svat_hetero_combo", 240, True)])
+def test_two_ranks_reproduce_single_domain(tmp_path, oracle, case, nsteps, one_exchange):
     from golden_util import compare, load_case
 
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, case, nsteps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, case, nsteps, str(tmp_path), one_exchange), nprocs=2, join=True)
     g, names, _ = load_case(case)
     ref = g[f"s{nsteps:05d}"]
     got = np.full_like(ref, np.nan)
