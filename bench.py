@@ -216,10 +216,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hip backend has no CPU fallback")
+    # rehearsal of the multi-rank path on a one-GPU box: RH_BENCH_SINGLE_DEVICE=1 puts every rank on device 0 and
+    # exchanges over gloo (RCCL refuses two ranks on one device); never used by the driver
+    rehearsal = bool(os.environ.get("RH_BENCH_SINGLE_DEVICE"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     if args.model == "sas":
         bench_sas(args, torch, dist, rank, local_rank, world, device)
