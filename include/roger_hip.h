@@ -192,6 +192,23 @@ void *rh_predicate_words(rh_ctx *ctx);
 int rh_predicates_expand(rh_ctx *ctx, int word, int32_t *dev_dst64);
 int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64);
 
+/* ---- device-side output accumulators --------------------------------
+ * The reference's "rate" diagnostic adds every registered variable after each step (`rate += var[..., tau]`,
+ * roger/diagnostics/rate.py:66-84) and its "collect" diagnostic keeps the current value
+ * (roger/diagnostics/collect.py); the catchment setups and the transport model's input consume them as DAILY sums
+ * of the fluxes and end-of-day storages (benchmarks/SVATOXYGEN18_benchmark.py:342-377).  With adaptive time steps
+ * decided on the device the host does not know where a day ends without synchronising, so the accumulators are
+ * indexed by day on the device: slot = (day of the step's start time) mod n_slots; the first step of a day
+ * overwrites its slot.  After rh_diag_configure every fused step (rh_svat_step, rh_run_steps, rh_step_phase3,
+ * rh_step_finish) is followed by one small kernel that updates the slots.
+ *   rate_planes[n_rate]:       plane ids summed per day          (24 B of traffic per plane, column and step)
+ *   collect_planes[n_collect]: plane ids whose end-of-day value is kept
+ * n_rate + n_collect <= 32; n_slots >= 1 days are resident: (n_slots, n_rate + n_collect, n_cells) float64. */
+int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int *collect_planes, int n_collect, int n_slots);
+/* One (variable, day slot) array: n_cells float64.  j counts the rate planes first, then the collect planes. */
+int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes); /* synchronises */
+void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot);
+
 /* HIP-event timing of the fused per-cell kernel.  rh_enable_timing(ctx, 1) starts a new
  * measurement: every following step records an event pair around the kernel on the context's
  * stream (no synchronisation).  rh_timing_summary synchronises and returns the summed kernel

@@ -83,6 +83,10 @@ int rh_sas_download(rh_sas_ctx *ctx, int array, void *host, size_t bytes); /* sy
 int rh_sas_upload_cells(rh_sas_ctx *ctx, int array, int64_t first_cell, int64_t n_cells, const void *host, size_t bytes);
 int rh_sas_download_cells(rh_sas_ctx *ctx, int array, int64_t first_cell, int64_t n_cells, void *host, size_t bytes);
 void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int array);
+/* Row `day_row` of a DAILY input from n_cells float64 already on this device (device-to-device, asynchronous on the
+ * context's stream; the caller orders it after the producer): the coupling point for the daily flux sums that the
+ * SVAT context accumulates (rh_diag_device_ptr in roger_hip.h). */
+int rh_sas_set_daily_from_device(rh_sas_ctx *ctx, int array, int64_t day_row, const double *dev_src);
 
 /* ---- the step --------------------------------------------------------------------------------
  * Stages of one day, in the order of svat_transport_model_deterministic; `stages` is a bit mask so

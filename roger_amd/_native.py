@@ -90,6 +90,10 @@ def load():
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
+    lib.rh_diag_configure.argtypes = [vp, vp, i32, vp, i32, i32]
+    lib.rh_diag_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    lib.rh_diag_device_ptr.argtypes = [vp, i32, i32]
+    lib.rh_diag_device_ptr.restype = vp
     lib.rh_svat_step.argtypes = [vp, i32]
     lib.rh_run_steps.argtypes = [vp, i64]
     lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
@@ -134,6 +138,7 @@ def _declare_sas(lib):
     lib.rh_sas_download.argtypes = [vp, i32, vp, C.c_size_t]
     lib.rh_sas_upload_cells.argtypes = [vp, i32, i64, i64, vp, C.c_size_t]
     lib.rh_sas_download_cells.argtypes = [vp, i32, i64, i64, vp, C.c_size_t]
+    lib.rh_sas_set_daily_from_device.argtypes = [vp, i32, i64, vp]
     lib.rh_sas_array_device_ptr.argtypes = [vp, i32]
     lib.rh_sas_array_device_ptr.restype = vp
     lib.rh_sas_stages.argtypes = [vp, i64, i32]
@@ -147,7 +152,7 @@ def _declare_sas(lib):
 SAS_DECLARED_SYMBOLS = (
     "rh_sas_default_config", "rh_sas_create", "rh_sas_destroy", "rh_sas_last_error", "rh_sas_set_stream",
     "rh_sas_sync", "rh_sas_num_arrays", "rh_sas_array_name", "rh_sas_array_index", "rh_sas_array_elems",
-    "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_upload_cells", "rh_sas_download_cells", "rh_sas_array_device_ptr", "rh_sas_stages",
+    "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_upload_cells", "rh_sas_download_cells", "rh_sas_set_daily_from_device", "rh_sas_array_device_ptr", "rh_sas_stages",
     "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary", "rh_sas_selftest_pow",
 )
 
@@ -238,6 +243,11 @@ class SasContext:
                                                     a.ctypes.data_as(C.c_void_p), a.nbytes), f"rh_sas_download_cells({name})")
         return a
 
+    def set_daily_from_device(self, name, day_row, dev_ptr):
+        """Row `day_row` of a daily input from n float64 on the device (e.g. Context.diag_device_ptr)."""
+        self._check(self._lib.rh_sas_set_daily_from_device(self._h, self.index(name), int(day_row), C.c_void_p(dev_ptr)),
+                    f"rh_sas_set_daily_from_device({name})")
+
     def device_ptr(self, name):
         return self._lib.rh_sas_array_device_ptr(self._h, self.index(name))
 
@@ -289,7 +299,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
-    "rh_step_summary", "rh_step_finish",
+    "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr",
 )
 
 
@@ -411,6 +421,23 @@ class Context:
     def step_phase3(self, monthly=False):
         # monthly: False/True, or -1 to use the month-change flag computed on the device
         self._check(self._lib.rh_step_phase3(self._h, int(monthly)), "rh_step_phase3")
+
+    def diag_configure(self, rate=(), collect=(), n_slots=1):
+        """Device-side daily accumulators: `rate` variables are summed per day, `collect` variables keep their
+        end-of-day value (time level tau); n_slots days stay resident."""
+        self._diag_names = list(rate) + list(collect)
+        ids = lambda names: (C.c_int * max(1, len(names)))(*[self.index[n] for n in names])  # noqa: E731
+        r, c = ids(list(rate)), ids(list(collect))
+        self._check(self._lib.rh_diag_configure(self._h, r, len(rate), c, len(collect), int(n_slots)), "rh_diag_configure")
+
+    def diag_download(self, name, slot):
+        a = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.rh_diag_download(self._h, self._diag_names.index(name), int(slot),
+                                               a.ctypes.data_as(C.c_void_p), a.nbytes), "rh_diag_download")
+        return a
+
+    def diag_device_ptr(self, name, slot):
+        return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))
 
     def step_finish(self, monthly=-1):
         self._check(self._lib.rh_step_finish(self._h, int(monthly)), "rh_step_finish")

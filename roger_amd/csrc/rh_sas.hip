@@ -953,6 +953,15 @@ int rh_sas_download_cells(rh_sas_ctx *ctx, int a, int64_t first_cell, int64_t n_
     return rh_sas_sync(ctx);
 }
 
+int rh_sas_set_daily_from_device(rh_sas_ctx *ctx, int a, int64_t day_row, const double *dev_src) {
+    if (!ctx) return RH_ERR_ARG;
+    if (a < 0 || a >= SA_COUNT || SAS_KIND[a] != K_DAILY) return sfail(ctx, RH_ERR_ARG, "rh_sas_set_daily_from_device: not a daily input array");
+    if (day_row < 0 || day_row >= ctx->cfg.forcing_days || !dev_src) return sfail(ctx, RH_ERR_ARG, "rh_sas_set_daily_from_device: bad row or null source");
+    SHIPCHK(ctx, hipMemcpyAsync((double *)ctx->arr[a] + day_row * ctx->cfg.n_cells, dev_src, (size_t)ctx->cfg.n_cells * sizeof(double),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    return RH_OK;
+}
+
 void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int a) { return (ctx && a >= 0 && a < SA_COUNT) ? ctx->arr[a] : nullptr; }
 
 int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {

@@ -51,6 +51,10 @@ struct DevState {
     // OR-reduced by k_ctrl at the start of the next step
     unsigned long long *sflags;
     int sflag_blocks;
+    // device-side output accumulators (rh_diag_configure): (diag_slots, diag_rate + diag_collect, n) float64
+    double *diag;
+    int diag_rate, diag_collect, diag_slots;
+    int diag_planes[32];
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
     const double *forc_cell[3];        // per-cell forcing (n, 144) or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
@@ -80,6 +84,8 @@ struct rh_ctx {
     double *mlms_buf;
     bool per_cell;
     bool summary_valid;   // D->sflags describe the columns as they are in the arena now
+    double *diag_buf;
+    int diag_n, diag_slots;
     unsigned long long *sflags_buf;
     int pred_blocks;
     bool forcing_set;
@@ -588,6 +594,25 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
     }
     wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], b);
 }
+// Output accumulators: after a step that covered (t0, t1], day = t0 / 86400, slot = day mod diag_slots; the first
+// step of a day (t0 on midnight) overwrites.  Rate planes add this step's value (Rate.diagnose, roger/diagnostics/
+// rate.py:66-84: `rate += var[..., tau]`), collect planes keep the current one.  S.time / S.dt_secs were advanced by
+// the control kernel before the fused kernel ran.
+__global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t t0 = D->S.time - D->S.dt_secs;
+    const int64_t slot = (t0 / 86400) % D->diag_slots;
+    const bool first = (t0 % 86400) == 0;
+    const int nr = D->diag_rate, nv = D->diag_rate + D->diag_collect;
+    double *base = D->diag + (size_t)slot * nv * a.n;
+    for (int j = 0; j < nv; ++j) {
+        double v;
+        rh_ld(a, D->diag_planes[j], i, v);
+        double *p = base + (size_t)j * a.n + i;
+        *p = (j < nr && !first) ? *p + v : v;
+    }
+}
 // multi-GPU: OR of the summary words into words[3] for the exchange
 __global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks) {
     if (do_hooks) hooks_set_forcing(D);
@@ -968,6 +993,9 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->series_buf = nullptr;
     ctx->mlms_buf = nullptr;
     ctx->sflags_buf = nullptr;
+    ctx->diag_buf = nullptr;
+    ctx->diag_n = 0;
+    ctx->diag_slots = 0;
     ctx->per_cell = false;
     const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256;
     ctx->arena.stride = stride;
@@ -1038,6 +1066,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
     if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
     if (ctx->sflags_buf) (void)hipFree(ctx->sflags_buf);
+    if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1284,6 +1313,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
         ctx->ev_used += 2;
     }
     ctx->summary_valid = true;  // the fused kernel leaves the summary words of the state it wrote
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev);
     return RH_OK;
 }
 
@@ -1410,6 +1440,56 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
         if (rc) return rc;
     }
     return RH_OK;
+}
+
+int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int *collect_planes, int n_collect, int n_slots) {
+    if (!ctx) return RH_ERR_ARG;
+    if (n_rate < 0 || n_collect < 0 || n_rate + n_collect > 32 || n_slots < 1 || (n_rate && !rate_planes) || (n_collect && !collect_planes))
+        return fail(ctx, RH_ERR_ARG, "rh_diag_configure: bad counts (n_rate + n_collect <= 32, n_slots >= 1)");
+    int planes[32];
+    for (int j = 0; j < n_rate + n_collect; ++j) {
+        planes[j] = j < n_rate ? rate_planes[j] : collect_planes[j - n_rate];
+        if (planes[j] < 0 || planes[j] >= RH_NPLANES || PLANE_IS_INT[planes[j]])
+            return fail(ctx, RH_ERR_ARG, "rh_diag_configure: plane ids must name float64 planes");
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->diag_buf) {
+        HIPCHK(ctx, hipFree(ctx->diag_buf));
+        ctx->diag_buf = nullptr;
+    }
+    const int nv = n_rate + n_collect;
+    ctx->diag_n = nv;
+    ctx->diag_slots = n_slots;
+    if (nv) {
+        const size_t bytes = (size_t)n_slots * nv * ctx->n * sizeof(double);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->diag_buf, bytes));
+        HIPCHK(ctx, hipMemsetAsync(ctx->diag_buf, 0, bytes, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag, &ctx->diag_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_rate, &n_rate, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_collect, &n_collect, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_slots, &n_slots, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dev->diag_planes, planes, sizeof(int) * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the sources are stack locals
+    return RH_OK;
+}
+static int diag_check(rh_ctx *ctx, int j, int slot) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->diag_n) return fail(ctx, RH_ERR_STATE, "rh_diag_configure has not been called");
+    if (j < 0 || j >= ctx->diag_n || slot < 0 || slot >= ctx->diag_slots) return fail(ctx, RH_ERR_ARG, "rh_diag: variable or slot out of range");
+    return RH_OK;
+}
+int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes) {
+    const int rc = diag_check(ctx, j, slot);
+    if (rc) return rc;
+    if (!host || bytes != (size_t)ctx->n * sizeof(double)) return fail(ctx, RH_ERR_ARG, "rh_diag_download: size mismatch");
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->diag_buf + ((size_t)slot * ctx->diag_n + j) * ctx->n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot) {
+    if (diag_check(ctx, j, slot)) return nullptr;
+    return ctx->diag_buf + ((size_t)slot * ctx->diag_n + j) * ctx->n;
 }
 
 int rh_predicates_expand(rh_ctx *ctx, int word, int32_t *dev_dst64) {
