@@ -127,6 +127,14 @@ int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day
 int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, const double *pet, const int64_t *year,
                           const int64_t *month, const int64_t *doy, int64_t nitt_forc);
 
+/* Per-cell weights on top of the resident series, as the distributed catchment setups apply them in `set_forcing`
+ * (examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186, 276-296):
+ *   prec_day = PREC * prec_weight,  ta_day = TA + ta_offset,  pet_day = PET * pet_weight     (n_cells float64 each)
+ * Needs rh_set_forcing_series first.  The day's (n_cells, 144) forcing is then formed on the device at midnight
+ * by the device-side hooks; the step takes the per-cell-forcing path (predicate kernels, three-phase protocol).
+ * Pass three NULLs to return to the shared series. */
+int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double *ta_offset, const double *pet_weight);
+
 /* ---- setup-time kernels ------------------------------------------------------------------ */
 int rh_topo(rh_ctx *ctx);               /* surface.calc_topo_kernel, roger/core/surface.py:40-71 */
 int rh_params_surface(rh_ctx *ctx);     /* calc_parameters_surface_kernel, surface.py:74-343 */

@@ -90,6 +90,7 @@ def load():
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
+    lib.rh_set_forcing_weights.argtypes = [vp, vp, vp, vp]
     lib.rh_diag_configure.argtypes = [vp, vp, i32, vp, i32, i32]
     lib.rh_diag_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
     lib.rh_diag_device_ptr.argtypes = [vp, i32, i32]
@@ -300,6 +301,7 @@ DECLARED_SYMBOLS = (
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr",
+    "rh_set_forcing_weights",
 )
 
 
@@ -421,6 +423,17 @@ class Context:
     def step_phase3(self, monthly=False):
         # monthly: False/True, or -1 to use the month-change flag computed on the device
         self._check(self._lib.rh_step_phase3(self._h, int(monthly)), "rh_step_phase3")
+
+    def set_forcing_weights(self, prec_weight=None, ta_offset=None, pet_weight=None):
+        """Per-cell weights on the resident series (prec * w, ta + offset, pet * w); None x 3 clears them."""
+        if prec_weight is None and ta_offset is None and pet_weight is None:
+            self._check(self._lib.rh_set_forcing_weights(self._h, None, None, None), "rh_set_forcing_weights")
+            return
+        arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (prec_weight, ta_offset, pet_weight)]
+        if any(a.size != self.n for a in arrs):
+            raise ValueError("weights must have one value per cell")
+        self._check(self._lib.rh_set_forcing_weights(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs]),
+                    "rh_set_forcing_weights")
 
     def diag_configure(self, rate=(), collect=(), n_slots=1):
         """Device-side daily accumulators: `rate` variables are summed per day, `collect` variables keep their

@@ -65,6 +65,8 @@ struct DevState {
     const int64_t *calendar[3];
     int64_t nitt_forc;
     int monthly;                       // set_parameters' month-change test, evaluated on the device
+    const double *weights[3];          // per-cell prec_weight, ta_offset, pet_weight (rh_set_forcing_weights) or null
+    int fill_cells;                    // the hooks took a new day: k_fill_cell_forcing forms the per-cell forcing
     const double *mlms;                // lut_mlms rows (oneD model), device copy
     int64_t mlms_rows;
     int max_slope_per;
@@ -79,6 +81,7 @@ struct rh_ctx {
     hipStream_t stream;
     bool own_stream;
     double *forc_cell_buf[3];
+    double *weight_buf[3];
     double *agg_cell_buf;
     void *series_buf;
     double *mlms_buf;
@@ -233,14 +236,27 @@ RH_DEV void hooks_set_forcing(DevState *D) {
             S.month[1] = D->calendar[1][i0];
             S.doy[1] = D->calendar[2][i0];
             S.itt_forc = i0 + RH_SLOTS_PER_DAY;
-            D->per_cell = 0;
+            D->per_cell = D->weights[0] ? 1 : 0;
         }
+        D->fill_cells = (have && D->weights[0]) ? 1 : 0;
         D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
     }
     __threadfence();
     __syncthreads();
 }
 __global__ __launch_bounds__(RH_BLOCK) void k_set_forcing(DevState *D) { hooks_set_forcing(D); }
+// weighted station forcing (eberbaechle/svat_distributed/svat.py:276-296): on the day the hooks took new forcing,
+// prec_day = PREC * prec_weight, ta_day = TA + ta_offset, pet_day = PET * pet_weight for every column
+__global__ __launch_bounds__(RH_BLOCK) void k_fill_cell_forcing(Arena a, DevState *D) {
+    if (!D->fill_cells) return;
+    const int64_t idx = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (idx >= a.n * RH_SLOTS_PER_DAY) return;
+    const int64_t i = idx / RH_SLOTS_PER_DAY;
+    const int s = (int)(idx % RH_SLOTS_PER_DAY);
+    const_cast<double *>(D->forc_cell[0])[idx] = D->forc[0][s] * D->weights[0][i];
+    const_cast<double *>(D->forc_cell[1])[idx] = D->forc[1][s] + D->weights[1][i];
+    const_cast<double *>(D->forc_cell[2])[idx] = D->forc[2][s] * D->weights[2][i];
+}
 
 // start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
 __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
@@ -989,6 +1005,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->dev = nullptr;
     ctx->arena.base = nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
+    for (auto &b : ctx->weight_buf) b = nullptr;
     ctx->agg_cell_buf = nullptr;
     ctx->series_buf = nullptr;
     ctx->mlms_buf = nullptr;
@@ -1061,6 +1078,8 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto &b : ctx->forc_cell_buf)
+        if (b) (void)hipFree(b);
+    for (auto &b : ctx->weight_buf)
         if (b) (void)hipFree(b);
     if (ctx->agg_cell_buf) (void)hipFree(ctx->agg_cell_buf);
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
@@ -1343,6 +1362,7 @@ int rh_step_phase3(rh_ctx *ctx, int monthly) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
+static void launch_hooks(rh_ctx *ctx);
 // single GPU: the same step with the reductions folded into the single-workgroup kernels
 static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
@@ -1354,6 +1374,10 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         if (rc) return rc;
         CHECK_LAUNCH(ctx);
         return RH_OK;
+    }
+    if (hooks) {  // per-cell forcing from the resident series: the hooks must have formed it before k_pred1 reads it
+        launch_hooks(ctx);
+        hooks = 0;
     }
     LAUNCH_PRED(ctx, k_pred1);
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
@@ -1424,11 +1448,51 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
     return RH_OK;
 }
 
+static void launch_hooks(rh_ctx *ctx) {
+    hipLaunchKernelGGL(k_set_forcing, dim3(1), dim3(RH_BLOCK), 0, ctx->stream, ctx->dev);
+    if (ctx->weight_buf[0])
+        hipLaunchKernelGGL(k_fill_cell_forcing, dim3(grid_for(ctx->n * RH_SLOTS_PER_DAY)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+}
 int rh_hooks_phase(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
-    hipLaunchKernelGGL(k_set_forcing, dim3(1), dim3(RH_BLOCK), 0, ctx->stream, ctx->dev);
+    launch_hooks(ctx);
     CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
+int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double *ta_offset, const double *pet_weight) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
+    const double *src[3] = {prec_weight, ta_offset, pet_weight};
+    const bool clear = !prec_weight && !ta_offset && !pet_weight;
+    if (!clear && (!prec_weight || !ta_offset || !pet_weight)) return fail(ctx, RH_ERR_ARG, "rh_set_forcing_weights: give all three arrays or none");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(double) * (size_t)ctx->n;
+    const double *dptr[3] = {nullptr, nullptr, nullptr};
+    if (clear) {
+        for (auto &b : ctx->weight_buf) {
+            if (b) HIPCHK(ctx, hipFree(b));
+            b = nullptr;
+        }
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            if (!ctx->weight_buf[k]) HIPCHK(ctx, hipMalloc((void **)&ctx->weight_buf[k], nb));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->weight_buf[k], src[k], nb, hipMemcpyHostToDevice, ctx->stream));
+            dptr[k] = ctx->weight_buf[k];
+        }
+        const size_t bytes = sizeof(double) * RH_SLOTS_PER_DAY * (size_t)ctx->n;
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->forc_cell_buf[k]) HIPCHK(ctx, hipMalloc((void **)&ctx->forc_cell_buf[k], bytes));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dev->forc_cell, ctx->forc_cell_buf, sizeof(double *) * 3, hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->agg_cell_buf) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->agg_cell_buf, sizeof(double) * 9 * (size_t)ctx->n));
+            HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->agg_cell, &ctx->agg_cell_buf, sizeof(double *), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dev->weights, dptr, sizeof(dptr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
     return RH_OK;
 }
 

@@ -298,3 +298,46 @@ def test_phased_stepper_single_rank(native):
         np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(other, names))
     for ctx in (a, b, c):
         ctx.close()
+
+
+def test_weighted_station_forcing_on_device(native, oracle):
+    """BASELINE configs[4] shape (Eberbaechle: 80 x 53 columns of 25 m^2, station forcing with per-cell prec_weight,
+    ta_offset, pet_weight, examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186, 276-296): the device
+    forms the per-cell day from the resident series and the weights and steps without the host; the oracle gets the
+    same per-cell arrays from the host.  Heterogeneous synthetic parameter maps (seed 7), 6 days, all step classes."""
+    import hip_util as H
+    from roger_amd.forcing import combo_forcing
+
+    g, names, _ = load_case("svat_hetero_combo")
+    luts = (g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    nx, ny = 80, 53
+    n = nx * ny
+    st = _oracle_setup(oracle, nx, ny, 7, luts)
+    onames = st.names
+    ctx = native.Context(nx, ny)
+    H.upload_snapshot(ctx, st.snapshot(), onames)
+    ctx.set_scalars(H.scalars_from_row(st.scalars_row()))
+    ctx.set_luts(*luts)
+    rng = np.random.default_rng(7)
+    pw, toff, ew = rng.uniform(0.8, 1.3, n), rng.uniform(-1.5, 1.5, n), rng.uniform(0.85, 1.15, n)
+    F = combo_forcing(ndays=6)
+    ctx.set_forcing_series(F)
+    ctx.set_forcing_weights(pw, toff, ew)
+    s = st.scal
+    steps = 0
+    while s.time < 6 * 86400:
+        if s.time % 86400 == 0:      # the setup's set_forcing hook, host side for the oracle
+            i = s.itt_forc
+            s.itt_day = 0
+            s.year[1], s.month[1], s.doy[1] = int(F["YEAR"][i]), int(F["MONTH"][i]), int(F["DOY"][i])
+            day = (F["PREC"][i:i + 144][None, :] * pw[:, None], F["TA"][i:i + 144][None, :] + toff[:, None],
+                   F["PET"][i:i + 144][None, :] * ew[:, None])
+            s.itt_forc = i + 144
+        monthly = (s.month[1] != s.month[0]) and (s.itt > 1)
+        st.step(*day, monthly)
+        steps += 1
+    ctx.run_steps(steps)
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
+    compare_bulk(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"weighted forcing, {steps} steps")
+    assert len({600, 3600, 86400} & {int(st.scal.dt_secs)}) == 1 and steps > 40
+    ctx.close()
