@@ -16,7 +16,9 @@
  *   calculate_age_statistics_*                     core/transport.py:59-312
  *   calc_ageing_sa_msa_iso_kernel                  core/transport.py:682-739, 780-805
  * with the helpers calc_SA, calc_tt, calc_mtt, calc_conc_iso_flux, calc_conc_iso_storage,
- * conc_to_delta, update_sa (transport.py:315-619) and the SAS families of core/sas.py.
+ * conc_to_delta, update_sa (transport.py:315-619) and the SAS families of core/sas.py: uniform (code 1),
+ * dirac (2), kumaraswami (3, 31-37), exponential (51), power (6, 61, 62).  Gamma (4) and the reversed exponential
+ * (52) are not implemented: rh_sas_sync reports a column that asks for them (RH_ERR_STATE).
  *
  * Same conventions as roger_hip.h: plain pointers and sizes, 0 / negative rh_status returns,
  * rh_sas_last_error for the text, one context = one HIP device + one stream, asynchronous

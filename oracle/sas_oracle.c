@@ -12,9 +12,10 @@
  *
  * numpy semantics restated: `cumsum` is a running sum, `sum` over the contiguous age axis is
  * pairwise (oc_np_sum), `max` propagates NaN, `where` evaluates both branches.
- * SAS families: uniform (code 1) and power law (6, 61, 62) -- roger/core/sas.py:5-40, 191-240;
- * the other families of the reference contribute exactly 0 for these codes and are not restated
- * (SURVEY.md section 8f rank 4).
+ * SAS families: uniform (code 1), dirac (2), kumaraswami (3, 31-37), exponential (51) and power law (6, 61, 62)
+ * -- roger/core/sas.py; every family contributes exactly 0 for the codes of the others, so the reference's sum
+ * over all families is the selected one.  Not restated: gamma (4, needs scipy's gammainc) and exponential with
+ * reversed age order (52).
  */
 #include <math.h>
 #include <stdint.h>
@@ -109,6 +110,34 @@ static void sas_omega(double *Om, const double *SA, int64_t nages, double *p, do
         if (code == 61) p[1] = p[3] + ((1 - S_rel) * p[4]);
         if (code == 62) p[1] = p[3] + (S_rel * p[4]);
         for (int64_t k = 0; k < nages; ++k) Om[k] = (SA[k] > 0 ? (SA[k] <= S ? pow(SA[k] / S, p[1]) : 1.) : 0.) * 1.0 * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    } else if (code == 2) { /* dirac (piston flow), sas.py:43-64: vs.nages = 0 .. ages is the edge index */
+        const double S = Smax * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = ((double)k <= p[1] ? 0 : 1) * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * 1.0 * mk;
+    } else if (code == 3 || (code >= 31 && code <= 37)) { /* kumaraswami, sas.py:67-147 */
+        const double S = Smax * mk;
+        double S_rel = (S - p[5]) / (p[6] - p[5]) * mk;
+        S_rel = (S_rel < 0 ? 0 : S_rel);
+        S_rel = (S_rel > 1 ? 1 : S_rel);
+        const double up = p[3] + (S_rel * p[4]), down = p[3] + ((1 - S_rel) * p[4]);
+        if (code == 31) { p[1] = 1; p[2] = up; }
+        if (code == 32) { p[1] = down; p[2] = 1; }
+        if (code == 33) { p[1] = 1; p[2] = down; }
+        if (code == 34) { p[1] = up; p[2] = 1; }
+        if (code == 35) { p[1] = down; p[2] = up; }
+        if (code == 36) p[1] = down;
+        if (code == 37) p[2] = up;
+        for (int64_t k = 0; k < nages; ++k) {
+            const double f = 1 - pow(1 - pow(SA[k] / S, p[1]), p[2]);
+            const double o = (S >= 0 ? (SA[k] > 0 ? (SA[k] < S ? f : 1.) : 0.) : (SA[k] > 0 ? f : 0.));
+            Om[k] = o * 1.0 * mk;
+        }
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    } else if (code == 51) { /* exponential with preference for young water, sas.py:168-190 */
+        const double S = Smax * mk;
+        for (int64_t k = 0; k < nages; ++k)
+            Om[k] = (SA[k] > 0 ? (SA[k] < S ? 1 - exp(p[1] * (-1) * (SA[k] / S)) : 1.) : 0.) * mk;
         for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
     }
 }

@@ -246,13 +246,21 @@ SAS_DEV double blk_max(Blk<W> &B, double v) {
 // Cumulative sum over the age axis (calc_SA :343-359, the cumsums of calc_tt :456-468).
 //   hi[j] = cumulative value at the upper edge of the thread's j-th age class
 //   lo    = cumulative value at the lower edge of its first class
-//   *pmax = max over all edges including the leading 0 (`npx.max(SA, axis=-1)`), if asked for
+//   *ptop = the value at the top of the stored water, if asked for: hi of the LAST age class THAT MOVES THE SUM
+//           (non-empty and not absorbed by rounding), which is also written into hi of every class above it.  It stands for `npx.max(SA, axis=-1)`: a sequential
+//           cumsum of non-negative terms is non-decreasing, its maximum is its last element, and every class above
+//           the last non-empty one repeats that element EXACTLY.  The SAS functions rely on it: Omega jumps to 1
+//           where SA == S (by 1 - exp(-a) for the exponential family; a kumaraswami exponent < 1 turns a one-ulp
+//           gap into 1e-9).  The parallel scan is only consistent inside a thread, so the equality is restored
+//           explicitly instead of taking a maximum over the lanes.
 // Construction: loc = running sum inside the thread, wexc = exclusive wave scan of the thread totals,
 // pw = running sum of the totals of the preceding waves; hi[j] = pw + (wexc + loc[j]), lo = pw + wexc.
-// fl(x + .) is monotone, so hi is non-decreasing in j for non-negative input, hi[j] == hi[j-1] (or lo)
-// exactly where the input is 0, and the maximum over a wave is pw + max(wexc + loc).
-template <int W, int E>
-SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double &lo, double *pmax) {
+// fl(x + .) is monotone, so hi is non-decreasing in j for non-negative input and hi[j] == hi[j-1] (or lo)
+// exactly where the input is 0.
+// EXACT_TOP: restore the exact equality above the last class that moves the sum (two more wave reductions: needed
+// where Omega is discontinuous or infinitely steep at S); otherwise *ptop = hi of class `top_k` = ages - 1.
+template <int W, int E, bool EXACT_TOP>
+SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double &lo, double *ptop, int base, int top_k) {
     double loc[E];
     loc[0] = v[0];
 #pragma unroll
@@ -260,36 +268,58 @@ SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double
     const double winc = wave_scan_sum(loc[E - 1]);
     const double wexc = lane_prev(winc, 0.0);
     double u[E];
-    double umax = wexc;
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        u[j] = wexc + loc[j];
-        umax = fmax(umax, u[j]);
+    for (int j = 0; j < E; ++j) u[j] = wexc + loc[j];
+    double ktop = -1.0, utop = 0.0;  // the wave's top class (as a double: exact for indices) and its u
+    if (ptop && EXACT_TOP) {
+        double kmine = -1.0, umine = 0.0;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (u[j] != (j == 0 ? wexc : u[j > 0 ? j - 1 : 0])) {  // the class moves the cumulative sum: a residue of
+                kmine = (double)(base + j);                         // 1e-17 mm under 100 mm is absorbed, as in the
+                umine = u[j];                                       // reference's sequential cumsum
+            }
+        ktop = wave_max(kmine);
+        utop = wave_max(kmine == ktop && ktop >= 0 ? umine : -INFINITY);  // exactly one lane holds class ktop
+    } else if (ptop) {
+        const int top_thread = top_k / E, top_j = top_k % E;  // uniform
+        double mine = u[0];
+#pragma unroll
+        for (int j = 1; j < E; ++j) mine = (j == top_j) ? u[j] : mine;
+        const unsigned long long b = __double_as_longlong(mine);
+        const int src = top_thread & 63;
+        const unsigned lo32 = __builtin_amdgcn_readlane((int)(unsigned)b, src), hi32 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+        utop = __longlong_as_double(((unsigned long long)hi32 << 32) | lo32);  // meaningful in the owning wave
+        ktop = (B.wave == (top_thread >> 6)) ? (double)top_k : -1.0;
     }
     if (W == 1) {
+        const double S = (ktop >= 0 ? utop : 0.0);
 #pragma unroll
-        for (int j = 0; j < E; ++j) hi[j] = u[j];
+        for (int j = 0; j < E; ++j) hi[j] = (ptop && EXACT_TOP && (double)(base + j) >= ktop) ? S : u[j];
         lo = wexc;
-        if (pmax) *pmax = fmax(0.0, wave_max(umax));
+        if (ptop) *ptop = S;
         return;
     }
-    if (pmax) umax = wave_max(umax);
     const int buf = B.phase++ & 1;
     if (B.lane == 63) {
         B.red[buf][B.wave][0] = winc;
-        B.red[buf][B.wave][1] = umax;
+        B.red[buf][B.wave][1] = ktop;
+        B.red[buf][B.wave][2] = utop;
     }
     __syncthreads();
-    double pw = 0.0, mine = 0.0, S = 0.0;
+    double pw = 0.0, mine = 0.0, S = 0.0, kglob = -1.0;
     for (int w = 0; w < W; ++w) {
         if (w == B.wave) mine = pw;
-        if (pmax) S = fmax(S, pw + B.red[buf][w][1]);
+        if (ptop && B.red[buf][w][1] > kglob) {  // the owner's own hi = its prefix + its u
+            kglob = B.red[buf][w][1];
+            S = pw + B.red[buf][w][2];
+        }
         pw = pw + B.red[buf][w][0];
     }
 #pragma unroll
-    for (int j = 0; j < E; ++j) hi[j] = mine + u[j];
+    for (int j = 0; j < E; ++j) hi[j] = (ptop && EXACT_TOP && (double)(base + j) >= kglob) ? S : mine + u[j];
     lo = mine + wexc;
-    if (pmax) *pmax = S;
+    if (ptop) *ptop = S;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,13 +336,16 @@ struct Dist {  // what the age statistics need of one flux
     double tt[E], TT_hi[E], TT_lo;
 };
 
-// Backward travel time distribution of one outgoing flux, calc_tt :362-509, with the SAS families
-// `uniform` (code 1, core/sas.py:5-40) and `power` (codes 6, 61, 62, core/sas.py:191-240).
-// The reference adds the masked results of all six families; for these codes the other four
-// contribute exact zeros.
-template <int W, int E>
-SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
-                     double (&tt)[E]) {
+// Backward travel time distribution of one outgoing flux, calc_tt :362-509, with the SAS families `uniform`
+// (code 1), `dirac` (2), `kumaraswami` (3, 31-37), `exponential` (51) and `power` (6, 61, 62) of core/sas.py.
+// The reference adds the masked results of all six families; every family contributes exact zeros for the
+// codes of the others, so the sum is the selected one.
+enum SasFamily { FAM_NONE, FAM_UNIFORM, FAM_DIRAC, FAM_KUMARASWAMI, FAM_EXPONENTIAL, FAM_POWER };
+// One instantiation per family, selected per column (uniform over the workgroup) by calc_tt below: the benchmark's
+// power law keeps its register budget (3 waves/SIMD without spills) whatever the other families need.
+template <int W, int E, int FAM>
+SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
+                            double (&tt)[E]) {
     const int A = P.ages;
     const double h = 1 / (double)P.substeps;
     const double fh = flux * h;
@@ -323,10 +356,11 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
         for (int j = 0; j < E; ++j) tt[j] = 0.0;
         return;
     }
-    const double code = p[0], p1 = p[1], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6];  // read once: the loop below stores nothing, but the compiler cannot know
-    const bool uniform = (code == 1), power = (code == 6 || code == 61 || code == 62);
+    const double code = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6];  // read once: the loop below stores nothing, but the compiler cannot know
+    constexpr bool uniform = FAM == FAM_UNIFORM, power = FAM == FAM_POWER, dirac = FAM == FAM_DIRAC;
+    constexpr bool kumaraswami = FAM == FAM_KUMARASWAMI, expo = FAM == FAM_EXPONENTIAL;
     const PowConsts C = load_pow_consts();
-    if (!uniform && !power && B.tid == 0) *P.unsupported = 1;
+    double Om_edge0 = 0.0;  // Omega at SA[0] = 0: 0 for every family but a dirac with a negative threshold
     double san[E], ttn[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -335,7 +369,7 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
     }
     for (int it = 0; it < P.substeps; ++it) {
         double SA_hi[E], SA_lo, Smax;
-        blk_cumsum<W, E>(B, san, SA_hi, SA_lo, &Smax);
+        blk_cumsum<W, E, (FAM == FAM_KUMARASWAMI || FAM == FAM_EXPONENTIAL)>(B, san, SA_hi, SA_lo, &Smax, base, A - 1);
         if (it == 0) {  // the first sub-step sees SA = calc_SA(sa) * maskCatch, the later ones cumsum(san) (:456-459)
 #pragma unroll
             for (int j = 0; j < E; ++j) SA_hi[j] *= mk;
@@ -371,12 +405,49 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
                 const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
                 Om[j] = (S <= 0 ? 0 : o) * mk;
             }
+        } else if (dirac) {  // piston flow, sas.py:43-64: the edge index (vs.nages) against the age threshold p1
+            const double S = Smax * mk;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double o = ((double)(base + j + 1) <= p1 ? 0 : 1) * mk;
+                Om[j] = (S <= 0 ? 0 : o) * 1.0 * mk;
+            }
+            Om_edge0 = (S <= 0 ? 0 : (0.0 <= p1 ? 0 : 1) * mk) * 1.0 * mk;
+        } else if (kumaraswami) {  // sas.py:67-147; the device library's pow: two per class, accuracy before speed
+            const double S = Smax * mk;
+            double S_rel = (S - p5) / (p6 - p5) * mk;
+            S_rel = (S_rel < 0 ? 0 : S_rel);
+            S_rel = (S_rel > 1 ? 1 : S_rel);
+            const double up = p3 + (S_rel * p4), down = p3 + ((1 - S_rel) * p4);
+            double a = p1, b = p2;
+            if (code == 31) { a = 1; b = up; }
+            if (code == 32) { a = down; b = 1; }
+            if (code == 33) { a = 1; b = down; }
+            if (code == 34) { a = up; b = 1; }
+            if (code == 35) { a = down; b = up; }
+            if (code == 36) a = down;
+            if (code == 37) b = up;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double x = SA_hi[j];
+                const double f = 1 - pow(1 - pow(x / S, a), b);
+                const double o = (S >= 0 ? (x > 0 ? (x < S ? f : 1.) : 0.) : (x > 0 ? f : 0.)) * 1.0 * mk;
+                Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
+        } else if (expo) {  // sas.py:168-190, code 51
+            const double S = Smax * mk;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double x = SA_hi[j];
+                const double o = (x > 0 ? (x < S ? 1 - exp(p1 * (-1) * (x / S)) : 1.) : 0.) * mk;
+                Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) Om[j] = 0.0;
         }
         double Om_lo, unused;
-        blk_prev2<W>(B, Om[E - 1], 0.0, 0.0, 0.0, Om_lo, unused);  // Omega(SA[0] = 0) = 0 for both families
+        blk_prev2<W>(B, Om[E - 1], 0.0, Om_edge0, 0.0, Om_lo, unused);
         double tti[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -402,6 +473,21 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
         tt[j] = (flux > 0 ? q / flux : 0);                                        // :497-499
     }
 }
+template <int W, int E>
+SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
+                     double (&tt)[E]) {
+    const double code = p[0];
+    if (code == 6 || code == 61 || code == 62) calc_tt_family<W, E, FAM_POWER>(B, P, p, flux, sa, mk, base, tt);
+    else if (code == 1) calc_tt_family<W, E, FAM_UNIFORM>(B, P, p, flux, sa, mk, base, tt);
+    else if (code == 3 || (code >= 31 && code <= 37)) calc_tt_family<W, E, FAM_KUMARASWAMI>(B, P, p, flux, sa, mk, base, tt);
+    else if (code == 2) calc_tt_family<W, E, FAM_DIRAC>(B, P, p, flux, sa, mk, base, tt);
+    else if (code == 51) calc_tt_family<W, E, FAM_EXPONENTIAL>(B, P, p, flux, sa, mk, base, tt);
+    else {
+        // not implemented: gamma (4: incomplete gamma function), exponential with reversed age order (52)
+        if (B.tid == 0 && flux * (1 / (double)P.substeps) > 0) *P.unsupported = 1;
+        calc_tt_family<W, E, FAM_NONE>(B, P, p, flux, sa, mk, base, tt);
+    }
+}
 
 // One outgoing flux: SA, tt, TT, mtt, C, C_iso, the sink's isotope mixing, update_sa.
 // calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
@@ -425,7 +511,7 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
     }
     if (P.diag || (KEEP && P.stats)) {  // TT[1:] = cumsum(tt)
         double TT_hi[E], TT_lo;
-        blk_cumsum<W, E>(B, tt, TT_hi, TT_lo, nullptr);
+        blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
         if (KEEP) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -545,7 +631,7 @@ SAS_DEV void residence_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base
                              bool skip10_90) {
     // RT = SA / max(SA), rt = diff(RT): calculate_age_statistics_root_zone/subsoil/soil :155-312
     double SA_hi[E], SA_lo, mx;
-    blk_cumsum<W, E>(B, sa, SA_hi, SA_lo, &mx);
+    blk_cumsum<W, E, false>(B, sa, SA_hi, SA_lo, &mx, base, P.ages - 1);
     mx *= mk;
     double RT_hi[E], rt[E];
     const double RT_lo = (mx > 0 ? (SA_lo * mk) / mx : 0);
@@ -893,7 +979,7 @@ int rh_sas_sync(rh_sas_ctx *ctx) {
     SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (bad)
         return sfail(ctx, RH_ERR_STATE,
-                     "a column selects a SAS family other than uniform (1) or power (6, 61, 62): not implemented by the hip backend");
+                     "a column selects a SAS family the hip backend does not implement (gamma 4, reversed exponential 52, or an unknown code)");
     return RH_OK;
 }
 

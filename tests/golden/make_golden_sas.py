@@ -109,6 +109,16 @@ def sas_params(nx, ny, variant, seed):
         p = np.zeros((nx, ny, 8))
         p[..., 0] = 6
         p[..., 1] = k * rng.uniform(0.7, 1.4, (nx, ny))
+        if variant == "families":   # dirac, kumaraswami (plain and storage-dependent variants), exponential, power
+            code = rng.choice([2, 3, 31, 32, 33, 34, 35, 36, 37, 51, 6], (nx, ny))
+            p[..., 0] = code
+            p[..., 1] = np.where(code == 2, rng.integers(0, 25, (nx, ny)).astype(float),
+                                 np.where(code == 51, rng.uniform(0.5, 5, (nx, ny)), rng.uniform(0.3, 3, (nx, ny))))
+            p[..., 2] = rng.uniform(0.3, 3, (nx, ny))
+            p[..., 3] = rng.uniform(0.3, 1.0, (nx, ny))
+            p[..., 4] = rng.uniform(0.5, 2.0, (nx, ny))
+            p[..., 5] = 50.0
+            p[..., 6] = 400.0
         if variant == "mixed":
             code = rng.choice([6, 1, 61, 62], (nx, ny))
             p[..., 0] = code
@@ -165,6 +175,7 @@ def main():
         "sas_power_a40": (3, 2, 24, 40, 6, "power", False, 3),
         "sas_mixed_a70": (2, 2, 16, 70, 4, "mixed", False, 5),
         "sas_stats_a30": (2, 2, 12, 30, 3, "mixed", True, 11),
+        "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed) in cases.items():
         if args.only and args.only != name:
