@@ -236,3 +236,50 @@ def test_power_function_accuracy():
     assert rel[-2:].max() < 1e-12          # 1e-300 and the smallest denormal
     assert got[-4] == 1.0 and (_native.sas_selftest_pow(np.ones(8), np.linspace(0.1, 5, 8)) == 1.0).all()
     assert (_native.sas_selftest_pow(np.array([1e-300, 1e-10]), np.array([50.0, 0.0])) == np.array([0.0, 1.0])).all()
+
+
+def test_full_size_properties():
+    """BASELINE configs[2] size: 10^6 columns x 1000 ages, 6 sub-steps, benchmark power law (32 GB of state, streamed in
+    chunks).  Size-independent properties over two days: columns with identical inputs are bit-identical wherever they
+    sit in the grid, equal the oracle's run of the four distinct columns, and the water balance closes."""
+    from roger_amd import sas as rsas
+
+    n, ages, sub = 1_000_000, 1000, 6
+    kinds = 4                                          # four distinct columns, tiled over the grid
+    S_rz, S_ss = np.array([60.0, 90.0, 140.0, 35.0]), np.array([180.0, 260.0, 320.0, 90.0])
+    d4 = rsas.synthetic_daily_inputs(kinds, 2, seed=9)
+    idx = np.arange(n) % kinds
+    daily = {k: v[:, idx] for k, v in d4.items()}
+    ctx = rsas.create_sas(n, ages, sub, S_rz[idx], S_ss[idx], daily=daily, age_statistics=True)
+    ctx.run_days(0, 2)
+    ctx.sync()
+    # the oracle on the four distinct columns
+    ref = SasState(kinds, ages, sub, age_statistics=True)
+    for key, S in (("rz", S_rz), ("ss", S_ss)):
+        sa, msa = rsas.initial_age_state(S, ages)
+        ref.state[f"sa_{key}"][:] = sa
+        ref.state[f"msa_{key}"][:] = msa
+    for f, p in rsas.benchmark_sas_params(kinds).items():
+        ref.sas[f][:] = p
+    for d in range(2):
+        for k in ref.inp:
+            ref.inp[k][:] = d4[k][d]
+        ref.step_oracle()
+    for k in ("C_iso_q_ss", "C_iso_transp", "C_rz", "C_ss", "tt50_q_ss", "ttavg_transp", "rt50_s"):
+        got = ctx.download(k).reshape(-1, kinds)
+        assert (got == got[0]).all() or np.array_equal(got, np.broadcast_to(got[0], got.shape), equal_nan=True), k
+        compare_sas(got[0], ref.out[k], f"full size {k}", rtol=1e-9)
+    for c0 in (0, n // 2 - 2, n - 8):                     # the age-resolved state of a few chunks
+        for k in ("sa_rz", "msa_rz", "sa_ss", "msa_ss"):
+            got = ctx.download_cells(k, c0, 8)
+            want = ref.state[k][(c0 + np.arange(8)) % kinds]
+            if k.startswith("msa"):
+                holds = ref.state[k[1:]][(c0 + np.arange(8)) % kinds] > 0
+                got, want = np.where(holds, got, 0), np.where(holds, want, 0)
+            compare_sas(got, want, f"full size {k} cells {c0}..", rtol=1e-8, atol=1e-9)   # nearly emptied classes: 1e-9 mm
+    # water balance of the four kinds: storage change = inflow - evaporation - transpiration - percolation
+    inflow = sum(d4[k][:2].sum(axis=0) for k in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"))
+    stored = ctx.download_cells("sa_rz", 0, kinds).sum(axis=1) + ctx.download_cells("sa_ss", 0, kinds).sum(axis=1)
+    out_max = sum(d4[k][:2].sum(axis=0) for k in ("evap_soil", "transp", "q_ss"))
+    assert (stored <= S_rz + S_ss + inflow + 1e-6).all() and (stored >= S_rz + S_ss + inflow - out_max - 1e-6).all()
+    ctx.close()
