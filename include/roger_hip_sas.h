@@ -104,7 +104,10 @@ enum {
     RH_SAS_CPR = 1 << 6,      /* capillary rise subsoil -> root zone */
     RH_SAS_STORAGE = 1 << 7,  /* root zone / subsoil / soil concentrations (+ age statistics if enabled) */
     RH_SAS_AGEING = 1 << 8,   /* shift by one age class, merge the oldest */
-    RH_SAS_ALL = (1 << 9) - 1
+    RH_SAS_ALL = (1 << 9) - 1,
+    /* not part of a day: soil.rescale_SA after the transport warm-up (rescale_sa_msa_iso_soil_kernel,
+     * core/soil.py:1250-1395): sa_rz, sa_ss scaled to S_rz_init, S_ss_init; storage concentrations recomputed */
+    RH_SAS_RESCALE = 1 << 9
 };
 /* `day` selects the row of the daily inputs: row (day mod forcing_days). */
 int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages);

@@ -41,6 +41,8 @@ typedef struct oc_sas {
     double *C_rz, *C_ss, *C_s, *C_iso_rz, *C_iso_ss, *C_iso_s; /* (n) */
     /* age statistics (n) or NULL: 10/25/50/75/90 percentile and mean of transp, q_ss, rz, ss, s */
     double *stats[5][6];
+    /* soil.rescale_SA after the warm-up run */
+    const double *S_rz_init, *S_ss_init;
 } oc_sas;
 
 /* numpy pairwise add.reduce (see svat_oracle.c) */
@@ -277,6 +279,34 @@ static void ageing(double *sa, double *msa, int64_t A, double *scratch) {
     sa[A - 1] += sam1[A - 1];
     sa[A - 1] = (sa[A - 1] < 1e-8 ? 0 : sa[A - 1]);
     msa[A - 1] = (sa[A - 1] <= 0 ? NAN : msa[A - 1]);
+}
+
+/* soil.rescale_SA for oxygen-18: rescale_sa_msa_iso_soil_kernel, core/soil.py:1250-1395 (time level tau) */
+void oc_sas_rescale(const oc_sas *P) {
+    const int64_t A = P->ages;
+    double *work = (double *)malloc(sizeof(double) * (A + 4));
+    for (int64_t i = 0; i < P->n; ++i) {
+        const double mk = (double)P->maskCatch[i];
+        double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+        const double t_rz = np_sum(sa_rz, A), t_ss = np_sum(sa_ss, A);
+        for (int64_t k = 0; k < A; ++k) sa_rz[k] = P->S_rz_init[i] * (sa_rz[k] / t_rz);
+        for (int64_t k = 0; k < A; ++k) sa_ss[k] = P->S_ss_init[i] * (sa_ss[k] / t_ss);
+        P->C_rz[i] = conc_storage(sa_rz, msa_rz, A, work);
+        P->C_iso_rz[i] = conc_to_delta(P, P->C_rz[i]) * mk;
+        P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work);
+        P->C_iso_ss[i] = conc_to_delta(P, P->C_ss[i]) * mk;
+        double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+        for (int64_t k = 0; k < A; ++k) {
+            sa_s[k] = sa_rz[k] + sa_ss[k];
+            const double tot = sa_rz[k] + sa_ss[k];
+            double v = (tot > 0 ? msa_rz[k] * (sa_rz[k] / tot) + msa_ss[k] * (sa_ss[k] / tot) : 0);
+            msa_s[k] = isnan(v) ? 0 : v;
+        }
+        msa_s[0] = 0;
+        P->C_s[i] = conc_storage(sa_s, msa_s, A, work);
+        P->C_iso_s[i] = conc_to_delta(P, P->C_s[i]) * mk;
+    }
+    free(work);
 }
 
 /* one day of svat_transport_model_deterministic for all columns */

@@ -158,7 +158,8 @@ SAS_DECLARED_SYMBOLS = (
 )
 
 # stage bits of rh_sas_stages (include/roger_hip_sas.h)
-SAS_STAGES = dict(INF_RZ=1, EVAP=2, TRANSP=4, Q_RZ=8, INF_SS=16, Q_SS=32, CPR=64, STORAGE=128, AGEING=256, ALL=511)
+SAS_STAGES = dict(INF_RZ=1, EVAP=2, TRANSP=4, Q_RZ=8, INF_SS=16, Q_SS=32, CPR=64, STORAGE=128, AGEING=256, ALL=511,
+                  RESCALE=512)
 
 
 class SasContext:

@@ -17,3 +17,17 @@ def calculate_initial_conditions(state):
     """roger/core/soil.py:995-1010 (+ surface.calc_initial_conditions_surface_kernel)"""
     numerics.validate_initial_conditions_soil(state)
     run_native(state, "rh_initial_conditions")
+
+
+def rescale_SA(state):
+    """roger/core/soil.py:1650-1671 for oxygen-18: rescale_sa_msa_iso_soil_kernel as one native launch
+    (rh_sas_stages with RH_SAS_RESCALE)."""
+    from .. import _native
+
+    sas = state.sas_context
+    if sas is None:
+        raise RuntimeError("rescale_SA needs settings.enable_offline_transport")
+    vs = state.variables
+    vs.flush_to_device()
+    sas.stages(0, _native.SAS_STAGES["RESCALE"])
+    vs.mark_device_newer(["sa_rz", "sa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"])

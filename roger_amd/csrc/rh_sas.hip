@@ -800,6 +800,52 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
         }
     }
 
+    if (P.stages & RH_SAS_RESCALE) {
+        // rescale_sa_msa_iso_soil_kernel, core/soil.py:1250-1395 (no maskCatch on sa and C here, as in the reference)
+        const double S_rz_init = ((const double *)P.a[SA_S_rz_init])[cell], S_ss_init = ((const double *)P.a[SA_S_ss_init])[cell];
+        double t[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            t[0] += sa_rz[j];
+            t[1] += sa_ss[j];
+        }
+        blk_sum<W, 2>(B, t);
+        double sa_s[E], msa_s[E], s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool in = base + j < A;
+            sa_rz[j] = in ? S_rz_init * (sa_rz[j] / t[0]) : 0.0;
+            sa_ss[j] = in ? S_ss_init * (sa_ss[j] / t[1]) : 0.0;
+            sa_s[j] = sa_rz[j] + sa_ss[j];
+            const double tot = sa_rz[j] + sa_ss[j];
+            const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
+            msa_s[j] = ((v != v) || (base + j == 0)) ? 0 : v;
+            s[0] += msa_rz[j] * sa_rz[j];
+            s[1] += sa_rz[j];
+            s[2] += msa_ss[j] * sa_ss[j];
+            s[3] += sa_ss[j];
+            s[4] += msa_s[j] * sa_s[j];
+            s[5] += sa_s[j];
+        }
+        blk_sum<W, 6>(B, s);
+        if (B.tid == 0) {
+            for (int k = 0; k < 3; ++k) {
+                const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
+                ((double *)P.a[SA_C_rz + k])[cell] = C;
+                ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+            }
+        }
+        if (P.diag) {
+            double *o0 = (double *)P.a[SA_sa_s] + cell * A, *o1 = (double *)P.a[SA_msa_s] + cell * A;
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (base + j < A) {
+                    o0[base + j] = sa_s[j];
+                    o1[base + j] = msa_s[j];
+                }
+        }
+    }
+
     if (P.stages & RH_SAS_AGEING) {
         ageing<W, E>(B, A, base, sa_rz, msa_rz);
         ageing<W, E>(B, A, base, sa_ss, msa_ss);
@@ -1053,7 +1099,7 @@ void *rh_sas_array_device_ptr(rh_sas_ctx *ctx, int a) { return (ctx && a >= 0 &&
 int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     if (!ctx) return RH_ERR_ARG;
     if (day < 0) return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: negative day");
-    if ((stages & ~RH_SAS_ALL) || !stages) return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: bad stage mask");
+    if ((stages & ~(RH_SAS_ALL | RH_SAS_RESCALE)) || !stages) return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: bad stage mask");
     const rh_sas_config &c = ctx->cfg;
     if ((stages & RH_SAS_STORAGE) && c.age_statistics && !c.keep_distributions &&
         (!(stages & RH_SAS_TRANSP) || !(stages & RH_SAS_Q_SS)))

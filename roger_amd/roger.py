@@ -144,11 +144,18 @@ class RogerSetup(metaclass=abc.ABCMeta):
                 state.settings.warmup_done = True
 
     def warmup(self, repeat=1):
-        """roger/roger.py:491-521.  The transport warm-up (repeated runs + soil.rescale_SA) is not part of the native
-        path; without it the model starts from the initial conditions of the setup script."""
-        if self.state.settings.enable_offline_transport and repeat > 0:
-            raise NotImplementedError("warmup(repeat > 0) needs soil.rescale_SA, which the hip backend does not implement; "
-                                      "call warmup(repeat=0) to start from the initial conditions")
+        """roger/roger.py:491-521: for offline transport `repeat` whole runs, each followed by soil.rescale_SA, then
+        itt = time = 0; warmup_done is set either way."""
+        from .core import soil
+
+        if self.state.settings.enable_offline_transport:
+            with self.state.timers["warmup"]:
+                for _ in range(repeat):
+                    self.run()
+                    soil.rescale_SA(self.state)
+                with self.state.variables.unlock():
+                    self.state.variables.itt = 0
+                    self.state.variables.time = 0
         with self.state.settings.unlock():
             self.state.settings.warmup_done = True
 
@@ -212,7 +219,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
         """roger/roger.py:523-580"""
         self._ensure_setup_done()
         vs = self.state.variables
-        runlen = self.state.settings.runlen
+        settings = self.state.settings
+        runlen = settings.runlen if settings.warmup_done else settings.runlen_warmup   # roger/roger.py:541-546
         start_time = vs.time
         while vs.time - start_time < runlen:
             self.step(self.state)

@@ -158,8 +158,10 @@ def build_transport_variables(settings):
     V["C_iso_in"] = Variable("C_iso_in", CATCH_GRID)
     for name in ("prec", "S_snow", "C_snow", "C_iso_snow"):
         V[name] = Variable(name, CATCH_GRID + TIMESTEPS)
-    for name in ("S_pwp_rz", "S_pwp_ss", "S_sat_rz", "S_sat_ss", "S_rz_init", "S_ss_init"):
+    for name in ("S_pwp_rz", "S_pwp_ss", "S_sat_rz", "S_sat_ss"):
         V[name] = Variable(name, CATCH_GRID)
+    for name in ("S_rz_init", "S_ss_init"):
+        V[name] = Variable(name, CATCH_GRID, sas=name)
     for name in ("PREC_DIST_DAILY", "INF_MAT_RZ", "INF_PF_RZ", "INF_PF_SS", "TRANSP", "EVAP_SOIL", "CPR_RZ", "Q_RZ", "Q_SS",
                  "S_RZ", "S_SS", "S_S", "S_SNOW", "C_IN", "C_ISO_IN"):
         V[name] = Variable(name, CATCH_GRID + ("t",))

@@ -71,8 +71,8 @@ def run_svat_daily(roger, params, forcing, ndays):
 from sas_scripts import make_transport_model as _make_transport_model  # noqa: E402  (tests/ is on sys.path)
 
 
-def make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics):
-    return _make_transport_model("roger", svat, sas, ages, substeps, ndays, age_statistics)
+def make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0):
+    return _make_transport_model("roger", svat, sas, ages, substeps, ndays, age_statistics, warmup_days)
 
 
 def grab(vs, names, stats):
@@ -130,7 +130,7 @@ def sas_params(nx, ny, variant, seed):
     return out
 
 
-def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed):
+def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed, warmup=False):
     from roger_amd.forcing import combo_forcing
 
     params = hetero_params(nx, ny, seed=seed)
@@ -139,12 +139,26 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     rng = np.random.default_rng(seed + 7)
     svat["d18O_prec"] = np.concatenate([[np.nan], rng.uniform(-12, -4, ndays)])
     sas = sas_params(nx, ny, variant, seed)
-    model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics)
+    model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0)
     model.setup()
-    with model.state.settings.unlock():
-        model.state.settings.warmup_done = True   # no warm-up / rescaling: the step itself is what is pinned
     vs = model.state.variables
     rec = {"meta": np.array([nx, ny, ndays, ages, substeps, int(age_statistics)])}
+    if warmup:
+        # RogerSetup.warmup (roger/roger.py:491-521): one whole run, soil.rescale_SA, itt = time = 0.  The state right
+        # before the rescaling is recorded too, so that the rescaling kernel can be pinned on its own.
+        from roger.core import soil as ref_soil
+
+        model.run()
+        for k, v in grab(vs, None, False).items():
+            rec[f"w000_{k}"] = v
+        ref_soil.rescale_SA(model.state)
+        with vs.unlock():
+            vs.itt = 0
+            vs.time = 0
+        for k in ("S_rz_init", "S_ss_init"):
+            rec[k] = np.asarray(getattr(vs, k))[2:-2, 2:-2].reshape(-1)
+    with model.state.settings.unlock():
+        model.state.settings.warmup_done = True
     for k, v in svat.items():
         rec[f"in_{k}"] = np.asarray(v)
     for flux, arr in sas.items():
@@ -176,11 +190,12 @@ def main():
         "sas_mixed_a70": (2, 2, 16, 70, 4, "mixed", False, 5),
         "sas_stats_a30": (2, 2, 12, 30, 3, "mixed", True, 11),
         "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
+        "sas_warmup_a30": (2, 2, 10, 30, 3, "power", False, 23, True),
     }
-    for name, (nx, ny, ndays, ages, substeps, variant, stats, seed) in cases.items():
+    for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:
             continue
-        run_case(roger, name, nx, ny, ndays, ages, substeps, variant, stats, args.out, seed)
+        run_case(roger, name, nx, ny, ndays, ages, substeps, variant, stats, args.out, seed, *rest)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,7 @@ class OracleSasContext:
         out.update(st.state)
         out.update(st.inp)
         out.update({f"sas_params_{f}": a for f, a in st.sas.items()})
+        out.update(st.S_init)
         out.update(st.out)
         return out
 
@@ -49,6 +50,14 @@ class OracleSasContext:
 
     def step(self, day):
         self.st.step_oracle()
+
+    def stages(self, day, mask):
+        if mask == 511:
+            self.st.step_oracle()
+        elif mask == 512:
+            self.st.rescale_oracle()
+        else:
+            raise NotImplementedError("the oracle stand-in runs whole days and the rescaling only")
 
     def sync(self):
         pass

@@ -15,7 +15,7 @@ FLUXES = ("evap_soil", "transp", "q_rz", "q_ss", "cpr_rz")          # order of t
 INFS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss")
 STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
-SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50")
+SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30")
 
 _P = C.POINTER(C.c_double)
 
@@ -34,6 +34,7 @@ class OcSas(C.Structure):
         ("sa_s", _P), ("msa_s", _P),
         ("C_rz", _P), ("C_ss", _P), ("C_s", _P), ("C_iso_rz", _P), ("C_iso_ss", _P), ("C_iso_s", _P),
         ("stats", (_P * 6) * 5),
+        ("S_rz_init", _P), ("S_ss_init", _P),
     ]
 
 
@@ -72,6 +73,7 @@ class SasState:
         self.state = {k: z(n, A) for k in ("sa_rz", "msa_rz", "sa_ss", "msa_ss")}
         self.inp = {k: z(n) for k in INFS + FLUXES + ("C_in",)}
         self.sas = {f: z(n, 8) for f in FLUXES}
+        self.S_init = {"S_rz_init": z(n), "S_ss_init": z(n)}
         self.out = {}
         for f in FLUXES:
             self.out[f"tt_{f}"] = z(n, A)
@@ -114,10 +116,14 @@ class SasState:
             for i, (w, p) in enumerate(STAT_TARGETS):
                 for j, q in enumerate(STAT_Q):
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
+        s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
         return s
 
     def step_oracle(self):
         lib().oc_sas_step(C.byref(self.struct()))
+
+    def rescale_oracle(self):
+        lib().oc_sas_rescale(C.byref(self.struct()))
 
 
 class SasGolden:

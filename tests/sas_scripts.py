@@ -11,7 +11,7 @@ of a SVAT run as input, the snow signal mixed in `set_forcing`.
 import importlib
 
 
-def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics):
+def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0):
     top = importlib.import_module(pkg)
     RogerSetup, roger_kernel, roger_routine, KernelOutput = top.RogerSetup, top.roger_kernel, top.roger_routine, top.KernelOutput
     allocate = importlib.import_module(pkg + ".variables").allocate
@@ -31,7 +31,7 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics):
             s.sas_solver_substeps = substeps
             s.nx, s.ny = nx, ny
             s.runlen = 24 * 60 * 60 * ndays
-            s.runlen_warmup = 0
+            s.runlen_warmup = 24 * 60 * 60 * warmup_days
             s.nitt = ndays + 1
             s.ages = ages
             s.nages = ages + 1

@@ -49,3 +49,22 @@ def test_transport_setup_on_device(case):
     model.step(model.state)
     assert (interior(vs.tt_transp) == 0).all() and np.isnan(interior(vs.C_transp)).all()
     model.state.sas_context.close()
+
+
+def test_transport_warmup_on_device():
+    """setup(); warmup(); run() as benchmarks/SVATOXYGEN18_benchmark.py:483-485 does, with a real warm-up run."""
+    g = sb.SasGolden("sas_warmup_a30")
+    svat, sas = golden_inputs(g)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=g.ndays)
+    model.setup()
+    model.warmup()
+    vs = model.state.variables
+    assert vs.itt == 0 and vs.time == 0 and model.state.settings.warmup_done
+    for k in ("sa_rz", "sa_ss"):
+        assert np.isclose(interior(getattr(vs, k), 1), g.day(0, k), rtol=5e-3, atol=5e-3).all(), k
+        assert np.allclose(interior(getattr(vs, k), 1).sum(axis=1), g.z["S" + k[2:] + "_init"], rtol=1e-12)
+    model.run()
+    assert vs.itt == g.ndays
+    for k in ("sa_rz", "sa_ss"):
+        assert np.isclose(interior(getattr(vs, k), 1), g.day(g.ndays, k), rtol=5e-3, atol=5e-3).all(), k
+    model.state.sas_context.close()

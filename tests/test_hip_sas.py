@@ -283,3 +283,22 @@ def test_full_size_properties():
     out_max = sum(d4[k][:2].sum(axis=0) for k in ("evap_soil", "transp", "q_ss"))
     assert (stored <= S_rz + S_ss + inflow + 1e-6).all() and (stored >= S_rz + S_ss + inflow - out_max - 1e-6).all()
     ctx.close()
+
+
+def test_rescale_after_warmup():
+    """soil.rescale_SA on the device (RH_SAS_RESCALE): the reference's state after its warm-up run -> rescaled state."""
+    from roger_amd._native import SAS_STAGES
+
+    g = SasGolden("sas_warmup_a30")
+    st = g.new_state()
+    ctx = make_ctx(st)
+    for k in st.state:
+        ctx.upload(k, g.z[f"w000_{k}"])
+    for k in ("S_rz_init", "S_ss_init"):
+        ctx.upload(k, g.z[k])
+    ctx.stages(0, SAS_STAGES["RESCALE"])
+    for k in ("sa_rz", "sa_ss", "sa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"):
+        compare_sas(ctx.download(k), g.day(0, k), f"rescale {k}")
+    for k in ("msa_rz", "msa_ss", "msa_s"):
+        compare_msa(ctx.download(k), g.day(0, k), g.day(0, k[1:]), f"rescale {k}")
+    ctx.close()

@@ -22,10 +22,16 @@ def interior(a, lvl=None):
     return a.reshape((-1,) + a.shape[2:])
 
 
-def run_and_compare(g, model, first_tie=None):
+def run_and_compare(g, model, first_tie=None, warmup=0):
     model.setup()
-    model.warmup(repeat=0)
+    model.warmup(repeat=warmup)
     vs = model.state.variables
+    assert vs.itt == 0 and vs.time == 0 and model.state.settings.warmup_done
+    if warmup:
+        for k in ("sa_rz", "sa_ss"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"after warm-up {k}")
+        for k in ("C_rz", "C_iso_ss", "C_s"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"after warm-up {k}")
     for d in range(1, g.ndays + 1):
         model.step(model.state)
         assert vs.itt == d and vs.time == d * 86400
@@ -66,6 +72,15 @@ def test_transport_setup_through_host_package(oracle_sas, case):
     run_and_compare(g, model, first_tie=sb.FIRST_TIE.get(case))
 
 
+def test_transport_warmup_and_run(oracle_sas):
+    """setup(); warmup(); run() -- the call sequence of benchmarks/SVATOXYGEN18_benchmark.py:483-485: one whole run,
+    soil.rescale_SA, clock reset, then the run proper."""
+    g = sb.SasGolden("sas_warmup_a30")
+    svat, sas = golden_inputs(g)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=g.ndays)
+    run_and_compare(g, model, warmup=1)
+
+
 def test_transport_settings_are_checked(oracle_sas):
     g = sb.SasGolden("sas_stats_a30")
     svat, sas = golden_inputs(g)
@@ -77,8 +92,6 @@ def test_transport_settings_are_checked(oracle_sas):
             override=dict(enable_oxygen18=False)).setup()
     m = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False)
     m.setup()
-    with pytest.raises(NotImplementedError, match="rescale_SA"):
-        m.warmup(repeat=1)
     with pytest.raises(ValueError, match="unexpected shape"):
         with m.state.variables.unlock():
             m.state.variables.sa_rz = np.zeros((3, 3))

@@ -87,3 +87,23 @@ def test_cases_present():
         tot = sum(np.nansum(g.day(d, f"tt_{f}")) for d in range(1, g.ndays + 1))
         assert tot > 0, f
     assert np.isfinite(g.day(g.ndays, "C_iso_q_ss")).any()
+
+
+def test_rescale_after_warmup():
+    """soil.rescale_SA (rescale_sa_msa_iso_soil_kernel, core/soil.py:1250-1395): the reference's state after its
+    warm-up run (w000_*) -> rescaled state (d000_*)."""
+    g = SasGolden("sas_warmup_a30")
+    st = g.new_state()
+    for k in st.state:
+        st.state[k][:] = g.z[f"w000_{k}"]
+    for k in st.S_init:
+        st.S_init[k][:] = g.z[k]
+    st.rescale_oracle()
+    for k in ("sa_rz", "sa_ss"):
+        compare_sas(st.state[k], g.day(0, k), f"rescale {k}")
+        compare_msa(st.state["m" + k], g.day(0, "m" + k), g.day(0, k), f"rescale m{k}")
+    compare_sas(st.out["sa_s"], g.day(0, "sa_s"), "rescale sa_s")
+    compare_msa(st.out["msa_s"], g.day(0, "msa_s"), g.day(0, "sa_s"), "rescale msa_s")
+    for k in ("C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"):
+        compare_sas(st.out[k], g.day(0, k), f"rescale {k}")
+    assert abs(st.state["sa_rz"].sum(axis=1) - g.z["S_rz_init"]).max() < 1e-9
