@@ -2,10 +2,11 @@
 
 Decomposition API follows the reference (roger/distributed.py:121-187): `num_proc = (px, py)`,
 ranks laid out x-fastest, even divisibility required, chunk slices with or without the 2-cell
-overlap.  On this path columns never read their neighbours, so no halo is exchanged; what the
-reference does per step -- gather 18 fields to rank 0, decide dt there, scatter back
-(adaptive_time_stepping_dist_safe.py:6-26) -- is replaced by two all-reduces of 64 predicate
-bits (as 64 int32, MAX) between the three phases of the native step.
+overlap, process neighbours, `exchange_overlap` for the 2-cell ghost frame, global reductions.  On
+this path columns never read their neighbours, so no halo is exchanged; what the reference does per
+step -- gather 18 fields to rank 0, decide dt there, scatter back
+(adaptive_time_stepping_dist_safe.py:6-26) -- is replaced by one all-reduce of 64 predicate bits
+(as 64 int32, MAX) per step.
 """
 
 
@@ -46,6 +47,99 @@ def get_chunk_slices(nx, ny, num_proc, rank, include_overlap=False):
         sxu, syu = nxl, nyl
     return ((slice(sxl + px * nxl, sxu + px * nxl), slice(syl + py * nyl, syu + py * nyl)),
             (slice(sxl, sxu), slice(syl, syu)))
+
+
+def get_process_neighbors(rank, num_proc):
+    """Ranks of the eight neighbours (None at the domain edge); roger/distributed.py:190-220."""
+    px, py = proc_rank_to_index(rank, num_proc)
+    west = px - 1 if px != 0 else None
+    east = px + 1 if px != num_proc[0] - 1 else None
+    south = py - 1 if py != 0 else None
+    north = py + 1 if py != num_proc[1] - 1 else None
+    idx = dict(west=(west, py), south=(px, south), east=(east, py), north=(px, north), southwest=(west, south),
+               southeast=(east, south), northeast=(east, north), northwest=(west, north))
+    return {k: (proc_index_to_rank(*i, num_proc) if None not in i else None) for k, i in idx.items()}
+
+
+_SEND_ORDER = ("west", "northwest", "north", "northeast", "east", "southeast", "south", "southwest")
+_RECV_ORDER = ("east", "southeast", "south", "southwest", "west", "northwest", "north", "northeast")
+_FROM = dict(west=(slice(2, 4), slice(None)), south=(slice(None), slice(2, 4)), east=(slice(-4, -2), slice(None)),
+             north=(slice(None), slice(-4, -2)), southwest=(slice(2, 4), slice(2, 4)), southeast=(slice(-4, -2), slice(2, 4)),
+             northeast=(slice(-4, -2), slice(-4, -2)), northwest=(slice(2, 4), slice(-4, -2)))
+_TO = dict(west=(slice(0, 2), slice(None)), south=(slice(None), slice(0, 2)), east=(slice(-2, None), slice(None)),
+           north=(slice(None), slice(-2, None)), southwest=(slice(0, 2), slice(0, 2)), southeast=(slice(-2, None), slice(0, 2)),
+           northeast=(slice(-2, None), slice(-2, None)), northwest=(slice(0, 2), slice(-2, None)))
+
+
+def exchange_overlap(arr, num_proc, group=None):
+    """Fill the 2-cell ghost frame of an (x, y, ...) array from the neighbouring ranks' interiors, non-periodic
+    (roger/distributed.py:223-331, the (x, y) case; same send / receive order).  `arr` is a torch tensor on the
+    rank's device -- RCCL moves it over xGMI between GPUs, gloo between CPU ranks -- or a numpy array (a new array
+    is returned).  Nothing on the SVAT / oneD / transport paths of the BASELINE configs calls this (columns do not
+    read their neighbours, routing is off); it completes the decomposition API for setups that do."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return arr
+    is_np = isinstance(arr, np.ndarray)
+    t = torch.from_numpy(np.array(arr)) if is_np else arr
+    nb = get_process_neighbors(dist.get_rank(group), num_proc)
+    for send_dir, recv_dir in zip(_SEND_ORDER, _RECV_ORDER):
+        send_proc, recv_proc = nb[send_dir], nb[recv_dir]
+        if send_proc is None and recv_proc is None:
+            continue
+        ops, recv_buf = [], None
+        if send_proc is not None:
+            ops.append(dist.P2POp(dist.isend, t[_FROM[send_dir]].contiguous(), send_proc, group))
+        if recv_proc is not None:
+            recv_buf = torch.empty_like(t[_TO[recv_dir]]).contiguous()
+            ops.append(dist.P2POp(dist.irecv, recv_buf, recv_proc, group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if recv_buf is not None:
+            t[_TO[recv_dir]] = recv_buf
+    return t.numpy() if is_np else t
+
+
+def _reduce(value, op, group=None):
+    """Scalar reduction over the ranks; roger/distributed.py:357-416."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=op, group=group)
+    return type(value)(t.item()) if isinstance(value, (bool, int, float)) else t.item()
+
+
+def global_and(value, group=None):
+    import torch.distributed as dist
+    return bool(_reduce(float(bool(value)), dist.ReduceOp.MIN, group))
+
+
+def global_or(value, group=None):
+    import torch.distributed as dist
+    return bool(_reduce(float(bool(value)), dist.ReduceOp.MAX, group))
+
+
+def global_max(value, group=None):
+    import torch.distributed as dist
+    return _reduce(value, dist.ReduceOp.MAX, group)
+
+
+def global_min(value, group=None):
+    import torch.distributed as dist
+    return _reduce(value, dist.ReduceOp.MIN, group)
+
+
+def global_sum(value, group=None):
+    import torch.distributed as dist
+    return _reduce(value, dist.ReduceOp.SUM, group)
 
 
 class PhasedStepper:
