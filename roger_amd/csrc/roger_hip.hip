@@ -136,15 +136,18 @@ RH_DEV void wave_or_store(unsigned long long *wave_slots, unsigned long long bit
 RH_DEV unsigned long long reduce_bflags(const unsigned long long *bf, int nblk) {
     __shared__ unsigned long long wv[RH_BLOCK / 64];
     unsigned long long b = 0;
-    // eight independent loads in flight per thread: a single workgroup reading tens of thousands of words one
-    // dependent load at a time is latency-bound (25 us for 15 000 words)
-    int k = threadIdx.x;
-    for (; k + 7 * RH_BLOCK < nblk; k += 8 * RH_BLOCK) {
-        const unsigned long long v0 = bf[k], v1 = bf[k + RH_BLOCK], v2 = bf[k + 2 * RH_BLOCK], v3 = bf[k + 3 * RH_BLOCK];
-        const unsigned long long v4 = bf[k + 4 * RH_BLOCK], v5 = bf[k + 5 * RH_BLOCK], v6 = bf[k + 6 * RH_BLOCK], v7 = bf[k + 7 * RH_BLOCK];
-        b |= ((v0 | v1) | (v2 | v3)) | ((v4 | v5) | (v6 | v7));
+    // 32 independent loads in flight per thread: the words were written by other CUs (other XCDs' L2s), a single
+    // workgroup reading 15 000 of them a few dependent loads at a time is latency-bound (2 us per round trip)
+    for (int k = threadIdx.x; k < nblk; k += 32 * RH_BLOCK) {
+        unsigned long long v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int idx = k + j * RH_BLOCK;
+            v[j] = idx < nblk ? bf[idx] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) b |= v[j];
     }
-    for (; k < nblk; k += RH_BLOCK) b |= bf[k];
     for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
     if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = b;
     __syncthreads();
@@ -353,7 +356,7 @@ RH_DEV void agg_body(DevState *D) {
         const bool cond3 = any_p_gthpi && any_p_gt0 && snow_any;
         const bool cond4 = all_p_lehpi && any_p_gt0 && snow_any;
         const bool cond5 = all_p_le0 && snow_any;
-        StepCtx &X = D->X;
+        StepCtx X = D->X;
         X.cond_time = (D->S.time % 86400 == 0);
         X.sel_daily = cond0 || cond00;
         X.sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
@@ -390,6 +393,7 @@ RH_DEV void agg_body(DevState *D) {
                 X.ta_sel = X.agg[3 * X.sel_p + 1];
             }
         }
+        D->X = X;
     }
 }
 __global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int do_reduce) {
@@ -448,9 +452,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
 }
 
 // infiltration.py:2155-2167 from the predicate word and the event ids
-RH_DEV void infiltration_conds(DevState *D, unsigned long long w) {
-    const rh_scalars &S = D->S;
-    StepCtx &X = D->X;
+RH_DEV void infiltration_conds(const rh_scalars &S, StepCtx &X, unsigned long long w) {
     X.cond1 = (S.event_id[0] == 0) && (S.event_id[1] >= 1);
     X.cond2 = bit(w, PC_P_EQ0) && bit(w, PC_PM1_NE0) && (S.event_id[0] >= 1);
     X.cond3 = bit(w, PC_P_NE0) && bit(w, PC_PM1_EQ0) && (S.event_id[0] == S.event_id[1]);
@@ -469,8 +471,10 @@ __global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce
 }
 // one thread
 RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel) {
-    rh_scalars &S = D->S;
-    StepCtx &X = D->X;
+    // one burst of loads, the bookkeeping in registers, one burst of stores: working on D->S / D->X in place costs a
+    // global-memory round trip per field for this single thread (the control kernel took 20 us that way)
+    rh_scalars S = D->S;
+    StepCtx X = D->X;
     X.apply_sel = apply_sel;
     const bool ev_start = bit(w, PC_RAIN) || bit(w, PC_SNOWMELT);
     const bool ev_end = !bit(w, PC_PREC_NOT_LE0) || !bit(w, PC_NOT_PGT0_TALE) || (bit(w, PC_SWEM1_GT0) && !bit(w, PC_SWE_NOT_LE0));
@@ -502,7 +506,7 @@ RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int a
     }
     X.dt = dt;
     X.month_tau = S.month[1];
-    infiltration_conds(D, w);
+    infiltration_conds(S, X, w);
     D->words[0] = 0;
     D->words[1] = 0;
     D->words[2] = 0;
@@ -517,6 +521,8 @@ RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int a
         S.month[0] = S.month[1];
         S.doy[0] = S.doy[1];
     }
+    D->S = S;
+    D->X = X;
 }
 
 // ---- summary path (shared forcing): the whole control part of a step in ONE single-workgroup kernel ----------
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_inf_pred(Arena a, DevState *D) {
     wave_or_to(&D->words[3], b);
 }
 __global__ void k_inf_conds(DevState *D) {
-    infiltration_conds(D, D->words[3]);
+    infiltration_conds(D->S, D->X, D->words[3]);
     D->words[3] = 0;
 }
 
