@@ -175,7 +175,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
                 "launches_timed": launches,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cells = max(8, min(n, int(args.cpu_cells) // 25))
             days = min(ndays_resident, args.steps + args.warmup, 4)
             v, secs = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily)
@@ -328,7 +328,7 @@ def main():
                 "launches_timed": launches,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cpu_steps = min(args.steps + args.warmup, 60)
             v, secs = cpu_baseline(args.cpu_cells, cpu_steps, forcing)
             out["cpu_baseline"] = {
