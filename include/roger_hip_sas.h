@@ -122,6 +122,9 @@ int rh_sas_timing_summary(rh_sas_ctx *ctx, double *total_ms, int64_t *launches);
 /* Diagnostic: the kernel's x**k routine (power-law SAS function, core/sas.py:228-231) on n host values,
  * 0 < x <= 1; lets the tests bound its error against the host's pow directly.  Uses the current device. */
 int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n);
+/* Diagnostic: the kernel's division by a loop-invariant divisor (hoisted refined reciprocal + one residual step),
+ * out = a / d, to be compared bit for bit with the host's IEEE division. */
+int rh_sas_selftest_div(const double *a, const double *d, double *out, int64_t n);
 
 #ifdef __cplusplus
 }

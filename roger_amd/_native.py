@@ -146,6 +146,7 @@ def _declare_sas(lib):
     lib.rh_sas_step.argtypes = [vp, i64]
     lib.rh_sas_run_days.argtypes = [vp, i64, i64]
     lib.rh_sas_selftest_pow.argtypes = [vp, vp, vp, i64]
+    lib.rh_sas_selftest_div.argtypes = [vp, vp, vp, i64]
     lib.rh_sas_enable_timing.argtypes = [vp, i32]
     lib.rh_sas_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 
@@ -154,7 +155,7 @@ SAS_DECLARED_SYMBOLS = (
     "rh_sas_default_config", "rh_sas_create", "rh_sas_destroy", "rh_sas_last_error", "rh_sas_set_stream",
     "rh_sas_sync", "rh_sas_num_arrays", "rh_sas_array_name", "rh_sas_array_index", "rh_sas_array_elems",
     "rh_sas_array_is_int", "rh_sas_upload", "rh_sas_download", "rh_sas_upload_cells", "rh_sas_download_cells", "rh_sas_set_daily_from_device", "rh_sas_array_device_ptr", "rh_sas_stages",
-    "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary", "rh_sas_selftest_pow",
+    "rh_sas_step", "rh_sas_run_days", "rh_sas_enable_timing", "rh_sas_timing_summary", "rh_sas_selftest_pow", "rh_sas_selftest_div",
 )
 
 # stage bits of rh_sas_stages (include/roger_hip_sas.h)
@@ -275,6 +276,18 @@ class SasContext:
         ms, cnt = C.c_double(), C.c_int64()
         self._check(self._lib.rh_sas_timing_summary(self._h, C.byref(ms), C.byref(cnt)), "rh_sas_timing_summary")
         return ms.value, cnt.value
+
+
+def sas_selftest_div(a, d):
+    """a / d by the SAS kernel's hoisted-reciprocal division (rh_sas_selftest_div)."""
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    d = np.ascontiguousarray(np.broadcast_to(d, a.shape), dtype=np.float64)
+    out = np.empty_like(a)
+    rc = lib.rh_sas_selftest_div(a.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.size)
+    if rc != 0:
+        raise NativeError(f"rh_sas_selftest_div failed ({rc})")
+    return out
 
 
 def sas_selftest_pow(x, k):

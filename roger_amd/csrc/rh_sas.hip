@@ -43,6 +43,25 @@
 #ifndef RH_SAS_POW
 #define RH_SAS_POW 3
 #endif
+// Division by a divisor that is uniform over many quotients (flux * h inside the sub-step loop): the compiler's
+// IEEE division is  rcp -> two Newton steps on the reciprocal -> q0 = a * r -> e = fma(-d, q0, a) -> fma(e, r, q0)
+// wrapped in v_div_scale / v_div_fixup for operands near the exponent limits.  With the refined reciprocal hoisted
+// out of the loop a quotient costs three instructions instead of twelve and has the same bits as `a / d` whenever
+// no scaling is needed (d and a / d within ~1e+-290, true for millimetres per day).
+struct UDiv {
+    double d, r;
+};
+SAS_DEV UDiv udiv_prepare(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    return UDiv{d, r};
+}
+SAS_DEV double udiv(double a, const UDiv &u) {
+    const double q0 = a * u.r;
+    return __builtin_fma(__builtin_fma(-u.d, q0, a), u.r, q0);
+}
+
 // Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
 // operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
 __constant__ double SAS_LOG_C[9] = {2.0 / 19.0, 2.0 / 17.0, 2.0 / 15.0, 2.0 / 13.0, 2.0 / 11.0, 2.0 / 9.0, 2.0 / 7.0, 2.0 / 5.0, 2.0 / 3.0};
@@ -360,6 +379,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
     constexpr bool uniform = FAM == FAM_UNIFORM, power = FAM == FAM_POWER, dirac = FAM == FAM_DIRAC;
     constexpr bool kumaraswami = FAM == FAM_KUMARASWAMI, expo = FAM == FAM_EXPONENTIAL;
     const PowConsts C = load_pow_consts();
+    const UDiv by_fh = udiv_prepare(fh);
     double Om_edge0 = 0.0;  // Omega at SA[0] = 0: 0 for every family but a dirac with a negative threshold
     double san[E], ttn[E];
 #pragma unroll
@@ -454,7 +474,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
             const double d = Om[j] - (j == 0 ? Om_lo : Om[j - 1]);
             double t = (d >= 0 ? d : 0);                                       // :430-433
             const double q = (flux * t * h > san[j] ? san[j] : flux * t * h);   // :435-438
-            t = q / fh;                                                         // :440-443 (fh > 0 here)
+            t = udiv(q, by_fh);                                                 // :440-443: q / (flux * h), fh > 0 here
             san[j] = san[j] + -t * flux * h;                                    // :445-448
             tti[j] = t;
         }
@@ -865,6 +885,10 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     }
 }
 
+__global__ void k_selftest_div(const double *a, const double *d, double *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = udiv(a[i], udiv_prepare(d[i]));
+}
 __global__ void k_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const PowConsts C = load_pow_consts();
@@ -1158,7 +1182,10 @@ int rh_sas_run_days(rh_sas_ctx *ctx, int64_t day0, int64_t ndays) {
     return RH_OK;
 }
 
-int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
+static int selftest2(const double *x, const double *k, double *out, int64_t n, int which);
+int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n) { return selftest2(x, k, out, n, 0); }
+int rh_sas_selftest_div(const double *a, const double *d, double *out, int64_t n) { return selftest2(a, d, out, n, 1); }
+static int selftest2(const double *x, const double *k, double *out, int64_t n, int which) {
     if (!x || !k || !out || n <= 0) return RH_ERR_ARG;
     double *d = nullptr;
     if (hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)) != hipSuccess) return RH_ERR_HIP;
@@ -1167,7 +1194,10 @@ int rh_sas_selftest_pow(const double *x, const double *k, double *out, int64_t n
         hipMemcpy(d + n, k, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         rc = RH_ERR_HIP;
     if (rc == RH_OK) {
-        hipLaunchKernelGGL(k_selftest_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
+        if (which == 0)
+            hipLaunchKernelGGL(k_selftest_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
+        else
+            hipLaunchKernelGGL(k_selftest_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(out, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
             rc = RH_ERR_HIP;

@@ -302,3 +302,19 @@ def test_rescale_after_warmup():
     for k in ("msa_rz", "msa_ss", "msa_s"):
         compare_msa(ctx.download(k), g.day(0, k), g.day(0, k[1:]), f"rescale {k}")
     ctx.close()
+
+
+def test_hoisted_division_is_ieee_division():
+    """The sub-step loop divides by flux * h through a hoisted refined reciprocal (rh_sas.hip: udiv); its quotients
+    must be the correctly rounded ones, bit for bit, over the operand range of the loop (q from 0 and 1e-18 mm up,
+    flux * h from 1e-6 to 1e2 mm)."""
+    from roger_amd import _native
+
+    rng = np.random.default_rng(1)
+    n = 400_000
+    d = 10.0 ** rng.uniform(-6, 2, n)
+    a = np.concatenate([10.0 ** rng.uniform(-18, 3, n - 4), [0.0, 1e-300, 5.0, 7.25]])
+    a[: n // 4] = d[: n // 4] * rng.uniform(0, 1, n // 4)          # q = flux * t * h with t in [0, 1]
+    got = _native.sas_selftest_div(a, d)
+    want = a / d
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {n} quotients differ"
