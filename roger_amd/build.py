@@ -28,7 +28,7 @@ def _newer(target, sources):
 
 def build_native(force=False, verbose=False):
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_sets.py")], check=True)
-    sources = [os.path.join(CSRC, f) for f in ("roger_hip.hip", "rh_sas.hip", "rh_physics.h", "rh_col.h", "rh_sets.inc")]
+    sources = [os.path.join(CSRC, f) for f in ("roger_hip.hip", "rh_sas.hip", "rh_physics.h", "rh_col.h", "rh_sets.inc", "rh_sas_tables.inc")]
     sources += [os.path.join(REPO, "include", f) for f in ("roger_hip.h", "rh_fields.def", "roger_hip_sas.h",
                                                            "rh_sas_arrays.def")]
     if force or _newer(LIB, sources):

@@ -64,21 +64,53 @@ SAS_DEV double udiv(double a, const UDiv &u) {
 
 // Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
 // operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
+#include "rh_sas_tables.inc"
+// RH_SAS_LOG: 1 = table-assisted log2 (64-entry table of {1/c, log2 c} in LDS, degree-8 log2(1 + r)); 0 = the
+// table-free version (s = (m - 1) / (m + 1), odd series to s^19)
+#ifndef RH_SAS_LOG
+#define RH_SAS_LOG 1
+#endif
+__constant__ double2 SAS_LOG_T[64] = {RH_SAS_LOG_TABLE};
+__constant__ double SAS_LOG1P_C[8] = {RH_SAS_LOG1P_COEF};
 __constant__ double SAS_LOG_C[9] = {2.0 / 19.0, 2.0 / 17.0, 2.0 / 15.0, 2.0 / 13.0, 2.0 / 11.0, 2.0 / 9.0, 2.0 / 7.0, 2.0 / 5.0, 2.0 / 3.0};
 __constant__ double SAS_EXP_C[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
                                      1.0 / 40320.0,      1.0 / 5040.0,      1.0 / 720.0,      1.0 / 120.0,     1.0 / 24.0,
                                      1.0 / 6.0,          0.5};
 struct PowConsts {
     double lc[9], ec[12];
+    const double2 *logt;  // the log2 table (LDS copy in the step kernel)
 };
-SAS_DEV PowConsts load_pow_consts() {
+SAS_DEV PowConsts load_pow_consts(const double2 *logt) {
     PowConsts c;
+    c.logt = logt;
+#if RH_SAS_LOG == 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.lc[i] = SAS_LOG1P_C[i];
+    c.lc[8] = 0.0;
+#else
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.lc[i] = SAS_LOG_C[i];
+#endif
 #pragma unroll
     for (int i = 0; i < 12; ++i) c.ec[i] = SAS_EXP_C[i];
     return c;
 }
+#if RH_SAS_LOG == 1
+// log2 x = e + log2 c_i + log2(1 + r):  x = m * 2^e with m in [1, 2), i = the top six mantissa bits, c_i the centre of
+// that sixty-fourth, r = m / c_i - 1 by one fma on the tabulated reciprocal (|r| <= 1/128; the table's log2 c_i is
+// -log2 of that very reciprocal, so the split is exact), log2(1 + r) by its series to r^8.
+SAS_DEV double sas_log2(const PowConsts &C, double x) {
+    const int e = __builtin_amdgcn_frexp_exp(x) - 1;
+    const double m = __builtin_amdgcn_frexp_mant(x) * 2.0;  // [1, 2)
+    const int i = (int)((unsigned)(__double_as_longlong(m) >> 46) & 63u);
+    const double2 t = C.logt[i];
+    const double r = __builtin_fma(m, t.x, -1.0);
+    double p = C.lc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p = __builtin_fma(p, r, C.lc[k]);
+    return ((double)e + t.y) + p * r;
+}
+#else
 SAS_DEV double sas_log2(const PowConsts &C, double x) {
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
@@ -98,6 +130,7 @@ SAS_DEV double sas_log2(const PowConsts &C, double x) {
     const double lnm = s * __builtin_fma(p, z, 2.0);
     return __builtin_fma(lnm, 1.44269504088896340736, (double)e);
 }
+#endif
 // 2**y.  No range clamp is needed: v_cvt_i32_f64 saturates and v_ldexp_f64 under/overflows to 0 / inf.
 SAS_DEV double sas_exp2(const PowConsts &C, double y) {
     const double n = __builtin_rint(y);
@@ -157,6 +190,7 @@ struct SasArgs {
 // ---------------------------------------------------------------------------------------------
 template <int W>
 struct Blk {
+    const double2 *logt;   // LDS copy of the log2 table
     int tid, lane, wave;
     unsigned phase;        // alternates the double-buffered LDS scratch; one barrier per use
     double (*red)[W][8];   // [2][W][8]
@@ -378,7 +412,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
     const double code = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6];  // read once: the loop below stores nothing, but the compiler cannot know
     constexpr bool uniform = FAM == FAM_UNIFORM, power = FAM == FAM_POWER, dirac = FAM == FAM_DIRAC;
     constexpr bool kumaraswami = FAM == FAM_KUMARASWAMI, expo = FAM == FAM_EXPONENTIAL;
-    const PowConsts C = load_pow_consts();
+    const PowConsts C = load_pow_consts(B.logt);
     const UDiv by_fh = udiv_prepare(fh);
     double Om_edge0 = 0.0;  // Omega at SA[0] = 0: 0 for every family but a dirac with a negative threshold
     double san[E], ttn[E];
@@ -723,7 +757,11 @@ template <int W, int E>
 __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
+    __shared__ double2 s_logt[64];
+    if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
+    __syncthreads();
     Blk<W> B;
+    B.logt = s_logt;
     B.tid = threadIdx.x;
     B.lane = threadIdx.x & 63;
     B.wave = threadIdx.x >> 6;
@@ -891,7 +929,7 @@ __global__ void k_selftest_div(const double *a, const double *d, double *out, in
 }
 __global__ void k_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const PowConsts C = load_pow_consts();
+    const PowConsts C = load_pow_consts(SAS_LOG_T);
     if (i < n) out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
 }
 
