@@ -130,8 +130,9 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
 /* Per-cell weights on top of the resident series, as the distributed catchment setups apply them in `set_forcing`
  * (examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186, 276-296):
  *   prec_day = PREC * prec_weight,  ta_day = TA + ta_offset,  pet_day = PET * pet_weight     (n_cells float64 each)
- * Needs rh_set_forcing_series first.  The day's (n_cells, 144) forcing is then formed on the device at midnight
- * by the device-side hooks; the step takes the per-cell-forcing path (predicate kernels, three-phase protocol).
+ * Needs rh_set_forcing_series first.  The day's series stays one 144-vector (staged in LDS); every column forms its
+ * own values from its weights on the fly, no (n_cells, 144) array exists.  The step takes the per-cell-forcing path
+ * (predicate kernels, three-phase protocol).
  * Pass three NULLs to return to the shared series. */
 int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double *ta_offset, const double *pet_weight);
 

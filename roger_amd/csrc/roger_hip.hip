@@ -66,7 +66,7 @@ struct DevState {
     int64_t nitt_forc;
     int monthly;                       // set_parameters' month-change test, evaluated on the device
     const double *weights[3];          // per-cell prec_weight, ta_offset, pet_weight (rh_set_forcing_weights) or null
-    int fill_cells;                    // the hooks took a new day: k_fill_cell_forcing forms the per-cell forcing
+
     const double *mlms;                // lut_mlms rows (oneD model), device copy
     int64_t mlms_rows;
     int max_slope_per;
@@ -181,27 +181,34 @@ RH_DEV double np_sum144(Get get) {
 
 // aggregates {prec, ta, pet} x {daily, hourly, 10 min} of one forcing series (stride between
 // consecutive slots given, so the same code serves the shared vector and per-cell rows)
+template <class P, class T, class E>
+RH_DEV void forcing_aggregates_of(P p_of, T t_of, E e_of, int64_t itd, double *a);
 RH_DEV void forcing_aggregates(const double *p, const double *t, const double *e, int64_t itd, double *a) {
-    a[0] = np_sum144([&](int k) { return p[k]; });
+    forcing_aggregates_of([&](int k) { return p[k]; }, [&](int k) { return t[k]; }, [&](int k) { return e[k]; }, itd, a);
+}
+// the same for a series given by accessors (weighted station forcing: PREC[k] * w, TA[k] + offset, PET[k] * w)
+template <class P, class T, class E>
+RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a) {
+    a[0] = np_sum144([&](int k) { return p(k); });
     {
         int cnt = 0;
-        for (int k = 0; k < 144; ++k) cnt += !isnan(t[k]);
-        a[1] = np_sum144([&](int k) { return isnan(t[k]) ? 0.0 : t[k]; }) / (double)cnt;
+        for (int k = 0; k < 144; ++k) cnt += !isnan(t(k));
+        a[1] = np_sum144([&](int k) { const double v = t(k); return isnan(v) ? 0.0 : v; }) / (double)cnt;
     }
-    a[2] = np_sum144([&](int k) { return e[k]; });
+    a[2] = np_sum144([&](int k) { return e(k); });
     auto in = [&](int k) { return (k >= itd) && (k < itd + 6); };
-    a[3] = np_sum144([&](int k) { return in(k) ? p[k] : 0.0; });
+    a[3] = np_sum144([&](int k) { return in(k) ? p(k) : 0.0; });
     {
         int cnt = 0;
-        for (int k = 0; k < 144; ++k) cnt += in(k) && !isnan(t[k]);
-        a[4] = np_sum144([&](int k) { return (in(k) && !isnan(t[k])) ? t[k] : 0.0; }) / (double)cnt;
+        for (int k = 0; k < 144; ++k) cnt += in(k) && !isnan(t(k));
+        a[4] = np_sum144([&](int k) { const double v = t(k); return (in(k) && !isnan(v)) ? v : 0.0; }) / (double)cnt;
     }
-    a[5] = np_sum144([&](int k) { return in(k) ? e[k] : 0.0; });
+    a[5] = np_sum144([&](int k) { return in(k) ? e(k) : 0.0; });
     int64_t k = itd < 0 ? itd + 144 : itd;
     k = k > 143 ? 143 : k;
-    a[6] = p[k];
-    a[7] = t[k];
-    a[8] = e[k];
+    a[6] = p((int)k);
+    a[7] = t((int)k);
+    a[8] = e((int)k);
 }
 
 RH_DEV unsigned long long forcing_bits(double p, double t, const Consts &K) {
@@ -241,31 +248,29 @@ RH_DEV void hooks_set_forcing(DevState *D) {
             S.itt_forc = i0 + RH_SLOTS_PER_DAY;
             D->per_cell = D->weights[0] ? 1 : 0;
         }
-        D->fill_cells = (have && D->weights[0]) ? 1 : 0;
         D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
     }
     __threadfence();
     __syncthreads();
 }
 __global__ __launch_bounds__(RH_BLOCK) void k_set_forcing(DevState *D) { hooks_set_forcing(D); }
-// weighted station forcing (eberbaechle/svat_distributed/svat.py:276-296): on the day the hooks took new forcing,
-// prec_day = PREC * prec_weight, ta_day = TA + ta_offset, pet_day = PET * pet_weight for every column
-__global__ __launch_bounds__(RH_BLOCK) void k_fill_cell_forcing(Arena a, DevState *D) {
-    if (!D->fill_cells) return;
-    const int64_t idx = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    if (idx >= a.n * RH_SLOTS_PER_DAY) return;
-    const int64_t i = idx / RH_SLOTS_PER_DAY;
-    const int s = (int)(idx % RH_SLOTS_PER_DAY);
-    const_cast<double *>(D->forc_cell[0])[idx] = D->forc[0][s] * D->weights[0][i];
-    const_cast<double *>(D->forc_cell[1])[idx] = D->forc[1][s] + D->weights[1][i];
-    const_cast<double *>(D->forc_cell[2])[idx] = D->forc[2][s] * D->weights[2][i];
+// Weighted station forcing (eberbaechle/svat_distributed/svat.py:276-296: prec_day = PREC * prec_weight, ta_day = TA +
+// ta_offset, pet_day = PET * pet_weight): the day's series stays one 144-vector, staged in LDS, and every column forms
+// its own values from its three weights on the fly -- no (n, 144) arrays, 24 bytes of weights per column and step.
+struct DaySeries {
+    double f[3][RH_SLOTS_PER_DAY];
+};
+RH_DEV void stage_day(const DevState *D, DaySeries &s) {
+    for (int k = threadIdx.x; k < 3 * RH_SLOTS_PER_DAY; k += RH_BLOCK) s.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
+    __syncthreads();
 }
-
 // start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
 __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
     const Consts K = D->K;
     unsigned long long b = 0;
-    const bool per_cell = D->per_cell != 0;
+    const bool per_cell = D->per_cell != 0, weighted = D->weights[0] != nullptr;
+    __shared__ DaySeries day;
+    if (per_cell && weighted) stage_day(D, day);
     for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * RH_BLOCK) {
         double swe, swe_top;
         rh_ld(a, RH_P_swe, i, swe);
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
         b |= (swe > 0) ? BIT(PB_SWE_GT0) : 0;
         b |= !(swe_top <= 0) ? BIT(PB_SWETOP_NOT_LE0) : 0;
         b |= (swe_top > 0) ? BIT(PB_SWETOP_GT0) : 0;
-        if (per_cell) {
+        if (per_cell && weighted) {
+            const double pw = D->weights[0][i], toff = D->weights[1][i];
+            for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(day.f[0][k] * pw, day.f[1][k] + toff, K);
+        } else if (per_cell) {
             const double *p = D->forc_cell[0] + i * RH_SLOTS_PER_DAY, *t = D->forc_cell[1] + i * RH_SLOTS_PER_DAY;
             for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p[k], t[k], K);
         }
@@ -406,10 +414,18 @@ __global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int
 // nine SoA planes (so the per-column kernels stay free of the 144-element loops).
 __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    const bool weighted = D->weights[0] != nullptr;
+    __shared__ DaySeries day;
+    if (weighted) stage_day(D, day);
     if (i >= a.n) return;
     double agg[9];
-    forcing_aggregates(D->forc_cell[0] + i * RH_SLOTS_PER_DAY, D->forc_cell[1] + i * RH_SLOTS_PER_DAY,
-                       D->forc_cell[2] + i * RH_SLOTS_PER_DAY, D->S.itt_day, agg);
+    if (weighted) {
+        const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
+        forcing_aggregates_of([&](int k) { return day.f[0][k] * pw; }, [&](int k) { return day.f[1][k] + toff; },
+                              [&](int k) { return day.f[2][k] * ew; }, D->S.itt_day, agg);
+    } else
+        forcing_aggregates(D->forc_cell[0] + i * RH_SLOTS_PER_DAY, D->forc_cell[1] + i * RH_SLOTS_PER_DAY,
+                           D->forc_cell[2] + i * RH_SLOTS_PER_DAY, D->S.itt_day, agg);
     for (int k = 0; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
@@ -1456,8 +1472,6 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
 
 static void launch_hooks(rh_ctx *ctx) {
     hipLaunchKernelGGL(k_set_forcing, dim3(1), dim3(RH_BLOCK), 0, ctx->stream, ctx->dev);
-    if (ctx->weight_buf[0])
-        hipLaunchKernelGGL(k_fill_cell_forcing, dim3(grid_for(ctx->n * RH_SLOTS_PER_DAY)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
 }
 int rh_hooks_phase(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
@@ -1487,10 +1501,6 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
             HIPCHK(ctx, hipMemcpyAsync(ctx->weight_buf[k], src[k], nb, hipMemcpyHostToDevice, ctx->stream));
             dptr[k] = ctx->weight_buf[k];
         }
-        const size_t bytes = sizeof(double) * RH_SLOTS_PER_DAY * (size_t)ctx->n;
-        for (int k = 0; k < 3; ++k)
-            if (!ctx->forc_cell_buf[k]) HIPCHK(ctx, hipMalloc((void **)&ctx->forc_cell_buf[k], bytes));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->dev->forc_cell, ctx->forc_cell_buf, sizeof(double *) * 3, hipMemcpyHostToDevice, ctx->stream));
         if (!ctx->agg_cell_buf) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->agg_cell_buf, sizeof(double) * 9 * (size_t)ctx->n));
             HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->agg_cell, &ctx->agg_cell_buf, sizeof(double *), hipMemcpyHostToDevice, ctx->stream));
