@@ -215,10 +215,11 @@ def test_vs_oracle_hetero_4096(native, oracle, per_cell):
     ctx.close()
 
 
-def test_full_size_properties(native, oracle):
-    """BASELINE config 2 size (nx*ny = 10^6, uniform benchmark parameters): size-independent
-    properties -- every column equals the single-column oracle run bit-for-tolerance, the mass
-    balance closes, the sanity flag holds."""
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (3200, 3125)])
+def test_full_size_properties(native, oracle, nx, ny):
+    """BASELINE configs[1] size (nx*ny = 10^6) and the north-star size (10^7), uniform benchmark
+    parameters: size-independent properties -- every column equals the single-column oracle run
+    bit-for-tolerance, the mass balance closes, the sanity flag holds."""
     import hip_util as H
     from roger_amd.forcing import toy_forcing
 
@@ -229,7 +230,6 @@ def test_full_size_properties(native, oracle):
     st.load_snapshot(g["state0"], names)
     st.load_scalars(g["scal0"])
     st.set_luts(*luts)
-    nx = ny = 1000
     ctx = native.Context(nx, ny)
     for row, nm in zip(g["state0"], names):
         ctx.upload(nm, np.full(nx * ny, row[0]))

@@ -132,3 +132,29 @@ def test_scope_errors(oracle_backend):
     bad["ks"] = bad["ks"] * -1
     with pytest.raises(ValueError, match="ks-parameter is out of range"):
         S.make_model(bad, forcing, 1).setup()   # numerics.validate_parameters_soil
+
+
+def test_restart_round_trip(tmp_path, monkeypatch):
+    """write_restart after n steps, read_restart into a fresh model, continue: identical to the uninterrupted run
+    (roger/restart.py counterpart with an .npz container)."""
+    import oracle_context as OC
+    from golden_util import load_case
+    from roger_amd import _native, restart
+    from svat_scripts import make_model, params_from_golden
+
+    monkeypatch.setattr(_native, "Context", OC.OracleContext)
+    g, names, forcing = load_case("svat_hetero_combo")
+    p = params_from_golden(g, names)
+    a, b = make_model(p, forcing, 2), make_model(p, forcing, 2)
+    a.setup()
+    b.setup()
+    for _ in range(40):
+        a.step(a.state)
+    f = restart.write_restart(a.state, tmp_path / "ckpt")
+    restart.read_restart(b.state, f)
+    assert b.state.variables.itt == a.state.variables.itt and b.state.variables.time == a.state.variables.time
+    for _ in range(25):
+        a.step(a.state)
+        b.step(b.state)
+    for nm in ("S", "theta_rz", "z_wf", "q_ss", "swe", "event_id", "time_event0", "itt_forc"):
+        np.testing.assert_array_equal(np.asarray(getattr(a.state.variables, nm)), np.asarray(getattr(b.state.variables, nm)), err_msg=nm)
