@@ -217,6 +217,9 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
 /* One (variable, day slot) array: n_cells float64.  j counts the rate planes first, then the collect planes. */
 int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes); /* synchronises */
 void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot);
+/* Number of steps accumulated in a day slot: the divisor of the "average" diagnostic (roger/diagnostics/average.py:
+ * `avg += var; n += 1`, output avg / n) for a variable registered as a rate plane.  Synchronises. */
+int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps);
 
 /* HIP-event timing of the fused per-cell kernel.  rh_enable_timing(ctx, 1) starts a new
  * measurement: every following step records an event pair around the kernel on the context's

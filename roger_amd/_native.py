@@ -93,6 +93,7 @@ def load():
     lib.rh_set_forcing_weights.argtypes = [vp, vp, vp, vp]
     lib.rh_diag_configure.argtypes = [vp, vp, i32, vp, i32, i32]
     lib.rh_diag_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    lib.rh_diag_steps.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     lib.rh_diag_device_ptr.argtypes = [vp, i32, i32]
     lib.rh_diag_device_ptr.restype = vp
     lib.rh_svat_step.argtypes = [vp, i32]
@@ -314,7 +315,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
-    "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr",
+    "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights",
 )
 
@@ -462,6 +463,12 @@ class Context:
         self._check(self._lib.rh_diag_download(self._h, self._diag_names.index(name), int(slot),
                                                a.ctypes.data_as(C.c_void_p), a.nbytes), "rh_diag_download")
         return a
+
+    def diag_steps(self, slot):
+        """Steps accumulated in a day slot (divide a rate variable by it for the "average" diagnostic)."""
+        n = C.c_int64()
+        self._check(self._lib.rh_diag_steps(self._h, int(slot), C.byref(n)), "rh_diag_steps")
+        return n.value
 
     def diag_device_ptr(self, name, slot):
         return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))

@@ -53,6 +53,7 @@ struct DevState {
     int sflag_blocks;
     // device-side output accumulators (rh_diag_configure): (diag_slots, diag_rate + diag_collect, n) float64
     double *diag;
+    long long *diag_steps;         // steps accumulated per day slot (the divisor of the "average" diagnostic)
     int diag_rate, diag_collect, diag_slots;
     int diag_planes[32];
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
@@ -88,6 +89,7 @@ struct rh_ctx {
     bool per_cell;
     bool summary_valid;   // D->sflags describe the columns as they are in the arena now
     double *diag_buf;
+    long long *diag_steps_buf;
     int diag_n, diag_slots;
     unsigned long long *sflags_buf;
     int pred_blocks;
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
     const bool first = (t0 % 86400) == 0;
     const int nr = D->diag_rate, nv = D->diag_rate + D->diag_collect;
     double *base = D->diag + (size_t)slot * nv * a.n;
+    if (i == 0) D->diag_steps[slot] = first ? 1 : D->diag_steps[slot] + 1;
     for (int j = 0; j < nv; ++j) {
         double v;
         rh_ld(a, D->diag_planes[j], i, v);
@@ -1033,6 +1036,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->mlms_buf = nullptr;
     ctx->sflags_buf = nullptr;
     ctx->diag_buf = nullptr;
+    ctx->diag_steps_buf = nullptr;
     ctx->diag_n = 0;
     ctx->diag_slots = 0;
     ctx->per_cell = false;
@@ -1108,6 +1112,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
     if (ctx->sflags_buf) (void)hipFree(ctx->sflags_buf);
     if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
+    if (ctx->diag_steps_buf) (void)hipFree(ctx->diag_steps_buf);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1537,6 +1542,10 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         HIPCHK(ctx, hipFree(ctx->diag_buf));
         ctx->diag_buf = nullptr;
     }
+    if (ctx->diag_steps_buf) {
+        HIPCHK(ctx, hipFree(ctx->diag_steps_buf));
+        ctx->diag_steps_buf = nullptr;
+    }
     const int nv = n_rate + n_collect;
     ctx->diag_n = nv;
     ctx->diag_slots = n_slots;
@@ -1544,7 +1553,10 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         const size_t bytes = (size_t)n_slots * nv * ctx->n * sizeof(double);
         HIPCHK(ctx, hipMalloc((void **)&ctx->diag_buf, bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->diag_buf, 0, bytes, ctx->stream));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->diag_steps_buf, (size_t)n_slots * sizeof(long long)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->diag_steps_buf, 0, (size_t)n_slots * sizeof(long long), ctx->stream));
     }
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_steps, &ctx->diag_steps_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag, &ctx->diag_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_rate, &n_rate, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_collect, &n_collect, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1565,6 +1577,16 @@ int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes) {
     if (!host || bytes != (size_t)ctx->n * sizeof(double)) return fail(ctx, RH_ERR_ARG, "rh_diag_download: size mismatch");
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->diag_buf + ((size_t)slot * ctx->diag_n + j) * ctx->n, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps) {
+    const int rc = diag_check(ctx, 0, slot);
+    if (rc) return rc;
+    if (!steps) return fail(ctx, RH_ERR_ARG, "rh_diag_steps: null pointer");
+    long long v = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&v, ctx->diag_steps_buf + slot, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *steps = (int64_t)v;
     return RH_OK;
 }
 void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot) {

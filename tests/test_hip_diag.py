@@ -43,6 +43,8 @@ def run_svat_with_accumulators(g, case):
 def test_daily_sums_match_reference(case):
     g = sb.SasGolden(case)
     model, ctx = run_svat_with_accumulators(g, case)
+    steps = [ctx.diag_steps(d - 1) for d in range(1, g.ndays + 1)]
+    assert sum(steps) == model.state.variables.itt and set(steps) <= set(range(1, 145)) and min(steps) == 1   # dry days: one step
     for d in range(1, g.ndays + 1):
         for k in RATE + COLLECT:
             want = g.z[f"in_{k}"][:, :, d].reshape(-1)
