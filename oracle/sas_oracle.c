@@ -3,7 +3,8 @@
  *
  * Scalar CPU restatement of the reference NumPy backend's offline oxygen-18 transport step with
  * StorAge-selection (SAS) functions, deterministic solver (RoGeR,
- * roger/core/transport.py:949-991 `svat_transport_model_deterministic`, without write_output).
+ * roger/core/transport.py:949-991 `svat_transport_model_deterministic`, without write_output), and of the
+ * same step for bromide (tracer = 1: the anion kernels, solute mass by age instead of a concentration).
  * One soil column at a time; age vectors are plain arrays.  It is the checker of the HIP SAS
  * kernel and the cpu_baseline of the SAS bench; the product never includes or calls it.
  *
@@ -43,6 +44,12 @@ typedef struct oc_sas {
     double *stats[5][6];
     /* soil.rescale_SA after the warm-up run */
     const double *S_rz_init, *S_ss_init;
+    /* tracer: 0 oxygen-18 (msa = concentration by age), 1 bromide (anion kernels: msa = solute mass by age) */
+    int64_t tracer;
+    const double *alpha_transp, *alpha_q, *S_sat_rz; /* (n) partition coefficients, saturation storage of the root zone */
+    const int32_t *lu_id;                            /* (n) land use: 500 < lu_id < 599 is a crop */
+    double *M[5];                                    /* (n) solute mass of the outgoing fluxes; [0] (evap_soil) unused */
+    double *M_inf[3], *M_rz, *M_ss, *M_s;            /* (n) */
 } oc_sas;
 
 /* numpy pairwise add.reduce (see svat_oracle.c) */
@@ -226,6 +233,131 @@ static void outflux(const oc_sas *P, int64_t i, int f, double flux, double *sa, 
     for (int64_t k = 0; k < A; ++k) msa[k] = (sa[k] <= 0 ? 0 : msa[k]) * mk;
 }
 
+/* --- anion (bromide) kernels: msa holds solute mass per age class ------------------------------------------ */
+
+/* nansum over the age axis: NaN -> 0, then numpy's pairwise add.reduce */
+static double np_nansum(const double *a, int64_t n, double *scratch) {
+    for (int64_t k = 0; k < n; ++k) scratch[k] = isnan(a[k]) ? 0 : a[k];
+    return np_sum(scratch, n);
+}
+
+/* outgoing flux of the anion kernels.  water_only: calc_evaporation_transport_kernel
+ * (evapotranspiration.py:620-650), the solute stays behind.  Otherwise calc_transpiration_transport_anion_kernel
+ * (:905-985), calc_percolation_rz/ss_transport_anion_kernel (subsurface_runoff.py:1630-1716, 1823-1893),
+ * calc_capillary_rise_rz_transport_anion_kernel (capillary_rise.py:503-590) with calc_mtt's anion branch
+ * (transport.py:583-596): mtt = msa / sa * alpha * tt * flux clipped to [0, msa]. */
+static void outflux_anion(const oc_sas *P, int64_t i, int f, double flux, double alpha, int water_only, double *sa, double *msa,
+                          double *sa_sink, double *msa_sink, double mk, double *work) {
+    const int64_t A = P->ages;
+    double *SA = work, *scratch = work + (A + 1);
+    double *tt = P->tt[f] + i * A, *mtt = P->mtt[f] + i * A, *TT = P->TT[f] + i * (A + 1);
+    calc_SA(SA, sa, A);
+    for (int64_t k = 0; k <= A; ++k) SA[k] *= mk;
+    calc_tt(P, tt, SA, sa, flux, P->sas_params[f] + i * 8, mk, scratch);
+    for (int64_t k = 0; k < A; ++k) tt[k] *= mk;
+    {
+        double acc = 0;
+        for (int64_t k = 0; k < A; ++k) {
+            acc = (k == 0) ? tt[0] : acc + tt[k];
+            TT[k + 1] = acc;
+        }
+    }
+    if (!water_only) {
+        for (int64_t k = 0; k < A; ++k) {
+            double m = (sa[k] > 0 ? msa[k] / sa[k] : 0) * alpha * tt[k] * flux;
+            m = (m <= 0 ? 0 : m);
+            m = (m > msa[k] ? msa[k] : m);
+            mtt[k] = m * mk;
+        }
+        const double tot = np_sum(mtt, A);
+        P->C[f][i] = (flux > 0 ? tot / flux : 0) * mk;
+        P->M[f][i] = tot * mk;
+    }
+    for (int64_t k = 0; k < A; ++k) { /* update_sa :599-619 */
+        double v = sa[k] + -flux * tt[k];
+        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
+        sa[k] = v * mk;
+    }
+    if (!water_only)
+        for (int64_t k = 0; k < A; ++k) msa[k] += -mtt[k] * mk;
+    if (sa_sink) {
+        for (int64_t k = 0; k < A; ++k) msa_sink[k] += mtt[k] * mk;
+        for (int64_t k = 0; k < A; ++k) sa_sink[k] += tt[k] * flux * mk;
+    }
+}
+
+/* ageing of the anion kernels: calc_ageing_sa :623-652, calc_ageing_msa :655-680 (no NaN marker) */
+static void ageing_anion(double *sa, double *msa, int64_t A) {
+    const double sa_last = sa[A - 1], msa_last = msa[A - 1];
+    for (int64_t k = A - 1; k >= 1; --k) {
+        sa[k] = sa[k - 1];
+        msa[k] = msa[k - 1];
+    }
+    sa[0] = 0;
+    msa[0] = 0;
+    sa[A - 1] += sa_last;
+    sa[A - 1] = (sa[A - 1] < 1e-8 ? 0 : sa[A - 1]);
+    msa[A - 1] += msa_last;
+}
+
+/* one day of svat_transport_model_deterministic for one column, bromide */
+static void step_anion(const oc_sas *P, int64_t i, double *work) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double C_in = P->C_in[i];
+    {   /* calc_infiltration_rz_transport_anion_kernel, infiltration.py:2350-2424 */
+        const double im = P->inf_mat_rz[i], ip = P->inf_pf_rz[i];
+        P->C_inf[0][i] = (im > 0 ? C_in : 0) * mk;
+        P->C_inf[1][i] = (ip > 0 ? C_in : 0) * mk;
+        P->M_inf[0][i] = P->C_inf[0][i] * im * mk;
+        P->M_inf[1][i] = P->C_inf[1][i] * ip * mk;
+        sa_rz[0] += im + ip * mk;
+        msa_rz[0] += P->M_inf[0][i] + P->M_inf[1][i] * mk;
+    }
+    outflux_anion(P, i, 0, P->evap_soil[i], 0, 1, sa_rz, msa_rz, NULL, NULL, mk, work);
+    {   /* crop solute uptake stops above 80 % saturation: evapotranspiration.py:932-939 */
+        const int crop = (P->lu_id[i] > 500) && (P->lu_id[i] < 599) && (np_sum(sa_rz, A) >= 0.8 * P->S_sat_rz[i]);
+        const double alpha = (crop ? 0 : P->alpha_transp[i]) * mk;
+        outflux_anion(P, i, 1, P->transp[i], alpha, 0, sa_rz, msa_rz, NULL, NULL, mk, work);
+    }
+    outflux_anion(P, i, 2, P->q_rz[i], P->alpha_q[i], 0, sa_rz, msa_rz, sa_ss, msa_ss, mk, work);
+    {   /* calc_infiltration_ss_transport_anion_kernel, infiltration.py:2516-2566 */
+        const double ip = P->inf_pf_ss[i];
+        P->C_inf[2][i] = (ip > 0 ? C_in : 0) * mk;
+        P->M_inf[2][i] = P->C_inf[2][i] * ip * mk;
+        sa_ss[0] += ip * mk;
+        msa_ss[0] += P->M_inf[2][i] * mk;
+    }
+    outflux_anion(P, i, 3, P->q_ss[i], P->alpha_q[i], 0, sa_ss, msa_ss, NULL, NULL, mk, work);
+    outflux_anion(P, i, 4, P->cpr_rz[i], P->alpha_q[i], 0, sa_ss, msa_ss, sa_rz, msa_rz, mk, work);
+    /* storages: root_zone.py:221-258, subsoil.py:186-223, soil.py:1094-1142 */
+    for (int64_t k = 0; k < A; ++k) sa_rz[k] = (sa_rz[k] < 1e-8 ? 0 : sa_rz[k]);
+    for (int64_t k = 0; k < A; ++k) msa_rz[k] = (sa_rz[k] <= 0 ? 0 : msa_rz[k]);
+    P->M_rz[i] = np_nansum(msa_rz, A, work) * mk;
+    {
+        const double S = np_sum(sa_rz, A);
+        P->C_rz[i] = (S > 0 ? P->M_rz[i] / S : 0);
+    }
+    for (int64_t k = 0; k < A; ++k) sa_ss[k] = (sa_ss[k] < 1e-8 ? 0 : sa_ss[k]);
+    for (int64_t k = 0; k < A; ++k) msa_ss[k] = (sa_ss[k] <= 0 ? 0 : msa_ss[k]);
+    P->M_ss[i] = np_nansum(msa_ss, A, work) * mk;
+    {
+        const double S = np_sum(sa_ss, A);
+        P->C_ss[i] = (S > 0 ? P->M_ss[i] / S : 0);
+    }
+    double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+    for (int64_t k = 0; k < A; ++k) {
+        sa_s[k] = sa_rz[k] + sa_ss[k] * mk;
+        msa_s[k] = msa_rz[k] + msa_ss[k] * mk;
+    }
+    P->M_s[i] = np_nansum(msa_s, A, work) * mk;
+    {
+        const double S = np_sum(sa_s, A);
+        P->C_s[i] = (S > 0 ? P->M_s[i] / S : 0);
+    }
+}
+
 /* infiltration into age class 0: infiltration.py:2218-2346 (rz: matrix then preferential flow),
  * :2441-2512 (ss) */
 static void inflow(const oc_sas *P, int64_t i, int which, double inf, double *sa, double *msa, double mk) {
@@ -291,6 +423,15 @@ void oc_sas_rescale(const oc_sas *P) {
         const double t_rz = np_sum(sa_rz, A), t_ss = np_sum(sa_ss, A);
         for (int64_t k = 0; k < A; ++k) sa_rz[k] = P->S_rz_init[i] * (sa_rz[k] / t_rz);
         for (int64_t k = 0; k < A; ++k) sa_ss[k] = P->S_ss_init[i] * (sa_ss[k] / t_ss);
+        if (P->tracer == 1) { /* bromide: rescale_sa_msa_anion_soil_kernel, core/soil.py:1399-1506 -- the soil starts free of bromide */
+            for (int64_t k = 0; k < A; ++k) {
+                msa_rz[k] = msa_ss[k] = P->msa_s[i * A + k] = 0;
+                P->sa_s[i * A + k] = sa_rz[k] + sa_ss[k];
+            }
+            P->C_rz[i] = P->C_ss[i] = P->C_s[i] = 0;
+            P->M_rz[i] = P->M_ss[i] = P->M_s[i] = 0;
+            continue;
+        }
         P->C_rz[i] = conc_storage(sa_rz, msa_rz, A, work);
         P->C_iso_rz[i] = conc_to_delta(P, P->C_rz[i]) * mk;
         P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work);
@@ -316,6 +457,11 @@ void oc_sas_step(const oc_sas *P) {
     for (int64_t i = 0; i < P->n; ++i) {
         const double mk = (double)P->maskCatch[i];
         double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+        double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+        if (P->tracer == 1) {
+            step_anion(P, i, work);
+            goto statistics;
+        }
         inflow(P, i, 0, P->inf_mat_rz[i], sa_rz, msa_rz, mk);
         inflow(P, i, 1, P->inf_pf_rz[i], sa_rz, msa_rz, mk);
         outflux(P, i, 0, P->evap_soil[i], sa_rz, msa_rz, NULL, NULL, mk, work);
@@ -331,7 +477,6 @@ void oc_sas_step(const oc_sas *P) {
         for (int64_t k = 0; k < A; ++k) sa_ss[k] = (sa_ss[k] < 1e-8 ? 0 : sa_ss[k]);
         P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work) * mk;
         P->C_iso_ss[i] = conc_to_delta(P, P->C_ss[i]) * mk;
-        double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
         for (int64_t k = 0; k < A; ++k) {
             sa_s[k] = sa_rz[k] + sa_ss[k] * mk;
             const double tot = sa_rz[k] + sa_ss[k];
@@ -340,6 +485,7 @@ void oc_sas_step(const oc_sas *P) {
         }
         P->C_s[i] = conc_storage(sa_s, msa_s, A, work) * mk;
         P->C_iso_s[i] = conc_to_delta(P, P->C_s[i]) * mk;
+    statistics:
         if (P->stats[0][0]) { /* transport.py:59-312 */
             static const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
             const double *ttd[2] = {P->tt[1] + i * A, P->tt[3] + i * A};
@@ -366,6 +512,11 @@ void oc_sas_step(const oc_sas *P) {
                 for (int64_t k = 0; k < A; ++k) prod[k] = (double)(k + 1) * rt[k];
                 P->stats[2 + d][5][i] = (np_sum(rt, A) > 0 ? np_sum(prod, A) : NAN);
             }
+        }
+        if (P->tracer == 1) {
+            ageing_anion(sa_rz, msa_rz, A);
+            ageing_anion(sa_ss, msa_ss, A);
+            continue;
         }
         ageing(sa_rz, msa_rz, A, work);
         ageing(sa_ss, msa_ss, A, work);

@@ -71,11 +71,17 @@ def run_svat_daily(roger, params, forcing, ndays):
 from sas_scripts import make_transport_model as _make_transport_model  # noqa: E402  (tests/ is on sys.path)
 
 
-def make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0):
-    return _make_transport_model("roger", svat, sas, ages, substeps, ndays, age_statistics, warmup_days)
+def make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0, **kw):
+    return _make_transport_model("roger", svat, sas, ages, substeps, ndays, age_statistics, warmup_days, **kw)
 
 
-def grab(vs, names, stats):
+# bromide (anion) transport: what is recorded instead of the isotope variables
+BR_CELL_VARS = ("C_in", "M_in", "C_inf_mat_rz", "C_inf_pf_rz", "C_inf_pf_ss", "M_inf_mat_rz", "M_inf_pf_rz", "M_inf_pf_ss", "C_transp",
+                "C_q_rz", "C_q_ss", "C_cpr_rz", "M_transp", "M_q_rz", "M_q_ss", "M_cpr_rz")
+BR_CELL2_VARS = ("C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")
+
+
+def grab(vs, names, stats, bromide=False):
     rec = {}
 
     def interior(a, lvl=None):
@@ -87,9 +93,9 @@ def grab(vs, names, stats):
 
     for k in AGE_VARS:
         rec[k] = interior(getattr(vs, k), 1)
-    for k in TT_VARS + NAGE_VARS + CELL_VARS:
+    for k in TT_VARS + NAGE_VARS + (BR_CELL_VARS if bromide else CELL_VARS):
         rec[k] = interior(getattr(vs, k))
-    for k in CELL2_VARS:
+    for k in (BR_CELL2_VARS if bromide else CELL2_VARS):
         rec[k] = interior(getattr(vs, k), 1)
         rec[k + "_m1"] = interior(getattr(vs, k), 0)
     if stats:
@@ -130,7 +136,7 @@ def sas_params(nx, ny, variant, seed):
     return out
 
 
-def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed, warmup=False):
+def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed, warmup=False, tracer="oxygen18"):
     from roger_amd.forcing import combo_forcing
 
     params = hetero_params(nx, ny, seed=seed)
@@ -139,7 +145,17 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     rng = np.random.default_rng(seed + 7)
     svat["d18O_prec"] = np.concatenate([[np.nan], rng.uniform(-12, -4, ndays)])
     sas = sas_params(nx, ny, variant, seed)
-    model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0)
+    bromide = tracer == "bromide"
+    extra = None
+    if bromide:   # partition coefficients, a crop column (500 < lu_id < 599) and two bromide pulses in the input
+        lu = np.array([8, 550, 10, 5, 8, 560])[np.arange(nx * ny) % 6].reshape(nx, ny)
+        C_IN = np.zeros((nx, ny, ndays + 1))
+        C_IN[:, :, 3] = rng.uniform(50, 120, (nx, ny))   # days with infiltration in the SVAT run (a pulse on a dry day is lost)
+        C_IN[:, :, 5] = rng.uniform(10, 40, (nx, ny))
+        C_IN[:, :, 7] = rng.uniform(5, 20, (nx, ny))
+        extra = dict(alpha_transp=rng.uniform(0.2, 1.0, (nx, ny)), alpha_q=rng.uniform(0.4, 1.0, (nx, ny)), lu_id=lu, C_IN=C_IN)
+    model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0,
+                                 tracer=tracer, extra=extra)
     model.setup()
     vs = model.state.variables
     rec = {"meta": np.array([nx, ny, ndays, ages, substeps, int(age_statistics)])}
@@ -149,7 +165,7 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
         from roger.core import soil as ref_soil
 
         model.run()
-        for k, v in grab(vs, None, False).items():
+        for k, v in grab(vs, None, False, bromide).items():
             rec[f"w000_{k}"] = v
         ref_soil.rescale_SA(model.state)
         with vs.unlock():
@@ -164,18 +180,21 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     for flux, arr in sas.items():
         rec[f"sas_{flux}"] = arr.reshape(-1, 8)
     rec["maskCatch"] = np.asarray(vs.maskCatch)[2:-2, 2:-2].reshape(-1).astype(np.int32)
-    for k, v in grab(vs, None, False).items():
+    if bromide:
+        for k in ("alpha_transp", "alpha_q", "lu_id", "S_sat_rz"):
+            rec[k] = np.asarray(getattr(vs, k))[2:-2, 2:-2].reshape(-1)
+    for k, v in grab(vs, None, False, bromide).items():
         rec[f"d000_{k}"] = v
     for day in range(1, ndays + 1):
         model.step(model.state)
         assert vs.itt == day
-        for k, v in grab(vs, None, age_statistics).items():
+        for k, v in grab(vs, None, age_statistics, bromide).items():
             rec[f"d{day:03d}_{k}"] = v
     path = os.path.join(outdir, f"{name}.npz")
     np.savez_compressed(path, **rec)
     print(f"{name}: {ndays} days, {nx * ny} cells, ages {ages}, substeps {substeps} -> {path} "
-          f"({os.path.getsize(path) / 1e6:.2f} MB); d18O of percolation on the last day: "
-          f"{np.asarray(vs.C_iso_q_ss)[2:-2, 2:-2].ravel()[:4]}")
+          f"({os.path.getsize(path) / 1e6:.2f} MB); signal of percolation on the last day: "
+          f"{np.asarray(vs.C_q_ss if bromide else vs.C_iso_q_ss)[2:-2, 2:-2].ravel()[:4]}")
 
 
 def main():
@@ -191,6 +210,7 @@ def main():
         "sas_stats_a30": (2, 2, 12, 30, 3, "mixed", True, 11),
         "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
         "sas_warmup_a30": (2, 2, 10, 30, 3, "power", False, 23, True),
+        "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

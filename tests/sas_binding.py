@@ -17,6 +17,8 @@ STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
 SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30")
 
+ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
+
 _P = C.POINTER(C.c_double)
 
 
@@ -35,6 +37,9 @@ class OcSas(C.Structure):
         ("C_rz", _P), ("C_ss", _P), ("C_s", _P), ("C_iso_rz", _P), ("C_iso_ss", _P), ("C_iso_s", _P),
         ("stats", (_P * 6) * 5),
         ("S_rz_init", _P), ("S_ss_init", _P),
+        ("tracer", C.c_int64),
+        ("alpha_transp", _P), ("alpha_q", _P), ("S_sat_rz", _P), ("lu_id", C.POINTER(C.c_int32)),
+        ("M", _P * 5), ("M_inf", _P * 3), ("M_rz", _P), ("M_ss", _P), ("M_s", _P),
     ]
 
 
@@ -64,9 +69,11 @@ class SasState:
     """All arrays of one SAS problem: state (sa/msa), daily inputs, outputs.  Used with the oracle
     (`step_oracle`) and, in the GPU tests, as the host mirror of the HIP context."""
 
-    def __init__(self, n, ages, substeps, age_statistics=False):
+    def __init__(self, n, ages, substeps, age_statistics=False, tracer="oxygen18"):
         self.n, self.ages, self.substeps = int(n), int(ages), int(substeps)
         self.age_statistics = bool(age_statistics)
+        self.tracer = tracer
+        self.anion = tracer == "bromide"   # the reference's anion kernels: msa is solute mass by age
         A = self.ages
         z = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
         self.maskCatch = np.ones(n, dtype=np.int32)
@@ -92,6 +99,11 @@ class SasState:
             for w, p in STAT_TARGETS:
                 for q in STAT_Q:
                     self.out[f"{p}{q}_{w}"] = z(n)
+        # bromide: partition coefficients, land use, saturation storage; solute masses of fluxes and storages
+        self.par = {"alpha_transp": np.ones(n), "alpha_q": np.ones(n), "S_sat_rz": z(n), "lu_id": np.zeros(n, dtype=np.int32)}
+        if self.anion:
+            for k in ANION_MASSES:
+                self.out[k] = z(n)
 
     def struct(self):
         s = OcSas(n=self.n, ages=self.ages, substeps=self.substeps, vsmow=VSMOW, d18O_min=D18O_MIN, d18O_max=D18O_MAX)
@@ -117,6 +129,16 @@ class SasState:
                 for j, q in enumerate(STAT_Q):
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
         s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
+        s.tracer = 1 if self.anion else 0
+        if self.anion:
+            for k in ("alpha_transp", "alpha_q", "S_sat_rz"):
+                setattr(s, k, _ptr(self.par[k]))
+            s.lu_id = self.par["lu_id"].ctypes.data_as(C.POINTER(C.c_int32))
+            for i, f in enumerate(FLUXES[1:], start=1):
+                s.M[i] = _ptr(self.out[f"M_{f}"])
+            for i, f in enumerate(INFS):
+                s.M_inf[i] = _ptr(self.out[f"M_{f}"])
+            s.M_rz, s.M_ss, s.M_s = (_ptr(self.out[k]) for k in ("M_rz", "M_ss", "M_s"))
         return s
 
     def step_oracle(self):
@@ -133,15 +155,19 @@ class SasGolden:
         self.z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
         self.nx, self.ny, self.ndays, self.ages, self.substeps, self.stats = (int(v) for v in self.z["meta"])
         self.n = self.nx * self.ny
+        self.tracer = "bromide" if "alpha_q" in self.z.files else "oxygen18"
 
     def day(self, d, var):
         return self.z[f"d{d:03d}_{var}"]
 
     def new_state(self):
-        st = SasState(self.n, self.ages, self.substeps, bool(self.stats))
+        st = SasState(self.n, self.ages, self.substeps, bool(self.stats), tracer=self.tracer)
         st.maskCatch[:] = self.z["maskCatch"]
         for f in FLUXES:
             st.sas[f][:] = self.z[f"sas_{f}"]
+        if st.anion:
+            for k in st.par:
+                st.par[k][:] = np.asarray(self.z[k]).reshape(-1)
         return st
 
     def load_state(self, st, d):

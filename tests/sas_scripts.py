@@ -11,7 +11,7 @@ of a SVAT run as input, the snow signal mixed in `set_forcing`.
 import importlib
 
 
-def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0):
+def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0, tracer="oxygen18", extra=None):
     top = importlib.import_module(pkg)
     RogerSetup, roger_kernel, roger_routine, KernelOutput = top.RogerSetup, top.roger_kernel, top.roger_routine, top.KernelOutput
     allocate = importlib.import_module(pkg + ".variables").allocate
@@ -21,6 +21,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
     delta_to_conc, conc_to_delta = tr.delta_to_conc, tr.conc_to_delta
 
     nx, ny = svat["S_rz"].shape[:2]
+    bromide = tracer == "bromide"   # anion transport (mass based): models/svat_bromide, deterministic solver
+    extra = extra or {}
 
     class GoldenSAS(RogerSetup):
         @roger_routine
@@ -41,7 +43,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             s.y_origin = 0.0
             s.time_origin = "01-01-2022"
             s.enable_offline_transport = True
-            s.enable_oxygen18 = True
+            s.enable_oxygen18 = not bromide
+            s.enable_bromide = bromide
             s.tm_structure = "power"
             s.enable_age_statistics = bool(age_statistics)
 
@@ -76,6 +79,9 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             for flux, arr in sas.items():   # (nx, ny, 8): [code, k, ...]
                 name = f"sas_params_{flux}"
                 setattr(vs, name, update(getattr(vs, name), at[2:-2, 2:-2, :], arr))
+            if bromide:   # models/svat_bromide/svat_bromide.py:193-195; lu_id feeds the crop-uptake switch of the transpiration kernel
+                for k in ("alpha_transp", "alpha_q", "lu_id"):
+                    setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], extra[k]))
 
         @roger_routine
         def set_parameters(self, state):
@@ -106,6 +112,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.SA_ss = update(vs.SA_ss, at[2:-2, 2:-2, :, 1:], npx.cumsum(vs.sa_rz[2:-2, 2:-2, :, :], axis=-1))
             vs.sa_s = update(vs.sa_s, at[2:-2, 2:-2, :, :], vs.sa_rz[2:-2, 2:-2, :, :] + vs.sa_ss[2:-2, 2:-2, :, :])
             vs.SA_s = update(vs.SA_s, at[2:-2, 2:-2, :, 1:], npx.cumsum(vs.sa_s[2:-2, 2:-2, :, :], axis=-1))
+            if bromide:   # no bromide in the soil at the start (models/svat_bromide/svat_bromide.py:230-260): msa = 0
+                return
             vs.C_iso_snow = update(vs.C_iso_snow, at[2:-2, 2:-2, : vs.taup1], npx.nan)
             vs.C_iso_rz = update(vs.C_iso_rz, at[2:-2, 2:-2, : vs.taup1], -10)
             vs.C_iso_ss = update(vs.C_iso_ss, at[2:-2, 2:-2, : vs.taup1], -10)
@@ -146,6 +154,9 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.S_SS = update(vs.S_SS, at[2:-2, 2:-2, :], svat["S_ss"])
             vs.S_S = update(vs.S_S, at[2:-2, 2:-2, :], vs.S_RZ[2:-2, 2:-2, :] + vs.S_SS[2:-2, 2:-2, :])
             vs.S_SNOW = update(vs.S_SNOW, at[2:-2, 2:-2, :], svat["S_snow"])
+            if bromide:   # bromide concentration of the input in mg/l, a pulse on selected days (extra["C_IN"]: (nx, ny, t))
+                vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], extra["C_IN"])
+                return
             vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 0], npx.nan)
             vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 1:], svat["d18O_prec"][None, None, 1:])
             vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], delta_to_conc(state, vs.C_ISO_IN)[2:-2, 2:-2, :])
@@ -165,6 +176,9 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.S_s = update(vs.S_s, at[2:-2, 2:-2, vs.tau], vs.S_rz[2:-2, 2:-2, vs.tau] + vs.S_ss[2:-2, 2:-2, vs.tau])
             vs.S_snow = update(vs.S_snow, at[2:-2, 2:-2, vs.tau], vs.S_SNOW[2:-2, 2:-2, i])
             vs.C_in = update(vs.C_in, at[2:-2, 2:-2], vs.C_IN[2:-2, 2:-2, i])
+            if bromide:   # models/svat_bromide/svat_bromide.py:343-347
+                vs.M_in = update(vs.M_in, at[2:-2, 2:-2], vs.C_in[2:-2, 2:-2] * vs.prec[2:-2, 2:-2, vs.tau])
+                return
             prec, snow = vs.prec[2:-2, 2:-2, vs.tau], vs.S_snow[2:-2, 2:-2, vs.tau]
             vs.C_snow = update(vs.C_snow, at[2:-2, 2:-2, vs.tau], npx.where(
                 snow > 0,
@@ -193,8 +207,10 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
     def after_timestep_kernel(state):
         vs = state.variables
         vs.S_snow = update(vs.S_snow, at[2:-2, 2:-2, vs.taum1], vs.S_snow[2:-2, 2:-2, vs.tau])
-        vs.C_snow = update(vs.C_snow, at[2:-2, 2:-2, vs.taum1], vs.C_snow[2:-2, 2:-2, vs.tau])
         vs.prec = update(vs.prec, at[2:-2, 2:-2, vs.taum1], vs.prec[2:-2, 2:-2, vs.tau])
+        if bromide:
+            return KernelOutput(prec=vs.prec, S_snow=vs.S_snow)
+        vs.C_snow = update(vs.C_snow, at[2:-2, 2:-2, vs.taum1], vs.C_snow[2:-2, 2:-2, vs.tau])
         return KernelOutput(prec=vs.prec, C_snow=vs.C_snow, S_snow=vs.S_snow)
 
     return GoldenSAS()
