@@ -20,6 +20,19 @@
  * dirac (2), kumaraswami (3, 31-37), exponential (51), power (6, 61, 62).  Gamma (4) and the reversed exponential
  * (52) are not implemented: rh_sas_sync reports a column that asks for them (RH_ERR_STATE).
  *
+ * With `tracer = RH_SAS_TRACER_BROMIDE` (settings.enable_bromide) the same step runs the reference's anion kernels
+ * instead, where msa_* hold solute MASS by age and C_* are concentrations in mg/l:
+ *   calc_infiltration_rz/ss_transport_anion_kernel core/infiltration.py:2350-2424, 2516-2566
+ *   calc_evaporation_transport_kernel              core/evapotranspiration.py:620-650 (water only)
+ *   calc_transpiration_transport_anion_kernel      core/evapotranspiration.py:905-985 (alpha_transp, crop uptake switch)
+ *   calc_percolation_rz/ss_transport_anion_kernel  core/subsurface_runoff.py:1630-1716, 1823-1893 (alpha_q)
+ *   calc_capillary_rise_rz_transport_anion_kernel  core/capillary_rise.py:503-590
+ *   calc_root_zone/subsoil_transport_anion_kernel, calculate_soil_transport_anion_kernel
+ *                                                  core/root_zone.py:221-258, subsoil.py:186-223, soil.py:1094-1142
+ *   calc_ageing_sa_kernel, calc_ageing_msa_kernel  core/transport.py:623-680, 743-778
+ * with calc_mtt's anion branch (transport.py:583-596); RH_SAS_RESCALE then follows rescale_sa_msa_anion_soil_kernel's
+ * bromide branch (core/soil.py:1399-1506).  Chloride, nitrate and the virtual tracer are not implemented.
+ *
  * Same conventions as roger_hip.h: plain pointers and sizes, 0 / negative rh_status returns,
  * rh_sas_last_error for the text, one context = one HIP device + one stream, asynchronous
  * launches fenced by rh_sas_sync / rh_sas_download.
@@ -42,6 +55,8 @@
 extern "C" {
 #endif
 
+#define RH_SAS_TRACER_OXYGEN18 0
+#define RH_SAS_TRACER_BROMIDE 1
 #define RH_SAS_MAX_NAGES 4096 /* ages + 1 <= this (benchmark: ages = 1000, SVATOXYGEN18_benchmark.py:28-44) */
 
 typedef struct rh_sas_config {
@@ -53,6 +68,8 @@ typedef struct rh_sas_config {
     int32_t age_statistics;    /* settings.enable_age_statistics */
     int32_t keep_distributions;/* also write tt_*, mtt_*, TT_*, sa_s, msa_s (diagnostics) */
     double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78) */
+    int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 (settings.enable_oxygen18) | RH_SAS_TRACER_BROMIDE (settings.enable_bromide) */
+    int32_t reserved;
 } rh_sas_config;
 
 typedef struct rh_sas_ctx rh_sas_ctx;

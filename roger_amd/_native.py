@@ -114,7 +114,11 @@ def load():
 class RhSasConfig(C.Structure):
     _fields_ = [("n_cells", C.c_int64), ("ages", C.c_int32), ("substeps", C.c_int32), ("device", C.c_int32),
                 ("forcing_days", C.c_int32), ("age_statistics", C.c_int32), ("keep_distributions", C.c_int32),
-                ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double)]
+                ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double),
+                ("tracer", C.c_int32), ("reserved", C.c_int32)]
+
+
+SAS_TRACERS = {"oxygen18": 0, "bromide": 1}   # RH_SAS_TRACER_*
 
 
 def _declare_sas(lib):
@@ -168,10 +172,14 @@ class SasContext:
     """One SAS / oxygen-18 transport problem on the device (rh_sas_ctx).  Thin, 1:1 with the C ABI."""
 
     def __init__(self, n_cells, ages, substeps=1, device=0, forcing_days=1, age_statistics=False,
-                 keep_distributions=False, **settings):
+                 keep_distributions=False, tracer="oxygen18", **settings):
         lib = load()
         cfg = RhSasConfig()
         lib.rh_sas_default_config(C.byref(cfg))
+        if tracer not in SAS_TRACERS:
+            raise ValueError(f"tracer {tracer!r}: the hip backend transports {sorted(SAS_TRACERS)}")
+        cfg.tracer = SAS_TRACERS[tracer]
+        self.tracer = tracer
         cfg.n_cells, cfg.ages, cfg.substeps, cfg.device = int(n_cells), int(ages), int(substeps), int(device)
         cfg.forcing_days = int(forcing_days)
         cfg.age_statistics, cfg.keep_distributions = int(bool(age_statistics)), int(bool(keep_distributions))
@@ -210,7 +218,7 @@ class SasContext:
         i = self.index(name)
         elems = self._lib.rh_sas_array_elems(self._h, i)
         if elems == 0:
-            raise NativeError(f"array {name} is not held by this context (age_statistics / keep_distributions)")
+            raise NativeError(f"array {name} is not held by this context (age_statistics / keep_distributions / tracer)")
         if name in DAILY_INPUTS:
             return (self.forcing_days, self.n)
         if elems == self.n:

@@ -158,7 +158,7 @@ enum SasArr {
     SA_COUNT
 };
 enum SasKind { K_AGE, K_NAGE, K_CELL, K_DAILY, K_PARAM, K_MASK };
-enum SasWhen { W_ALWAYS, W_STATS, W_DIAG };
+enum SasWhen { W_ALWAYS, W_STATS, W_DIAG, W_ANION };
 
 static const char *const SAS_NAMES[] = {
 #define RH_SAS_ARRAY(name, kind, when) #name,
@@ -729,6 +729,153 @@ SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bromide: the reference's anion kernels.  msa is solute mass by age; a flux takes
+// mtt = msa / sa * alpha * tt * flux, clipped to [0, msa] (calc_mtt, core/transport.py:583-596).
+// ---------------------------------------------------------------------------------------------
+
+// TT = cumsum(tt) for the age statistics (KEEP) and the diagnostics arrays; mtt may be null (soil evaporation)
+template <int W, int E, bool KEEP>
+SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, int base, const double (&tt)[E], const double *mtt,
+                         Dist<E> &keep) {
+    if (!(P.diag || (KEEP && P.stats))) return;
+    const int A = P.ages;
+    double TT_hi[E], TT_lo;
+    blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
+    if (KEEP) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            keep.tt[j] = tt[j];
+            keep.TT_hi[j] = TT_hi[j];
+        }
+        keep.TT_lo = TT_lo;
+    }
+    if (P.diag) {
+        double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
+        double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
+        double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
+        if (B.tid == 0) o_TT[0] = 0.0;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (base + j < A) {
+                o_tt[base + j] = tt[j];
+                if (mtt) o_mtt[base + j] = mtt[j];
+                o_TT[base + j + 1] = TT_hi[j];
+            }
+    }
+}
+
+// One outgoing flux of the anion kernels.  WATER: calc_evaporation_transport_kernel (core/evapotranspiration.py:620-650),
+// the solute stays behind.  Otherwise calc_transpiration_transport_anion_kernel (:905-985),
+// calc_percolation_rz/ss_transport_anion_kernel (core/subsurface_runoff.py:1630-1716, 1823-1893),
+// calc_capillary_rise_rz_transport_anion_kernel (core/capillary_rise.py:503-590).
+template <int W, int E, bool SINK, bool KEEP, bool WATER>
+SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double alpha, double (&sa)[E], double (&msa)[E],
+                           double (&sa_sink)[E], double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
+    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
+    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
+    double tt[E];
+    calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
+    double mtt[E], s[1] = {0.0};
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        tt[j] *= mk;
+        if (!WATER) {
+            double m = (sa[j] > 0 ? msa[j] / sa[j] : 0) * alpha * tt[j] * flux;
+            m = (m <= 0 ? 0 : m);
+            m = (m > msa[j] ? msa[j] : m);
+            mtt[j] = m * mk;
+            s[0] += mtt[j];
+        }
+    }
+    record_dist<W, E, KEEP>(B, P, cell, f, base, tt, WATER ? nullptr : mtt, keep);
+    if (!WATER) {
+        blk_sum<W, 1>(B, s);
+        if (B.tid == 0) {
+            ((double *)P.a[SA_C_evap_soil + f])[cell] = (flux > 0 ? s[0] / flux : 0) * mk;
+            ((double *)P.a[SA_M_evap_soil + f])[cell] = s[0] * mk;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        double v = sa[j] + -flux * tt[j];  // update_sa :599-619
+        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
+        sa[j] = v * mk;
+        if (!WATER) msa[j] += -mtt[j] * mk;
+        if (SINK) {
+            msa_sink[j] += mtt[j] * mk;
+            sa_sink[j] += tt[j] * flux * mk;
+        }
+    }
+}
+
+// calc_infiltration_rz_transport_anion_kernel (core/infiltration.py:2350-2424): matrix and preferential-flow
+// infiltration join age class 0 in one addition; calc_infiltration_ss_transport_anion_kernel (:2516-2566).
+template <int W, int E>
+SAS_DEV void inflow_anion(Blk<W> &B, const SasArgs &P, int64_t cell, bool subsoil, double (&sa)[E], double (&msa)[E], double mk,
+                          int base) {
+    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
+    double d_sa, d_msa;
+    if (!subsoil) {
+        const double im = ((const double *)P.a[SA_inf_mat_rz])[P.day_off + cell];
+        const double ip = ((const double *)P.a[SA_inf_pf_rz])[P.day_off + cell];
+        const double C0 = (im > 0 ? C_in : 0) * mk, C1 = (ip > 0 ? C_in : 0) * mk;
+        const double M0 = C0 * im * mk, M1 = C1 * ip * mk;
+        if (B.tid == 0) {
+            ((double *)P.a[SA_C_inf_mat_rz])[cell] = C0;
+            ((double *)P.a[SA_C_inf_pf_rz])[cell] = C1;
+            ((double *)P.a[SA_M_inf_mat_rz])[cell] = M0;
+            ((double *)P.a[SA_M_inf_pf_rz])[cell] = M1;
+        }
+        d_sa = im + ip * mk;
+        d_msa = M0 + M1 * mk;
+    } else {
+        const double ip = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell];
+        const double C2 = (ip > 0 ? C_in : 0) * mk;
+        const double M2 = C2 * ip * mk;
+        if (B.tid == 0) {
+            ((double *)P.a[SA_C_inf_pf_ss])[cell] = C2;
+            ((double *)P.a[SA_M_inf_pf_ss])[cell] = M2;
+        }
+        d_sa = ip * mk;
+        d_msa = M2 * mk;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+        if (base + j == 0) {
+            sa[j] += d_sa;
+            msa[j] += d_msa;
+        }
+}
+
+// calc_ageing_sa (core/transport.py:623-652) and calc_ageing_msa (:655-680): shift by one class, merge the oldest
+template <int W, int E>
+SAS_DEV void ageing_anion(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E]) {
+    double p_sa, p_msa;
+    blk_prev2<W>(B, sa[E - 1], msa[E - 1], 0.0, 0.0, p_sa, p_msa);
+    double n_sa[E], n_msa[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = base + j;
+        n_sa[j] = (j == 0 ? p_sa : sa[j > 0 ? j - 1 : 0]);
+        n_msa[j] = (j == 0 ? p_msa : msa[j > 0 ? j - 1 : 0]);
+        if (k == 0) {
+            n_sa[j] = 0;
+            n_msa[j] = 0;
+        }
+        if (k == A - 1) {
+            n_sa[j] += sa[j];
+            n_sa[j] = (n_sa[j] < 1e-8 ? 0 : n_sa[j]);
+            n_msa[j] += msa[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        sa[j] = n_sa[j];
+        msa[j] = n_msa[j];
+    }
+}
+
 // tt / TT of one flux back from the diagnostics arrays (age statistics in a launch of their own)
 template <int E>
 SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> &D) {
@@ -753,7 +900,7 @@ SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> 
 #else
 #define SAS_OCCUPANCY
 #endif
-template <int W, int E>
+template <int W, int E, bool ANION>
 __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
@@ -791,6 +938,33 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     const bool stats = P.stats && (P.stages & RH_SAS_STORAGE);
 
     // order of svat_transport_model_deterministic :949-991
+    if constexpr (ANION) {
+        const double alpha_q = ((const double *)P.a[SA_alpha_q])[cell];
+        if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, sa_rz, msa_rz, mk, base);
+        if (P.stages & RH_SAS_EVAP)
+            outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+        if (P.stages & RH_SAS_TRANSP) {
+            // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
+            const int lu = ((const int *)P.a[SA_lu_id])[cell];
+            double S[1] = {0.0};
+#pragma unroll
+            for (int j = 0; j < E; ++j) S[0] += sa_rz[j];
+            blk_sum<W, 1>(B, S);
+            const bool stop = (lu > 500) && (lu < 599) && (S[0] >= 0.8 * ((const double *)P.a[SA_S_sat_rz])[cell]);
+            const double alpha = (stop ? 0 : ((const double *)P.a[SA_alpha_transp])[cell]) * mk;
+            outflux_anion<W, E, false, true, false>(B, P, cell, 1, alpha, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+            have_transp = true;
+        }
+        if (P.stages & RH_SAS_Q_RZ)
+            outflux_anion<W, E, true, false, false>(B, P, cell, 2, alpha_q, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
+        if (P.stages & RH_SAS_INF_SS) inflow_anion<W, E>(B, P, cell, true, sa_ss, msa_ss, mk, base);
+        if (P.stages & RH_SAS_Q_SS) {
+            outflux_anion<W, E, false, true, false>(B, P, cell, 3, alpha_q, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
+            have_q_ss = true;
+        }
+        if (P.stages & RH_SAS_CPR)
+            outflux_anion<W, E, true, false, false>(B, P, cell, 4, alpha_q, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
+    } else {
     if (P.stages & RH_SAS_INF_RZ) {
         inflow<W, E>(B, P, cell, 0, sa_rz, msa_rz, mk, base);
         inflow<W, E>(B, P, cell, 1, sa_rz, msa_rz, mk, base);
@@ -807,6 +981,7 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
         have_q_ss = true;
     }
     if (P.stages & RH_SAS_CPR) outflux<W, E, true, false>(B, P, cell, 4, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
+    }
 
     if (P.stages & RH_SAS_STORAGE) {
         // calc_root_zone_transport_iso_kernel (core/root_zone.py:189-217), calc_subsoil_transport_iso_kernel
@@ -818,22 +993,39 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             sa_rz[j] = (sa_rz[j] < 1e-8 ? 0 : sa_rz[j]);
             sa_ss[j] = (sa_ss[j] < 1e-8 ? 0 : sa_ss[j]);
             sa_s[j] = sa_rz[j] + sa_ss[j] * mk;
-            const double tot = sa_rz[j] + sa_ss[j];
-            const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
-            msa_s[j] = (v != v) ? 0 : v;
-            s[0] += msa_rz[j] * sa_rz[j];
+            if constexpr (ANION) {
+                // calc_root_zone/subsoil_transport_anion_kernel (core/root_zone.py:221-258, subsoil.py:186-223),
+                // calculate_soil_transport_anion_kernel (core/soil.py:1094-1142): M = nansum(msa), C = M / sum(sa)
+                msa_rz[j] = (sa_rz[j] <= 0 ? 0 : msa_rz[j]);
+                msa_ss[j] = (sa_ss[j] <= 0 ? 0 : msa_ss[j]);
+                msa_s[j] = msa_rz[j] + msa_ss[j] * mk;
+                s[0] += (msa_rz[j] != msa_rz[j]) ? 0 : msa_rz[j];
+                s[2] += (msa_ss[j] != msa_ss[j]) ? 0 : msa_ss[j];
+                s[4] += (msa_s[j] != msa_s[j]) ? 0 : msa_s[j];
+            } else {
+                const double tot = sa_rz[j] + sa_ss[j];
+                const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
+                msa_s[j] = (v != v) ? 0 : v;
+                s[0] += msa_rz[j] * sa_rz[j];
+                s[2] += msa_ss[j] * sa_ss[j];
+                s[4] += msa_s[j] * sa_s[j];
+            }
             s[1] += sa_rz[j];
-            s[2] += msa_ss[j] * sa_ss[j];
             s[3] += sa_ss[j];
-            s[4] += msa_s[j] * sa_s[j];
             s[5] += sa_s[j];
         }
         blk_sum<W, 6>(B, s);
-        if (B.tid == 0) {  // calc_conc_iso_storage :538-562
+        if (B.tid == 0) {
             for (int k = 0; k < 3; ++k) {
-                const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0) * mk;
-                ((double *)P.a[SA_C_rz + k])[cell] = C;
-                ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+                if constexpr (ANION) {
+                    const double M = s[2 * k] * mk;
+                    ((double *)P.a[SA_M_rz + k])[cell] = M;
+                    ((double *)P.a[SA_C_rz + k])[cell] = (s[2 * k + 1] > 0 ? M / s[2 * k + 1] : 0);
+                } else {  // calc_conc_iso_storage :538-562
+                    const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0) * mk;
+                    ((double *)P.a[SA_C_rz + k])[cell] = C;
+                    ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+                }
             }
         }
         if (P.diag) {
@@ -875,6 +1067,10 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             sa_rz[j] = in ? S_rz_init * (sa_rz[j] / t[0]) : 0.0;
             sa_ss[j] = in ? S_ss_init * (sa_ss[j] / t[1]) : 0.0;
             sa_s[j] = sa_rz[j] + sa_ss[j];
+            if constexpr (ANION) {  // rescale_sa_msa_anion_soil_kernel, bromide (core/soil.py:1399-1506): the soil starts free of it
+                msa_rz[j] = 0;
+                msa_ss[j] = 0;
+            }
             const double tot = sa_rz[j] + sa_ss[j];
             const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
             msa_s[j] = ((v != v) || (base + j == 0)) ? 0 : v;
@@ -890,7 +1086,8 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             for (int k = 0; k < 3; ++k) {
                 const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
                 ((double *)P.a[SA_C_rz + k])[cell] = C;
-                ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+                if constexpr (ANION) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
+                else ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
             }
         }
         if (P.diag) {
@@ -905,8 +1102,13 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     }
 
     if (P.stages & RH_SAS_AGEING) {
-        ageing<W, E>(B, A, base, sa_rz, msa_rz);
-        ageing<W, E>(B, A, base, sa_ss, msa_ss);
+        if constexpr (ANION) {
+            ageing_anion<W, E>(B, A, base, sa_rz, msa_rz);
+            ageing_anion<W, E>(B, A, base, sa_ss, msa_ss);
+        } else {
+            ageing<W, E>(B, A, base, sa_rz, msa_rz);
+            ageing<W, E>(B, A, base, sa_ss, msa_ss);
+        }
     }
 
     {
@@ -967,6 +1169,7 @@ static int64_t sas_elems(const rh_sas_config &c, int a) {
     const int when = SAS_WHEN[a];
     if (when == W_STATS && !c.age_statistics) return 0;
     if (when == W_DIAG && !c.keep_distributions) return 0;
+    if (when == W_ANION && c.tracer != RH_SAS_TRACER_BROMIDE) return 0;
     switch (SAS_KIND[a]) {
     case K_AGE: return c.n_cells * c.ages;
     case K_NAGE: return c.n_cells * (c.ages + 1);
@@ -980,7 +1183,10 @@ static int64_t sas_elems(const rh_sas_config &c, int a) {
 
 template <int W, int E>
 static void launch_sas(rh_sas_ctx *ctx, const SasArgs &args) {
-    hipLaunchKernelGGL((k_sas<W, E>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
+    if (ctx->cfg.tracer == RH_SAS_TRACER_BROMIDE)
+        hipLaunchKernelGGL((k_sas<W, E, true>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
+    else
+        hipLaunchKernelGGL((k_sas<W, E, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
 }
 
 extern "C" {
@@ -1015,6 +1221,8 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
     if (cfg->ages < 2 || cfg->ages + 1 > RH_SAS_MAX_NAGES)
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: ages must be in [2, RH_SAS_MAX_NAGES - 1]");
     if (cfg->substeps < 1 || cfg->forcing_days < 1) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: substeps and forcing_days must be >= 1");
+    if (cfg->tracer != RH_SAS_TRACER_OXYGEN18 && cfg->tracer != RH_SAS_TRACER_BROMIDE)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18 or RH_SAS_TRACER_BROMIDE");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");
@@ -1054,6 +1262,12 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
         std::vector<int32_t> ones((size_t)cfg->n_cells, 1);
         if ((e = hipMemcpyAsync(ctx->arr[SA_maskCatch], ones.data(), ones.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpy(maskCatch)");
+        if (cfg->tracer == RH_SAS_TRACER_BROMIDE) {   // alpha_transp, alpha_q: initial=1 (roger/variables.py:5377-5405)
+            std::vector<double> one((size_t)cfg->n_cells, 1.0);
+            for (int a : {SA_alpha_transp, SA_alpha_q})
+                if ((e = hipMemcpyAsync(ctx->arr[a], one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+                    return bail(e, "hipMemcpy(alpha)");
+        }
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     }
     *out = ctx;

@@ -20,10 +20,14 @@ CASES = [c for c in SAS_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz")
 def make_ctx(st, **kw):
     from roger_amd import _native
 
-    ctx = _native.SasContext(st.n, st.ages, st.substeps, age_statistics=st.age_statistics, keep_distributions=True, **kw)
+    ctx = _native.SasContext(st.n, st.ages, st.substeps, age_statistics=st.age_statistics, keep_distributions=True,
+                             tracer=st.tracer, **kw)
     ctx.upload("maskCatch", st.maskCatch)
     for f in FLUXES:
         ctx.upload(f"sas_params_{f}", st.sas[f])
+    if st.anion:
+        for k, a in st.par.items():
+            ctx.upload(k, a)
     return ctx
 
 
@@ -133,8 +137,10 @@ def random_problem(n, ages, substeps, seed, stats=False):
 
 
 def clone(st):
-    c = SasState(st.n, st.ages, st.substeps, st.age_statistics)
+    c = SasState(st.n, st.ages, st.substeps, st.age_statistics, tracer=st.tracer)
     c.maskCatch[:] = st.maskCatch
+    for k in st.par:
+        c.par[k][:] = st.par[k]
     for k in st.state:
         c.state[k][:] = st.state[k]
     for k in st.inp:

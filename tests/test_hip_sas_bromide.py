@@ -1,0 +1,222 @@
+"""GPU parity of the bromide transport step (tracer = RH_SAS_TRACER_BROMIDE: the reference's anion kernels, where msa is
+solute mass by age) against the reference's golden run and the CPU oracle, through the C ABI of include/roger_hip_sas.h.
+
+Tolerance (fp64): rtol 1e-10 / atol 1e-11 on every output of a day started from the reference's state; the kernel keeps
+the reference's operation order per element, its sums over the age axis are parallel."""
+import numpy as np
+import pytest
+
+from sas_binding import FLUXES, SasGolden, SasState, compare_sas
+from test_hip_sas import clone, make_ctx, pull, push, random_problem
+from test_oracle_sas import bromide_names
+
+pytestmark = pytest.mark.gpu
+
+
+def check(st, want_of, names, tag, rtol=1e-10, atol=1e-11):
+    for k in names:
+        got = st.state[k] if k in st.state else st.out[k]
+        compare_sas(got, want_of(k), f"{tag} {k}", rtol=rtol, atol=atol)
+
+
+def test_single_days_from_reference_states():
+    g = SasGolden("sas_bromide_a40")
+    st = g.new_state()
+    ctx = make_ctx(st)
+    assert ctx.tracer == "bromide"
+    for d in range(1, g.ndays + 1):
+        g.load_state(st, d - 1)
+        g.load_inputs(st, d)
+        push(ctx, st)
+        ctx.step(0)
+        pull(ctx, st)
+        check(st, lambda k: g.day(d, k), bromide_names(bool(g.stats)), f"bromide day {d}")
+    ctx.close()
+
+
+def test_trajectory_on_device():
+    """Twelve days free-running on the device (state never leaves HBM) against the reference's trajectory."""
+    g = SasGolden("sas_bromide_a40")
+    st = g.new_state()
+    ctx = make_ctx(st)
+    g.load_state(st, 0)
+    push(ctx, st)
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        for k, a in st.inp.items():
+            ctx.upload(k, a[None, :])
+        ctx.step(0)
+        pull(ctx, st)
+        check(st, lambda k: g.day(d, k), bromide_names(bool(g.stats)), f"bromide trajectory day {d}", rtol=1e-9)
+    ctx.close()
+
+
+def test_stage_by_stage_equals_fused():
+    from roger_amd._native import SAS_STAGES
+
+    g = SasGolden("sas_bromide_a40")
+    st = g.new_state()
+    fused, split = make_ctx(st), make_ctx(st)
+    d = 6
+    g.load_state(st, d - 1)
+    g.load_inputs(st, d)
+    push(fused, st)
+    push(split, st)
+    fused.step(0)
+    for name in ("INF_RZ", "EVAP", "TRANSP", "Q_RZ", "INF_SS", "Q_SS", "CPR", "STORAGE", "AGEING"):
+        split.stages(0, SAS_STAGES[name])
+    for nm in fused.names:
+        try:
+            a = fused.download(nm)
+        except Exception:
+            continue
+        b = split.download(nm)
+        if nm[:2] in ("tt", "rt") and a.ndim == 1:
+            assert np.allclose(a, b, rtol=1e-12, atol=0, equal_nan=True), nm
+        else:
+            assert np.array_equal(a, b, equal_nan=True), nm
+    fused.close()
+    split.close()
+
+
+def bromide_problem(n, ages, substeps, seed, stats):
+    st0 = random_problem(n, ages, substeps, seed, stats)
+    st = SasState(n, ages, substeps, stats, tracer="bromide")
+    st.maskCatch[:] = st0.maskCatch
+    for k in st0.state:
+        st.state[k][:] = st0.state[k]
+    for k in st0.inp:
+        st.inp[k][:] = st0.inp[k]
+    for k in st0.sas:
+        st.sas[k][:] = st0.sas[k]
+    rng = np.random.default_rng(seed + 1)
+    for key in ("rz", "ss"):   # solute mass by age: a concentration of 0 .. 20 mg/l in two thirds of the classes
+        conc = rng.uniform(0, 20, (n, ages)) * (rng.uniform(size=(n, ages)) < 0.66)
+        st.state[f"msa_{key}"][:] = st.state[f"sa_{key}"] * conc
+    st.inp["C_in"][:] = rng.uniform(0, 60, n) * (rng.uniform(size=n) < 0.5)
+    st.par["alpha_transp"][:] = rng.uniform(0.1, 1.0, n)
+    st.par["alpha_q"][:] = rng.uniform(0.3, 1.2, n)
+    st.par["lu_id"][:] = rng.choice([8, 10, 510, 550, 598, 599, 600], n)
+    st.par["S_sat_rz"][:] = st.state["sa_rz"].sum(axis=1) * rng.choice([0.9, 1.1, 1.3, 1.6], n)   # 80 % rule on both sides
+    return st
+
+
+@pytest.mark.parametrize("n,ages,substeps,stats", [(96, 1000, 4, True), (120, 300, 3, False), (48, 1500, 2, True),
+                                                  (40, 2500, 2, False), (200, 17, 4, True), (150, 100, 5, True)])
+def test_random_columns_against_oracle(n, ages, substeps, stats):
+    """Every workgroup shape on random columns, three days in a row, all SAS families; the oracle runs beside.
+
+    Residue ties (sas_binding.FIRST_TIE) weigh more here than with oxygen-18: soil evaporation takes water only, so an
+    age class it empties keeps its solute with `sa - flux * (sa / flux)` = 0 or ~1e-16 mm of water.  With the residue,
+    calc_mtt's `msa / sa * alpha * tt * flux` hands alpha times that class's solute to the next flux; without it,
+    nothing -- and the storage kernel drops it at the end of the day (`msa = where(sa <= 0, 0, msa)`).  The last bit of
+    `pow` decides.  Columns without such a class must agree to 1e-10 (>= 90 % of them); in the others the solute terms
+    may differ by what one age class holds, the water terms stay within the oxygen-18 loose bound."""
+    st = bromide_problem(n, ages, substeps, 100 + ages, stats)
+    ref = clone(st)
+    ctx = make_ctx(st)
+    push(ctx, st)
+    names = bromide_names(stats)
+    rng = np.random.default_rng(5)
+    frac = []
+    for day in range(3):
+        day_start = {k: st.state[k].copy() for k in ("msa_rz", "msa_ss")}
+        ref.step_oracle()
+        ctx.step(0)
+        ctx.sync()
+        pull(ctx, st)
+        tight = np.ones(n, bool)
+        # what a residue tie can move in a column (see the docstring): the solute of one age class
+        class_mass = np.maximum(day_start["msa_rz"].max(axis=1), day_start["msa_ss"].max(axis=1)) + 1e-9
+        for k in names:
+            a = st.state[k] if k in st.state else st.out[k]
+            b = ref.state[k] if k in ref.state else ref.out[k]
+            is_stat = k[:2] in ("tt", "rt") and a.ndim == 1
+            ok = np.isclose(a, b, rtol=1e-9 if is_stat else 1e-10, atol=1e-11, equal_nan=True).reshape(n, -1).all(axis=1)
+            if k.startswith(("mtt_", "msa_", "M_")):
+                dev = np.abs(a - b).reshape(n, -1).max(axis=1)
+                assert (dev <= 2.5 * class_mass).all(), f"day {day} {k}: a column moved by more than a tie can, {dev.max()}"
+            elif not k.startswith("C_"):   # water: as for oxygen-18
+                lo = 0.05 if is_stat else 5e-3
+                loose = np.isclose(a, b, rtol=lo, atol=lo, equal_nan=True) | (is_stat & (np.isnan(a) ^ np.isnan(b)))
+                assert loose.all(), f"day {day} {k}: beyond the loose bound, max dev {np.nanmax(np.abs(a - b))}"
+            tight &= ok
+        frac.append(tight.mean())
+        # the next day starts from the device's state on both sides (ties do not accumulate into the comparison)
+        for k in st.state:
+            ref.state[k][:] = st.state[k]
+        for side in (st, ref):
+            side.inp["transp"][:] = side.inp["transp"] * 0.5
+        new_cin = rng.uniform(0, 60, n)
+        st.inp["C_in"][:] = new_cin
+        ref.inp["C_in"][:] = new_cin
+        for k, a in st.inp.items():
+            ctx.upload(k, a[None, :])
+    assert min(frac) >= 0.9, frac   # residue ties of the discontinuous / power-law families (sas_binding.FIRST_TIE)
+    ctx.close()
+
+
+def test_rescale_after_warmup():
+    """RH_SAS_RESCALE with bromide: the age vectors are rescaled to the initial storages and the soil is emptied of bromide
+    (rescale_sa_msa_anion_soil_kernel, core/soil.py:1399-1506)."""
+    from roger_amd._native import SAS_STAGES
+
+    st = bromide_problem(64, 200, 2, 9, False)
+    st.S_init["S_rz_init"][:] = st.state["sa_rz"].sum(axis=1) * 1.1
+    st.S_init["S_ss_init"][:] = st.state["sa_ss"].sum(axis=1) * 0.9
+    ref = clone(st)
+    for k in st.S_init:
+        ref.S_init[k][:] = st.S_init[k]
+    ctx = make_ctx(st)
+    push(ctx, st)
+    for k, a in st.S_init.items():
+        ctx.upload(k, a)
+    ctx.stages(0, SAS_STAGES["RESCALE"])
+    pull(ctx, st)
+    ref.rescale_oracle()
+    for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss"):
+        compare_sas(st.state[k], ref.state[k], f"rescale {k}", rtol=1e-12)
+    for k in ("sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s"):
+        compare_sas(st.out[k], ref.out[k], f"rescale {k}", rtol=1e-12)
+    assert not st.state["msa_rz"].any() and not st.out["M_s"].any()
+    np.testing.assert_allclose(st.state["sa_rz"].sum(axis=1), st.S_init["S_rz_init"], rtol=1e-12)
+    ctx.close()
+
+
+def test_tracer_specific_arrays():
+    from roger_amd import _native
+
+    iso = _native.SasContext(4, 30, 1)
+    with pytest.raises(_native.NativeError):
+        iso.shape("M_rz")
+    iso.close()
+    br = _native.SasContext(4, 30, 1, tracer="bromide")
+    np.testing.assert_array_equal(br.download("alpha_transp"), 1.0)   # initial=1 (roger/variables.py:5377-5405)
+    np.testing.assert_array_equal(br.download("alpha_q"), 1.0)
+    assert br.download("lu_id").dtype == np.int32
+    br.close()
+    with pytest.raises(ValueError):
+        _native.SasContext(4, 30, 1, tracer="nitrate")
+
+
+def test_mass_balance_large():
+    """1e4 columns x 1000 ages, 3 days: bromide in = bromide stored + taken up + percolated, to the solute dropped with
+    emptied age classes (never gained)."""
+    n, ages = 10000, 1000
+    st = bromide_problem(n, ages, 2, 77, False)
+    st.maskCatch[:] = 1
+    for f in FLUXES:
+        st.sas[f][:, 0] = 6
+    ctx = make_ctx(st)
+    push(ctx, st)
+    m0 = st.state["msa_rz"].sum(axis=1) + st.state["msa_ss"].sum(axis=1)
+    gain = np.zeros(n)
+    for day in range(3):
+        ctx.step(0)
+        gain += sum(ctx.download(f"M_{k}") for k in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"))
+        gain -= ctx.download("M_transp") + ctx.download("M_q_ss")
+    m1 = ctx.download("msa_rz").sum(axis=1) + ctx.download("msa_ss").sum(axis=1)
+    assert (m1 <= (m0 + gain) * (1 + 1e-9) + 1e-6).all()
+    loss = ((m0 + gain) - m1) / (m0 + gain)
+    assert np.median(loss) < 1e-6 and np.quantile(loss, 0.99) < 2e-2 and loss.max() < 0.3, (np.median(loss), loss.max())
+    ctx.close()
