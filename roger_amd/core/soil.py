@@ -20,8 +20,8 @@ def calculate_initial_conditions(state):
 
 
 def rescale_SA(state):
-    """roger/core/soil.py:1650-1671 for oxygen-18: rescale_sa_msa_iso_soil_kernel as one native launch
-    (rh_sas_stages with RH_SAS_RESCALE)."""
+    """roger/core/soil.py:1650-1671: rescale_sa_msa_iso_soil_kernel (oxygen-18) or the bromide branch of
+    rescale_sa_msa_anion_soil_kernel as one native launch (rh_sas_stages with RH_SAS_RESCALE)."""
     from .. import _native
 
     sas = state.sas_context
@@ -30,4 +30,5 @@ def rescale_SA(state):
     vs = state.variables
     vs.flush_to_device()
     sas.stages(0, _native.SAS_STAGES["RESCALE"])
-    vs.mark_device_newer(["sa_rz", "sa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"])
+    vs.mark_device_newer(["sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s",
+                          "M_rz", "M_ss", "M_s"])

@@ -26,6 +26,15 @@ def conc_to_delta(state, conc):
 
 
 def _written_by_step(settings):
+    if settings.enable_bromide:   # the anion kernels: solute masses instead of delta values, no signal of the soil evaporation
+        names = ["sa_rz", "msa_rz", "sa_ss", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s"]
+        for f in SAS_FLUXES:
+            names += [f"tt_{f}", f"TT_{f}"] + ([f"mtt_{f}", f"C_{f}", f"M_{f}"] if f != "evap_soil" else [])
+        for f in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
+            names += [f"C_{f}", f"M_{f}"]
+        if settings.enable_age_statistics:
+            names += [f"{p}{q}_{w}" for w, p in SAS_STAT_TARGETS for q in ("10", "25", "50", "75", "90", "avg")]
+        return names
     names = ["sa_rz", "msa_rz", "sa_ss", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "C_iso_rz", "C_iso_ss", "C_iso_s"]
     for f in SAS_FLUXES:
         names += [f"tt_{f}", f"mtt_{f}", f"TT_{f}", f"C_{f}", f"C_iso_{f}"]
@@ -38,7 +47,7 @@ def _written_by_step(settings):
 
 @roger_routine
 def calculate_storage_selection(state):
-    """roger/core/transport.py:3136 for `enable_oxygen18 and sas_solver == "deterministic"`:
+    """roger/core/transport.py:3136 for `(enable_oxygen18 or enable_bromide) and sas_solver == "deterministic"`:
     svat_transport_model_deterministic (:949-991) as one native launch (rh_sas_step).  What the user's
     set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
     `vs.<name>` is read."""

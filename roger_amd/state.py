@@ -335,13 +335,14 @@ class RogerState:
 
         device = int(os.environ.get("LOCAL_RANK", "0"))
         if s.enable_offline_transport:
-            # offline oxygen-18 transport: the state lives in a SAS context (include/roger_hip_sas.h); the reference's
+            # offline oxygen-18 / bromide transport: the state lives in a SAS context (include/roger_hip_sas.h); the reference's
             # variables tt_*, mtt_*, TT_*, sa_s, msa_s are exposed, hence keep_distributions
             if self._var_meta is None:
                 self._var_meta = var_mod.build_transport_variables(s)
             self._sas_ctx = _native.SasContext(
                 (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,
-                age_statistics=s.enable_age_statistics, keep_distributions=True, vsmow=s.VSMOW_conc18O,
+                age_statistics=s.enable_age_statistics, keep_distributions=True,
+                tracer="bromide" if s.enable_bromide else "oxygen18", vsmow=s.VSMOW_conc18O,
                 d18O_min=s.d18O_min, d18O_max=s.d18O_max)
             self._ctx = HostScalars()
             self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)

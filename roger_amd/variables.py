@@ -169,6 +169,17 @@ def build_transport_variables(settings):
         for w, p in SAS_STAT_TARGETS:
             for q in ("10", "25", "50", "75", "90", "avg"):
                 V[f"{p}{q}_{w}"] = Variable(f"{p}{q}_{w}", CATCH_GRID, sas=f"{p}{q}_{w}")
+    if settings.enable_bromide:
+        # the anion kernels' variables (roger/variables.py:534, 2114-2122, 2474, 2536, 4071, 4324, 4666, 5377-5405, 5602)
+        V["S_sat_rz"] = Variable("S_sat_rz", CATCH_GRID, sas="S_sat_rz")
+        V["lu_id"] = Variable("lu_id", CATCH_GRID, dtype=i64, sas="lu_id")
+        for name in ("alpha_transp", "alpha_q"):
+            V[name] = Variable(name, CATCH_GRID, initial=1, sas=name)
+        for f in SAS_FLUXES + ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
+            V[f"M_{f}"] = Variable(f"M_{f}", CATCH_GRID, sas=f"M_{f}")
+        for st in ("rz", "ss", "s"):
+            V[f"M_{st}"] = Variable(f"M_{st}", CATCH_GRID + TIMESTEPS, sas=f"M_{st}")
+        V["M_in"] = Variable("M_in", CATCH_GRID)
     return V
 
 

@@ -12,10 +12,11 @@ from roger_amd._native import DAILY_INPUTS, NativeError
 
 class OracleSasContext:
     def __init__(self, n_cells, ages, substeps=1, device=0, forcing_days=1, age_statistics=False,
-                 keep_distributions=False, **settings):
+                 keep_distributions=False, tracer="oxygen18", **settings):
         assert forcing_days == 1
         self.n, self.ages, self.substeps, self.forcing_days = int(n_cells), int(ages), int(substeps), 1
-        self.st = sb.SasState(self.n, self.ages, self.substeps, age_statistics)
+        self.tracer = tracer
+        self.st = sb.SasState(self.n, self.ages, self.substeps, age_statistics, tracer=tracer)
         self.keep = keep_distributions
         self.names = list(self._arrays())
 
@@ -27,6 +28,8 @@ class OracleSasContext:
         out.update({f"sas_params_{f}": a for f, a in st.sas.items()})
         out.update(st.S_init)
         out.update(st.out)
+        if st.anion:
+            out.update(st.par)
         return out
 
     def shape(self, name):
@@ -34,7 +37,7 @@ class OracleSasContext:
         return (1, self.n) if name in DAILY_INPUTS else a.shape
 
     def dtype(self, name):
-        return np.int32 if name == "maskCatch" else np.float64
+        return np.int32 if name in ("maskCatch", "lu_id") else np.float64
 
     def upload(self, name, host):
         a = np.asarray(host)

@@ -9,7 +9,7 @@ import pytest
 
 import sas_binding as sb
 from sas_scripts import make_transport_model
-from test_host_package_sas import golden_inputs, interior
+from test_host_package_sas import bromide_model, golden_inputs, interior, run_and_compare_bromide
 
 pytestmark = pytest.mark.gpu
 
@@ -67,4 +67,13 @@ def test_transport_warmup_on_device():
     assert vs.itt == g.ndays
     for k in ("sa_rz", "sa_ss"):
         assert np.isclose(interior(getattr(vs, k), 1), g.day(g.ndays, k), rtol=5e-3, atol=5e-3).all(), k
+    model.state.sas_context.close()
+
+
+def test_bromide_setup_on_device():
+    """settings.enable_bromide through roger_amd on the real context: the reference's twelve-day bromide run."""
+    g = sb.SasGolden("sas_bromide_a40")
+    model = bromide_model(g)
+    run_and_compare_bromide(g, model)
+    assert model.state.sas_context.tracer == "bromide"
     model.state.sas_context.close()

@@ -95,3 +95,57 @@ def test_transport_settings_are_checked(oracle_sas):
     with pytest.raises(ValueError, match="unexpected shape"):
         with m.state.variables.unlock():
             m.state.variables.sa_rz = np.zeros((3, 3))
+
+
+# --- bromide ---------------------------------------------------------------------------------------------------------
+
+def bromide_model(g, pkg="roger_amd"):
+    svat, sas = golden_inputs(g)
+    shape = (g.nx, g.ny)
+    C_IN = np.zeros(shape + (g.ndays + 1,))
+    for d in range(1, g.ndays + 1):
+        C_IN[:, :, d] = g.day(d, "C_in").reshape(shape)
+    extra = {k: g.z[k].reshape(shape) for k in ("alpha_transp", "alpha_q", "lu_id")}
+    extra["C_IN"] = C_IN
+    return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer="bromide", extra=extra)
+
+
+TWO_LEVELS = ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")   # (x, y, timesteps, ...)
+
+
+def run_and_compare_bromide(g, model, rtol=1e-9):
+    """The setup class that produced sas_bromide_a40 through the reference (settings.enable_bromide, the anion kernels),
+    run free through roger_amd: every day of the trajectory."""
+    from test_oracle_sas import bromide_names
+
+    model.setup()
+    model.warmup(repeat=0)
+    vs = model.state.variables
+    for d in range(1, g.ndays + 1):
+        model.step(model.state)
+        assert vs.itt == d
+        for k in bromide_names(bool(g.stats)) + ["C_in", "M_in"]:
+            v = getattr(vs, k)
+            lvl = 1 if k in TWO_LEVELS else None
+            sb.compare_sas(interior(v, lvl), g.day(d, k), f"bromide day {d} {k}", rtol=rtol, atol=1e-11)
+        for k in ("M_rz", "C_ss", "sa_rz"):   # after_substep_anion: taum1 follows tau
+            sb.compare_sas(interior(getattr(vs, k), 0), g.day(d, k), f"bromide day {d} {k}[taum1]", rtol=rtol, atol=1e-11)
+
+
+def test_bromide_setup_through_host_package(oracle_sas):
+    g = sb.SasGolden("sas_bromide_a40")
+    run_and_compare_bromide(g, bromide_model(g))
+
+
+def test_transport_needs_exactly_one_tracer():
+    g = sb.SasGolden("sas_bromide_a40")
+    model = bromide_model(g)
+
+    class Both(type(model)):
+        def set_settings(self, state):
+            super().set_settings(state)
+            with state.settings.unlock():
+                state.settings.enable_oxygen18 = True
+
+    with pytest.raises(NotImplementedError, match="exactly one"):
+        Both().setup()
