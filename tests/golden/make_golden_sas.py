@@ -211,6 +211,7 @@ def main():
         "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
         "sas_warmup_a30": (2, 2, 10, 30, 3, "power", False, 23, True),
         "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
+        "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

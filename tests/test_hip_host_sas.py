@@ -77,3 +77,10 @@ def test_bromide_setup_on_device():
     run_and_compare_bromide(g, model)
     assert model.state.sas_context.tracer == "bromide"
     model.state.sas_context.close()
+
+
+def test_bromide_warmup_on_device():
+    g = sb.SasGolden("sas_bromide_warmup_a30")
+    model = bromide_model(g, warmup_days=g.ndays)
+    run_and_compare_bromide(g, model, warmup=1)
+    model.state.sas_context.close()

@@ -183,6 +183,35 @@ def test_rescale_after_warmup():
     ctx.close()
 
 
+def test_rescale_against_reference():
+    """The reference's own warm-up state -> RH_SAS_RESCALE on the device -> the reference's rescaled state, then the
+    run proper on the device."""
+    from roger_amd._native import SAS_STAGES
+
+    g = SasGolden("sas_bromide_warmup_a30")
+    st = g.new_state()
+    for k in st.state:
+        st.state[k][:] = g.z[f"w000_{k}"]
+    for k in st.S_init:
+        st.S_init[k][:] = g.z[k]
+    ctx = make_ctx(st)
+    push(ctx, st)
+    for k, a in st.S_init.items():
+        ctx.upload(k, a)
+    ctx.stages(0, SAS_STAGES["RESCALE"])
+    pull(ctx, st)
+    check(st, lambda k: g.day(0, k), ["sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s"],
+          "bromide rescale")
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        for k, a in st.inp.items():
+            ctx.upload(k, a[None, :])
+        ctx.step(0)
+        pull(ctx, st)
+        check(st, lambda k: g.day(d, k), bromide_names(bool(g.stats)), f"bromide after warm-up day {d}", rtol=1e-9)
+    ctx.close()
+
+
 def test_tracer_specific_arrays():
     from roger_amd import _native
 

@@ -99,7 +99,7 @@ def test_transport_settings_are_checked(oracle_sas):
 
 # --- bromide ---------------------------------------------------------------------------------------------------------
 
-def bromide_model(g, pkg="roger_amd"):
+def bromide_model(g, pkg="roger_amd", warmup_days=0):
     svat, sas = golden_inputs(g)
     shape = (g.nx, g.ny)
     C_IN = np.zeros(shape + (g.ndays + 1,))
@@ -107,20 +107,25 @@ def bromide_model(g, pkg="roger_amd"):
         C_IN[:, :, d] = g.day(d, "C_in").reshape(shape)
     extra = {k: g.z[k].reshape(shape) for k in ("alpha_transp", "alpha_q", "lu_id")}
     extra["C_IN"] = C_IN
-    return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer="bromide", extra=extra)
+    return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=warmup_days,
+                                tracer="bromide", extra=extra)
 
 
 TWO_LEVELS = ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")   # (x, y, timesteps, ...)
 
 
-def run_and_compare_bromide(g, model, rtol=1e-9):
+def run_and_compare_bromide(g, model, rtol=1e-9, warmup=0):
     """The setup class that produced sas_bromide_a40 through the reference (settings.enable_bromide, the anion kernels),
     run free through roger_amd: every day of the trajectory."""
     from test_oracle_sas import bromide_names
 
     model.setup()
-    model.warmup(repeat=0)
+    model.warmup(repeat=warmup)
     vs = model.state.variables
+    if warmup:   # soil.rescale_SA: rescaled age vectors, the soil emptied of bromide
+        for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "M_rz", "C_s"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"bromide after warm-up {k}", rtol=rtol, atol=1e-11)
+        assert not np.asarray(vs.msa_rz).any() and vs.itt == 0
     for d in range(1, g.ndays + 1):
         model.step(model.state)
         assert vs.itt == d
@@ -135,6 +140,11 @@ def run_and_compare_bromide(g, model, rtol=1e-9):
 def test_bromide_setup_through_host_package(oracle_sas):
     g = sb.SasGolden("sas_bromide_a40")
     run_and_compare_bromide(g, bromide_model(g))
+
+
+def test_bromide_warmup_and_run(oracle_sas):
+    g = sb.SasGolden("sas_bromide_warmup_a30")
+    run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
 
 
 def test_transport_needs_exactly_one_tracer():

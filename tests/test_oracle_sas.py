@@ -157,3 +157,24 @@ def test_bromide_trajectory():
     # (not exact: an age class emptied of water drops what solute it still held, `msa = where(sa <= 0, 0, msa)`)
     np.testing.assert_allclose(st.out["M_s"], m_in - m_out, rtol=1e-4, atol=1e-9)
     assert (st.out["M_s"] <= (m_in - m_out) * (1 + 1e-12) + 1e-9).all()
+
+
+def test_bromide_rescale_after_warmup():
+    """rescale_sa_msa_anion_soil_kernel, bromide branch (core/soil.py:1399-1506): the reference's state after its warm-up
+    run (w000_*) -> rescaled age vectors, the soil emptied of bromide (d000_*); then the run proper, free-running."""
+    g = SasGolden("sas_bromide_warmup_a30")
+    st = g.new_state()
+    for k in st.state:
+        st.state[k][:] = g.z[f"w000_{k}"]
+    assert st.state["msa_rz"].any()          # the warm-up run left bromide in the soil
+    for k in st.S_init:
+        st.S_init[k][:] = g.z[k]
+    st.rescale_oracle()
+    for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss"):
+        compare_sas(st.state[k], g.day(0, k), f"bromide rescale {k}")
+    for k in ("sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s"):
+        compare_sas(st.out[k], g.day(0, k), f"bromide rescale {k}")
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        st.step_oracle()
+        check_day_bromide(g, st, d, "bromide after warm-up", rtol=1e-9)
