@@ -271,6 +271,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.timing_summary()
+    per_ms, per_dt = ctx.timing_detail()
     ctx.enable_timing(False)
     s1 = ctx.get_scalars()
     if world > 1:
@@ -312,6 +313,13 @@ def main():
                 "cells_per_gpu": n_local,
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, one 256-byte predicate all-reduce per step",
+                # per time-step class (kernel time only, rank 0); `value` is the aggregate over the run
+                "dt_classes": {
+                    name: {"steps": int((per_dt == secs).sum()),
+                           "avg_kernel_ms": float(per_ms[per_dt == secs].mean()),
+                           "cell_timesteps_per_s_kernel": float(n_local / (per_ms[per_dt == secs].mean() / 1e3))}
+                    for name, secs in (("10min", 600), ("1h", 3600), ("24h", 86400)) if (per_dt == secs).any()
+                },
             },
             "roofline": {
                 "bound": "hbm",

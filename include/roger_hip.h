@@ -227,6 +227,9 @@ int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps);
  * time and the number of timed launches since then. */
 int rh_enable_timing(rh_ctx *ctx, int on);
 int rh_timing_summary(rh_ctx *ctx, double *total_ms, int64_t *launches);
+/* Per timed launch: the kernel's duration and the dt_secs of its step (600 / 3600 / 86400: the time-step classes of
+ * adaptive_time_stepping, core/adaptive_time_stepping.py:22-381), the first min(cap, *launches) of them. */
+int rh_timing_detail(rh_ctx *ctx, double *kernel_ms, int32_t *dt_secs, int64_t cap, int64_t *launches);
 
 /* Profiling aid: one kernel that copies `nplanes` float64 planes src_plane0.. -> dst_plane0.. with
  * the access shape of the fused kernel (8 bytes per lane and plane); moves a known

@@ -105,6 +105,7 @@ def load():
     lib.rh_predicate_words.argtypes = [vp]
     lib.rh_predicate_words.restype = vp
     lib.rh_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.rh_timing_detail.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
     lib.rh_enable_timing.argtypes = [vp, i32]
     _declare_sas(lib)
     _lib = lib
@@ -321,7 +322,7 @@ DECLARED_SYMBOLS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
-    "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_enable_timing", "rh_set_forcing_series",
+    "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights",
@@ -511,4 +512,13 @@ class Context:
         ms, cnt = C.c_double(), C.c_int64()
         self._check(self._lib.rh_timing_summary(self._h, C.byref(ms), C.byref(cnt)), "rh_timing_summary")
         return float(ms.value), int(cnt.value)
-        return float(ms.value)
+
+    def timing_detail(self, cap=65536):
+        """(kernel ms, dt_secs) per timed launch since enable_timing(True): the time-step class of every step."""
+        ms = np.zeros(cap, dtype=np.float64)
+        dts = np.zeros(cap, dtype=np.int32)
+        cnt = C.c_int64()
+        self._check(self._lib.rh_timing_detail(self._h, ms.ctypes.data_as(C.POINTER(C.c_double)),
+                                               dts.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(cnt)), "rh_timing_detail")
+        k = min(int(cnt.value), cap)
+        return ms[:k], dts[:k]

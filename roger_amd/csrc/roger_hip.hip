@@ -56,6 +56,9 @@ struct DevState {
     long long *diag_steps;         // steps accumulated per day slot (the divisor of the "average" diagnostic)
     int diag_rate, diag_collect, diag_slots;
     int diag_planes[32];
+    // rh_enable_timing: dt_secs of every step since then (the time-step class of each timed launch)
+    int *dt_log;
+    int dt_log_cap, dt_log_n;
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
     const double *forc_cell[3];        // per-cell forcing (n, 144) or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
@@ -97,8 +100,10 @@ struct rh_ctx {
     bool timing;
     std::vector<hipEvent_t> events;  // pairs (start, stop) around the fused kernel, one per timed step
     size_t ev_used;
+    int *dt_log_buf;
     std::string err;
 };
+#define RH_DT_LOG_CAP 65536
 
 static std::string g_create_err;
 
@@ -541,6 +546,11 @@ RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int a
     }
     D->S = S;
     D->X = X;
+    if (D->dt_log) {
+        const int k = D->dt_log_n;
+        if (k < D->dt_log_cap) D->dt_log[k] = (int)dts;
+        D->dt_log_n = k + 1;
+    }
 }
 
 // ---- summary path (shared forcing): the whole control part of a step in ONE single-workgroup kernel ----------
@@ -1027,6 +1037,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->forcing_set = false;
     ctx->timing = false;
     ctx->ev_used = 0;
+    ctx->dt_log_buf = nullptr;
     ctx->dev = nullptr;
     ctx->arena.base = nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
@@ -1103,6 +1114,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->dt_log_buf) (void)hipFree(ctx->dt_log_buf);
     for (auto &b : ctx->forc_cell_buf)
         if (b) (void)hipFree(b);
     for (auto &b : ctx->weight_buf)
@@ -1625,6 +1637,32 @@ int rh_enable_timing(rh_ctx *ctx, int on) {
     if (!ctx) return RH_ERR_ARG;
     ctx->timing = on != 0;
     ctx->ev_used = 0;
+    if (on && !ctx->dt_log_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->dt_log_buf, sizeof(int) * RH_DT_LOG_CAP));
+    int *log = on ? ctx->dt_log_buf : nullptr;
+    const int cap = RH_DT_LOG_CAP, zero = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->dt_log, &log, sizeof(int *), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->dt_log_cap, &cap, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->dt_log_n, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_timing_detail(rh_ctx *ctx, double *kernel_ms, int32_t *dt_secs, int64_t cap, int64_t *launches) {
+    if (!ctx || !kernel_ms || !dt_secs || !launches || cap < 0) return RH_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int logged = 0;
+    if (ctx->dt_log_buf) HIPCHK(ctx, hipMemcpy(&logged, &ctx->dev->dt_log_n, sizeof(int), hipMemcpyDeviceToHost));
+    const int64_t n = (int64_t)(ctx->ev_used / 2);
+    if (logged != n || n > RH_DT_LOG_CAP)
+        return fail(ctx, RH_ERR_STATE, "rh_timing_detail: the step log does not match the timed launches (timing enabled mid-step, "
+                                       "or more than 65536 steps)");
+    *launches = n;
+    const int64_t m = n < cap ? n : cap;
+    for (int64_t k = 0; k < m; ++k) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[2 * k], ctx->events[2 * k + 1]));
+        kernel_ms[k] = ms;
+    }
+    if (m) HIPCHK(ctx, hipMemcpy(dt_secs, ctx->dt_log_buf, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
     return RH_OK;
 }
 int rh_timing_summary(rh_ctx *ctx, double *total_ms, int64_t *launches) {

@@ -341,3 +341,24 @@ def test_weighted_station_forcing_on_device(native, oracle):
     compare_bulk(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"weighted forcing, {steps} steps")
     assert len({600, 3600, 86400} & {int(st.scal.dt_secs)}) == 1 and steps > 40
     ctx.close()
+
+
+def test_timing_detail_reports_time_step_classes():
+    """rh_timing_detail: dt_secs of every timed step from the device-side log, one kernel duration each; the classes
+    add up to the simulated time."""
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.svat import create_svat
+
+    ctx = create_svat(64, 32, device=0)
+    ctx.set_forcing_series(combo_forcing(ndays=30))
+    ctx.run_steps(3)
+    s0 = ctx.get_scalars()
+    ctx.enable_timing(True)
+    ctx.run_steps(150)
+    ms, dts = ctx.timing_detail()
+    ctx.enable_timing(False)
+    s1 = ctx.get_scalars()
+    assert len(ms) == len(dts) == 150 and (ms > 0).all()
+    assert set(np.unique(dts)) <= {600, 3600, 86400} and len(np.unique(dts)) >= 2
+    assert int(dts.sum()) == s1.time - s0.time
+    ctx.close()
