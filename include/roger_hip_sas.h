@@ -17,8 +17,8 @@
  *   calc_ageing_sa_msa_iso_kernel                  core/transport.py:682-739, 780-805
  * with the helpers calc_SA, calc_tt, calc_mtt, calc_conc_iso_flux, calc_conc_iso_storage,
  * conc_to_delta, update_sa (transport.py:315-619) and the SAS families of core/sas.py: uniform (code 1),
- * dirac (2), kumaraswami (3, 31-37), exponential (51), power (6, 61, 62).  Gamma (4) and the reversed exponential
- * (52) are not implemented: rh_sas_sync reports a column that asks for them (RH_ERR_STATE).
+ * dirac (2), kumaraswami (3, 31-37), gamma (4), exponential (51, 52), power (6, 61, 62).  rh_sas_sync reports a column
+ * whose code is none of these (RH_ERR_STATE).
  *
  * With `tracer = RH_SAS_TRACER_BROMIDE` (settings.enable_bromide) the same step runs the reference's anion kernels
  * instead, where msa_* hold solute MASS by age and C_* are concentrations in mg/l:

@@ -15,8 +15,8 @@
  * pairwise (oc_np_sum), `max` propagates NaN, `where` evaluates both branches.
  * SAS families: uniform (code 1), dirac (2), kumaraswami (3, 31-37), exponential (51) and power law (6, 61, 62)
  * -- roger/core/sas.py; every family contributes exactly 0 for the codes of the others, so the reference's sum
- * over all families is the selected one.  Not restated: gamma (4, needs scipy's gammainc) and exponential with
- * reversed age order (52).
+ * over all families is the selected one.  Also gamma (4; the incomplete gamma function by series / continued
+ * fraction instead of scipy's cephes code) and the exponential with reversed age order (52).
  */
 #include <math.h>
 #include <stdint.h>
@@ -99,6 +99,41 @@ static void calc_SA(double *SA, const double *sa, int64_t ages) {
     }
 }
 
+/* Regularised lower incomplete gamma function P(a, x) -- what scipy.special.gammainc returns (the gamma SAS family,
+ * sas.py:153).  scipy's implementation (cephes igam / igamc with Temme's expansion for large a) is not restated: P is a
+ * mathematical function, evaluated here by its power series for x < a + 1 and by the continued fraction of Q = 1 - P
+ * (modified Lentz) otherwise, both to double precision; pinned against the reference's outputs by the golden case
+ * sas_gamma_a40. */
+static double oc_gammainc(double a, double x) {
+    if (!(x > 0) || !(a > 0)) return 0.0;
+    const double lead = exp(a * log(x) - x - lgamma(a));
+    if (x < a + 1) {
+        double ap = a, del = 1 / a, sum = del;
+        for (int n = 0; n < 2000; ++n) {
+            ap += 1;
+            del *= x / ap;
+            sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        return sum * lead;
+    }
+    const double tiny = 1e-300;
+    double b = x + 1 - a, c = 1 / tiny, d = 1 / b, h = d;
+    for (int i = 1; i < 2000; ++i) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2;
+        d = an * d + b;
+        if (fabs(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1) < 1e-16) break;
+    }
+    return 1 - lead * h;
+}
+
 /* Omega(S_T) over the nages points of SA; sas.py.  `p` is the column's 8 parameters (a private
  * copy: the storage-dependent variants 61/62 rewrite p[1], sas.py:219-226). */
 static void sas_omega(double *Om, const double *SA, int64_t nages, double *p, double mk) {
@@ -147,6 +182,21 @@ static void sas_omega(double *Om, const double *SA, int64_t nages, double *p, do
         const double S = Smax * mk;
         for (int64_t k = 0; k < nages; ++k)
             Om[k] = (SA[k] > 0 ? (SA[k] < S ? 1 - exp(p[1] * (-1) * (SA[k] / S)) : 1.) : 0.) * mk;
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    } else if (code == 52) { /* exponential, age order reversed (preference for old water), sas.py:186-190: Omega then
+                              * DEcreases from 1 to 0 along the age axis and calc_tt clips every difference to 0 */
+        const double S = Smax * mk;
+        for (int64_t k = 0; k < nages; ++k) {
+            const double x = SA[nages - 1 - k];
+            Om[k] = (x > 0 ? (x < S ? 1 - exp(p[1] * (-1) * (x / S)) : 1.) : 0.) * mk;
+        }
+        for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
+    } else if (code == 4) { /* gamma, sas.py:139-163: gammainc is regularised already and is divided by Gamma(a) once
+                             * more; the top edge (SA == S) gets 0, not 1 */
+        const double S = Smax * 1.0 * mk;
+        const double G = exp(lgamma(p[1]));
+        for (int64_t k = 0; k < nages; ++k)
+            Om[k] = (SA[k] > 0 ? (SA[k] < S ? oc_gammainc(p[1], p[2] * SA[k] / S) / G : 0.) : 0) * 1.0 * mk;
         for (int64_t k = 0; k < nages; ++k) Om[k] = (S <= 0 ? 0 : Om[k]) * mk;
     }
 }

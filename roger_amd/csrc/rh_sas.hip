@@ -393,7 +393,39 @@ struct Dist {  // what the age statistics need of one flux
 // (code 1), `dirac` (2), `kumaraswami` (3, 31-37), `exponential` (51) and `power` (6, 61, 62) of core/sas.py.
 // The reference adds the masked results of all six families; every family contributes exact zeros for the
 // codes of the others, so the sum is the selected one.
-enum SasFamily { FAM_NONE, FAM_UNIFORM, FAM_DIRAC, FAM_KUMARASWAMI, FAM_EXPONENTIAL, FAM_POWER };
+enum SasFamily { FAM_NONE, FAM_UNIFORM, FAM_DIRAC, FAM_KUMARASWAMI, FAM_EXPONENTIAL, FAM_POWER, FAM_GAMMA };
+
+// Regularised lower incomplete gamma function P(a, x) = scipy.special.gammainc(a, x) (the gamma SAS family, sas.py:153):
+// power series for x < a + 1, continued fraction of Q = 1 - P (modified Lentz) otherwise; lgam = lgamma(a).
+__device__ __attribute__((noinline)) double sas_gammainc(double a, double x, double lgam) {
+    if (!(x > 0) || !(a > 0)) return 0.0;
+    const double lead = exp(a * log(x) - x - lgam);
+    if (x < a + 1) {
+        double ap = a, del = 1 / a, sum = del;
+        for (int n = 0; n < 2000; ++n) {
+            ap += 1;
+            del *= x / ap;
+            sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        return sum * lead;
+    }
+    const double tiny = 1e-300;
+    double b = x + 1 - a, c = 1 / tiny, d = 1 / b, h = d;
+    for (int i = 1; i < 2000; ++i) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2;
+        d = an * d + b;
+        if (fabs(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1) < 1e-16) break;
+    }
+    return 1 - lead * h;
+}
 // One instantiation per family, selected per column (uniform over the workgroup) by calc_tt below: the benchmark's
 // power law keeps its register budget (3 waves/SIMD without spills) whatever the other families need.
 template <int W, int E, int FAM>
@@ -411,7 +443,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
     }
     const double code = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6];  // read once: the loop below stores nothing, but the compiler cannot know
     constexpr bool uniform = FAM == FAM_UNIFORM, power = FAM == FAM_POWER, dirac = FAM == FAM_DIRAC;
-    constexpr bool kumaraswami = FAM == FAM_KUMARASWAMI, expo = FAM == FAM_EXPONENTIAL;
+    constexpr bool kumaraswami = FAM == FAM_KUMARASWAMI, expo = FAM == FAM_EXPONENTIAL, gamma = FAM == FAM_GAMMA;
     const PowConsts C = load_pow_consts(B.logt);
     const UDiv by_fh = udiv_prepare(fh);
     double Om_edge0 = 0.0;  // Omega at SA[0] = 0: 0 for every family but a dirac with a negative threshold
@@ -423,7 +455,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
     }
     for (int it = 0; it < P.substeps; ++it) {
         double SA_hi[E], SA_lo, Smax;
-        blk_cumsum<W, E, (FAM == FAM_KUMARASWAMI || FAM == FAM_EXPONENTIAL)>(B, san, SA_hi, SA_lo, &Smax, base, A - 1);
+        blk_cumsum<W, E, (FAM == FAM_KUMARASWAMI || FAM == FAM_EXPONENTIAL || FAM == FAM_GAMMA)>(B, san, SA_hi, SA_lo, &Smax, base, A - 1);
         if (it == 0) {  // the first sub-step sees SA = calc_SA(sa) * maskCatch, the later ones cumsum(san) (:456-459)
 #pragma unroll
             for (int j = 0; j < E; ++j) SA_hi[j] *= mk;
@@ -496,6 +528,15 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
                 const double o = (x > 0 ? (x < S ? 1 - exp(p1 * (-1) * (x / S)) : 1.) : 0.) * mk;
                 Om[j] = (S <= 0 ? 0 : o) * mk;
             }
+        } else if (gamma) {  // sas.py:139-163, code 4: the regularised gammainc divided by Gamma(a) once more; 0 at SA == S
+            const double S = Smax * 1.0 * mk;
+            const double lgam = lgamma(p1);
+            const double G = exp(lgam);
+            for (int j = 0; j < E; ++j) {
+                const double x = SA_hi[j];
+                const double o = (x > 0 ? (x < S ? sas_gammainc(p1, p2 * x / S, lgam) / G : 0.) : 0) * 1.0 * mk;
+                Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) Om[j] = 0.0;
@@ -536,9 +577,14 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
     else if (code == 3 || (code >= 31 && code <= 37)) calc_tt_family<W, E, FAM_KUMARASWAMI>(B, P, p, flux, sa, mk, base, tt);
     else if (code == 2) calc_tt_family<W, E, FAM_DIRAC>(B, P, p, flux, sa, mk, base, tt);
     else if (code == 51) calc_tt_family<W, E, FAM_EXPONENTIAL>(B, P, p, flux, sa, mk, base, tt);
+#ifndef RH_SAS_NO_GAMMA  // (experiments: the kernel without the gamma family's code)
+    else if (code == 4) calc_tt_family<W, E, FAM_GAMMA>(B, P, p, flux, sa, mk, base, tt);
+#endif
     else {
-        // not implemented: gamma (4: incomplete gamma function), exponential with reversed age order (52)
-        if (B.tid == 0 && flux * (1 / (double)P.substeps) > 0) *P.unsupported = 1;
+        // 52, the exponential with reversed age order (sas.py:186-190): Omega DEcreases from 1 to 0 along the age axis,
+        // calc_tt clips every difference to 0 (:430-433) -- no water is selected, like Omega = 0.  Any other code is
+        // unknown to the reference's families (all masked out: Omega = 0 as well) and is reported.
+        if (code != 52 && B.tid == 0 && flux * (1 / (double)P.substeps) > 0) *P.unsupported = 1;
         calc_tt_family<W, E, FAM_NONE>(B, P, p, flux, sa, mk, base, tt);
     }
 }
@@ -1301,7 +1347,7 @@ int rh_sas_sync(rh_sas_ctx *ctx) {
     SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (bad)
         return sfail(ctx, RH_ERR_STATE,
-                     "a column selects a SAS family the hip backend does not implement (gamma 4, reversed exponential 52, or an unknown code)");
+                     "a column's sas_params select a code that is none of the reference's SAS families (1, 2, 3, 31-37, 4, 51, 52, 6, 61, 62)");
     return RH_OK;
 }
 

@@ -125,6 +125,12 @@ def sas_params(nx, ny, variant, seed):
             p[..., 4] = rng.uniform(0.5, 2.0, (nx, ny))
             p[..., 5] = 50.0
             p[..., 6] = 400.0
+        if variant == "gamma":      # gamma (4: shape p1, scale p2; scipy's gammainc), reversed exponential (52), power
+            code = rng.choice([4, 4, 4, 52, 6], (nx, ny))
+            p[..., 0] = code
+            p[..., 1] = np.where(code == 6, p[..., 1], np.where(code == 4, rng.choice([0.4, 0.8, 1.0, 2.5, 6.0], (nx, ny)),
+                                                                rng.uniform(0.5, 5, (nx, ny))))
+            p[..., 2] = rng.uniform(0.8, 9, (nx, ny))
         if variant == "mixed":
             code = rng.choice([6, 1, 61, 62], (nx, ny))
             p[..., 0] = code
@@ -210,6 +216,7 @@ def main():
         "sas_stats_a30": (2, 2, 12, 30, 3, "mixed", True, 11),
         "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
         "sas_warmup_a30": (2, 2, 10, 30, 3, "power", False, 23, True),
+        "sas_gamma_a40": (4, 3, 12, 40, 3, "gamma", False, 37),
         "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
         "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
     }

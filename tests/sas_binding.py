@@ -15,7 +15,7 @@ FLUXES = ("evap_soil", "transp", "q_rz", "q_ss", "cpr_rz")          # order of t
 INFS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss")
 STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
-SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30")
+SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40")
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 
@@ -207,7 +207,10 @@ def compare_sas(got, want, what, rtol=1e-10, atol=1e-12):
 # able to deliver it.  Whether the residue is 0 or 1e-16 depends on the last bit of `pow`, which differs
 # between numpy's AVX-512 pow and libm (and the GPU's ocml pow).  From that day on a trajectory is only
 # reproducible to ~1e-3 mm / 1e-4 permil; the per-day tests from reference states stay at 1e-10.
-FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6}
+FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6, "sas_gamma_a40": 3}
+# Share of (day, column) pairs that must meet the tight tolerance when every day restarts from the reference's state
+# (oracle; measured: gamma 0.972 = 4 of 144, one column whose power-law capillary rise follows a flux that empties classes)
+MIN_TIGHT = {"sas_gamma_a40": 0.97}
 
 
 def check_day_loose(g, st, d, tag, atol_mm=2e-2, atol_permil=2e-3):

@@ -215,18 +215,44 @@ def test_mass_balance_full_age_axis():
     ctx.close()
 
 
-def test_unsupported_family_is_reported():
+def test_unknown_family_is_reported():
     from roger_amd import _native
 
     st = random_problem(8, 40, 2, seed=3)
-    st.sas["transp"][:, 0] = 4          # gamma: not implemented by the hip backend
+    st.sas["transp"][:, 0] = 7          # none of the reference's families (all of them mask it out: no water selected)
     st.inp["transp"][:] = 1.0
     ctx = make_ctx(st)
     push(ctx, st)
     ctx.step(0)
-    with pytest.raises(_native.NativeError, match="SAS family"):
+    with pytest.raises(_native.NativeError, match="SAS families"):
         ctx.sync()
     ctx.close()
+
+
+def test_gamma_and_reversed_exponential_against_oracle():
+    """Codes 4 and 52 on random columns of every workgroup shape: a wide range of shapes / scales for the incomplete
+    gamma function (series and continued-fraction branch), against the oracle's own evaluation."""
+    for n, ages, substeps in ((128, 1000, 3), (200, 100, 4), (60, 2200, 2), (150, 30, 5)):
+        st = random_problem(n, ages, substeps, seed=ages)
+        rng = np.random.default_rng(ages + 1)
+        for f in FLUXES:
+            p = st.sas[f]
+            p[:, 0] = rng.choice([4, 4, 4, 52], n)
+            p[:, 1] = np.where(p[:, 0] == 4, rng.choice([0.2, 0.5, 1.0, 1.7, 3.0, 8.0, 25.0], n), rng.uniform(0.5, 5, n))
+            p[:, 2] = rng.choice([0.3, 1.0, 2.0, 5.0, 12.0, 40.0], n)
+        ref = clone(st)
+        ctx = make_ctx(st)
+        push(ctx, st)
+        ctx.step(0)
+        ctx.sync()
+        pull(ctx, st)
+        ref.step_oracle()
+        tight = column_deviation(st, lambda k: ref.state[k] if k in ref.state else ref.out[k], n, False)
+        assert tight.mean() >= 0.97, (ages, tight.mean())
+        for f in FLUXES:   # the reversed exponential selects nothing
+            rev = st.sas[f][:, 0] == 52
+            assert not st.out[f"tt_{f}"][rev].any()
+        ctx.close()
 
 
 def test_power_function_accuracy():
