@@ -98,7 +98,9 @@ int64_t rh_num_cells(const rh_ctx *ctx);
  * (x, y) interior).  Counterpart of assigning / reading `vs.<name>` in a setup script. */
 int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes);
 int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes);
-/* Device address of a plane, for zero-copy wrapping by the host package. */
+/* Device address of cell 0 of a plane.  The arena is tiled (64 cells per tile, a 512-byte slot per plane and tile,
+ * roger_amd/csrc/rh_col.h): cell i of the plane is at
+ *     ptr + (i / 64) * (rh_num_planes() * 512) + (i % 64) * sizeof(element). */
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane);
 
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s);

@@ -1,10 +1,9 @@
 // rh_col.h -- one soil column ("cell") in registers, and the SoA device arena it is loaded from.
 //
-// Data layout in HBM: one arena per GPU, RH_NPLANES planes, each plane n_cells contiguous
-// elements (float64 or int32) in C order over the rank's interior (x, y) grid, plane p at
-// base + p * stride (stride a multiple of 256 B).  Lane l of a wavefront owns cell
-// blockIdx*256 + l, so every plane access is one fully coalesced 512-byte (float64) request per
-// wave-instruction; nothing is re-read within a kernel.
+// Data layout in HBM: one arena per GPU holding RH_NPLANES planes (float64 or int32) over the rank's interior (x, y)
+// grid in C order, laid out in tiles of 64 cells (see Arena below).  Lane l of a wavefront owns cell blockIdx*256 +
+// 64*wave + l, so every plane access is one fully coalesced 512-byte (float64) request per wave-instruction; nothing is
+// re-read within a kernel.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,24 +27,40 @@ struct Col {
 #undef RH_DECL_I32_2
 };
 
+// RH_TILED = 1 (default): the arena is a sequence of tiles of 64 cells (one wavefront's columns); inside a tile every
+// plane has a 512-byte slot (64 float64, or 64 int32 in its first half), slots in plane order.  Everything one
+// wavefront loads and stores during a step lies in ONE contiguous span of RH_NPLANES * 512 bytes (77 KB) instead of
+// RH_NPLANES addresses 8 MB apart: one or two address translations per wave instead of one per plane, and consecutive
+// plane accesses fall into the same DRAM pages.  A plane access is still one fully coalesced 512-byte request.
+// RH_TILED = 0: plane-major (plane p at base + p * stride), kept for experiments.
+#ifndef RH_TILED
+#define RH_TILED 1
+#endif
+#define RH_TILE_CELLS 64
+#define RH_SLOT_BYTES 512
+
 struct Arena {
     char *base;
-    size_t stride;  // bytes between planes
+    size_t stride;  // tiled: bytes per tile (RH_NPLANES * RH_SLOT_BYTES); plane-major: bytes between planes
     int64_t n;      // cells
 };
 
-RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, double &dst) {
-    dst = reinterpret_cast<const double *>(a.base + (size_t)plane * a.stride)[i];
+// Address of cell i of a plane.  Tiled: the tile index is uniform over the wavefront (every kernel maps lane l of a
+// wave to cell 64 * k + l), so it is taken from the first active lane and the whole tile/plane part of the address is
+// scalar arithmetic; the per-lane part is lane * element size.
+template <typename T>
+RH_DEV T *rh_cell(const Arena &a, int plane, int64_t i) {
+#if RH_TILED
+    const int tile = __builtin_amdgcn_readfirstlane((int)(i >> 6));
+    return reinterpret_cast<T *>(a.base + (size_t)tile * a.stride + (size_t)plane * RH_SLOT_BYTES) + (int)(i & (RH_TILE_CELLS - 1));
+#else
+    return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
+#endif
 }
-RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, int &dst) {
-    dst = reinterpret_cast<const int *>(a.base + (size_t)plane * a.stride)[i];
-}
-RH_DEV void rh_st(const Arena &a, int plane, int64_t i, double v) {
-    reinterpret_cast<double *>(a.base + (size_t)plane * a.stride)[i] = v;
-}
-RH_DEV void rh_st(const Arena &a, int plane, int64_t i, int v) {
-    reinterpret_cast<int *>(a.base + (size_t)plane * a.stride)[i] = v;
-}
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, double &dst) { dst = *rh_cell<const double>(a, plane, i); }
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, int &dst) { dst = *rh_cell<const int>(a, plane, i); }
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, double v) { *rh_cell<double>(a, plane, i) = v; }
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, int v) { *rh_cell<int>(a, plane, i) = v; }
 
 // Settings that the kernels read (subset of rh_config, device copy).
 struct Consts {

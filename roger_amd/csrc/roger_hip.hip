@@ -101,6 +101,7 @@ struct rh_ctx {
     std::vector<hipEvent_t> events;  // pairs (start, stop) around the fused kernel, one per timed step
     size_t ev_used;
     int *dt_log_buf;
+    void *stage_buf;      // one contiguous plane (n * 8 bytes): uploads and downloads pass through it
     std::string err;
 };
 #define RH_DT_LOG_CAP 65536
@@ -914,6 +915,18 @@ __global__ __launch_bounds__(RH_BLOCK) void k_calib_copy(Arena a, int src0, int 
     }
 }
 
+// one plane between the arena and a contiguous buffer of n elements (rh_upload / rh_download / rh_plane_device_ptr)
+template <typename T>
+__global__ __launch_bounds__(RH_BLOCK) void k_plane_gather(Arena a, int plane, T *dst) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i < a.n) dst[i] = *rh_cell<const T>(a, plane, i);
+}
+template <typename T>
+__global__ __launch_bounds__(RH_BLOCK) void k_plane_scatter(Arena a, int plane, const T *src) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i < a.n) *rh_cell<T>(a, plane, i) = src[i];
+}
+
 // initial values of the variable registry that are not zero (roger/variables.py `initial=`)
 __global__ __launch_bounds__(RH_BLOCK) void k_init_registry(Arena a) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -1051,9 +1064,15 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->diag_n = 0;
     ctx->diag_slots = 0;
     ctx->per_cell = false;
-    const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256;
+#if RH_TILED
+    const size_t n_tiles = ((size_t)ctx->n + RH_TILE_CELLS - 1) / RH_TILE_CELLS;
+    const size_t stride = (size_t)RH_NPLANES * RH_SLOT_BYTES, arena_bytes = n_tiles * stride;
+#else
+    const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256, arena_bytes = stride * RH_NPLANES;
+#endif
     ctx->arena.stride = stride;
     ctx->arena.n = ctx->n;
+    ctx->stage_buf = nullptr;
     auto bail = [&](hipError_t e, const char *what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         rh_destroy(ctx);
@@ -1062,8 +1081,9 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     hipError_t e;
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
     ctx->own_stream = true;
-    if ((e = hipMalloc((void **)&ctx->arena.base, stride * RH_NPLANES)) != hipSuccess) return bail(e, "hipMalloc(arena)");
-    if ((e = hipMemsetAsync(ctx->arena.base, 0, stride * RH_NPLANES, ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->arena.base, arena_bytes)) != hipSuccess) return bail(e, "hipMalloc(arena)");
+    if ((e = hipMemsetAsync(ctx->arena.base, 0, arena_bytes, ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
     if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     Consts K;
@@ -1126,6 +1146,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
     if (ctx->diag_steps_buf) (void)hipFree(ctx->diag_steps_buf);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->stage_buf) (void)hipFree(ctx->stage_buf);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1160,7 +1181,12 @@ int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_upload: null host pointer");
-    HIPCHK(ctx, hipMemcpyAsync(ctx->arena.base + (size_t)plane * ctx->arena.stride, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage_buf, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (elem == sizeof(double))
+        hipLaunchKernelGGL(k_plane_scatter<double>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (const double *)ctx->stage_buf);
+    else
+        hipLaunchKernelGGL(k_plane_scatter<int>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (const int *)ctx->stage_buf);
+    CHECK_LAUNCH(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be a temporary
     ctx->summary_valid = false;
     return RH_OK;
@@ -1171,7 +1197,12 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_download: null host pointer");
-    HIPCHK(ctx, hipMemcpyAsync(host, ctx->arena.base + (size_t)plane * ctx->arena.stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (elem == sizeof(double))
+        hipLaunchKernelGGL(k_plane_gather<double>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (double *)ctx->stage_buf);
+    else
+        hipLaunchKernelGGL(k_plane_gather<int>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (int *)ctx->stage_buf);
+    CHECK_LAUNCH(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->stage_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RH_OK;
 }
@@ -1179,7 +1210,11 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
     if (!ctx || plane < 0 || plane >= RH_NPLANES) return nullptr;
     ctx->summary_valid = false;  // the caller may write through the pointer
+#if RH_TILED
+    return ctx->arena.base + (size_t)plane * RH_SLOT_BYTES;   // cell i: + (i / 64) * tile_bytes + (i % 64) * element size
+#else
     return ctx->arena.base + (size_t)plane * ctx->arena.stride;
+#endif
 }
 
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
