@@ -190,6 +190,12 @@ int rh_svat_step(rh_ctx *ctx, int monthly);
  * rh_run_steps and rh_svat_step use this path without the exchange.  Returns RH_ERR_STATE with per-cell forcing. */
 int rh_step_summary(rh_ctx *ctx);
 int rh_step_finish(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-side month-change flag */
+/* The same two calls with the exchange format folded in: rh_step_summary_expand also writes the summary word as 64
+ * int32 (0 / 1) to dev_dst64 (what rh_predicates_expand(ctx, 3, .) would produce), rh_step_finish_compress takes the
+ * all-reduced 64 int32 directly (instead of rh_predicates_compress(ctx, 3, .) + rh_step_finish): two launches less
+ * per step on the multi-GPU path. */
+int rh_step_summary_expand(rh_ctx *ctx, int32_t *dev_dst64);
+int rh_step_finish_compress(rh_ctx *ctx, int monthly, const int32_t *dev_src64);
 /* Device-side `set_forcing` + `set_parameters` hooks (needs rh_set_forcing_series); runs before
  * phase 1. */
 int rh_hooks_phase(rh_ctx *ctx);

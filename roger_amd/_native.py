@@ -90,6 +90,8 @@ def load():
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
+    lib.rh_step_summary_expand.argtypes = [vp, vp]
+    lib.rh_step_finish_compress.argtypes = [vp, i32, vp]
     lib.rh_set_forcing_weights.argtypes = [vp, vp, vp, vp]
     lib.rh_diag_configure.argtypes = [vp, vp, i32, vp, i32, i32]
     lib.rh_diag_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
@@ -324,7 +326,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
-    "rh_step_summary", "rh_step_finish", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
+    "rh_step_summary", "rh_step_finish", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights",
 )
 
@@ -484,6 +486,14 @@ class Context:
 
     def step_finish(self, monthly=-1):
         self._check(self._lib.rh_step_finish(self._h, int(monthly)), "rh_step_finish")
+
+    def step_summary_expand(self, dev_dst64):
+        """rh_step_summary with the summary word also written as 64 int32 (0 / 1) to the device pointer."""
+        self._check(self._lib.rh_step_summary_expand(self._h, C.c_void_p(dev_dst64)), "rh_step_summary_expand")
+
+    def step_finish_compress(self, dev_src64, monthly=-1):
+        """rh_step_finish from the all-reduced 64 int32 at the device pointer."""
+        self._check(self._lib.rh_step_finish_compress(self._h, int(monthly), C.c_void_p(dev_src64)), "rh_step_finish_compress")
 
     def sync(self):
         self.call("rh_sync")

@@ -611,10 +611,20 @@ RH_DEV unsigned long long summary_bits(double swe, double swe_top, double prec, 
     return summary_bits_sw(summary_bits_pt(prec, ta, K), swe, swe_top);
 }
 // from_word3 != 0: the summary was reduced (and exchanged between ranks) before, it sits in words[3]
-__global__ __launch_bounds__(RH_BLOCK) void k_ctrl(DevState *D, int do_hooks, int from_word3) {
+// src64 != null: the exchanged summary arrives as 64 int32 (0 / 1) and is folded here (k_words_compress folded in)
+__global__ __launch_bounds__(RH_BLOCK) void k_ctrl(DevState *D, int do_hooks, int from_word3, const int *src64) {
     if (do_hooks) hooks_set_forcing(D);
     __shared__ unsigned long long s_sum;
     unsigned long long cells;
+    if (src64) {
+        if (threadIdx.x < 64) {
+            unsigned long long b = src64[threadIdx.x] ? (1ull << threadIdx.x) : 0ull;
+            for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
+            if (threadIdx.x == 0) D->words[3] = b;
+        }
+        __threadfence();
+        __syncthreads();
+    }
     if (from_word3) {
         if (threadIdx.x == 0) D->bflags[0][0] = D->words[3];
         __threadfence();
@@ -666,10 +676,12 @@ __global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
     }
 }
 // multi-GPU: OR of the summary words into words[3] for the exchange
-__global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks) {
+// dst64 != null: also spread over 64 int32 (0 / 1) for the MAX all-reduce (k_words_expand folded in)
+__global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks, int *dst64) {
     if (do_hooks) hooks_set_forcing(D);
     const unsigned long long w = reduce_bflags(D->sflags, D->sflag_blocks);
     if (threadIdx.x == 0) D->words[3] = w;
+    if (dst64 && threadIdx.x < 64) dst64[threadIdx.x] = (int)((w >> threadIdx.x) & 1ull);
 }
 
 __global__ void k_advance(DevState *D) {  // roger.py:449-450
@@ -1443,7 +1455,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     if (!ctx->per_cell) {
         // summary path: the previous fused kernel left what the predicates need; one control kernel, one fused kernel
         if (!ctx->summary_valid) LAUNCH_CELLS(ctx, k_summary);
-        LAUNCH_WG(ctx, k_ctrl, ctx->dev, hooks, 0);
+        LAUNCH_WG(ctx, k_ctrl, ctx->dev, hooks, 0, (const int *)nullptr);
         int rc = launch_fused_kernel(ctx, monthly);
         if (rc) return rc;
         CHECK_LAUNCH(ctx);
@@ -1463,7 +1475,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
-int rh_step_summary(rh_ctx *ctx) {
+static int step_summary(rh_ctx *ctx, int32_t *dev_dst64) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
     if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_summary: the summary path needs forcing shared by all columns; use rh_step_phase1/2/3");
@@ -1471,18 +1483,28 @@ int rh_step_summary(rh_ctx *ctx) {
         LAUNCH_CELLS(ctx, k_summary);
         ctx->summary_valid = true;
     }
-    LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0);
+    LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0, (int *)dev_dst64);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
-int rh_step_finish(rh_ctx *ctx, int monthly) {
+static int step_finish(rh_ctx *ctx, int monthly, const int32_t *dev_src64) {
     if (!ctx) return RH_ERR_ARG;
     if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_finish: the summary path needs forcing shared by all columns");
-    LAUNCH_WG(ctx, k_ctrl, ctx->dev, 0, 1);
+    LAUNCH_WG(ctx, k_ctrl, ctx->dev, 0, 1, (const int *)dev_src64);
     int rc = launch_fused_kernel(ctx, monthly);
     if (rc) return rc;
     CHECK_LAUNCH(ctx);
     return RH_OK;
+}
+int rh_step_summary(rh_ctx *ctx) { return step_summary(ctx, nullptr); }
+int rh_step_finish(rh_ctx *ctx, int monthly) { return step_finish(ctx, monthly, nullptr); }
+int rh_step_summary_expand(rh_ctx *ctx, int32_t *dev_dst64) {
+    if (!dev_dst64) return RH_ERR_ARG;
+    return step_summary(ctx, dev_dst64);
+}
+int rh_step_finish_compress(rh_ctx *ctx, int monthly, const int32_t *dev_src64) {
+    if (!dev_src64) return RH_ERR_ARG;
+    return step_finish(ctx, monthly, dev_src64);
 }
 int rh_svat_step(rh_ctx *ctx, int monthly) {
     if (!ctx) return RH_ERR_ARG;

@@ -171,6 +171,16 @@ class PhasedStepper:
         b = self.backend
         if getattr(b, "one_exchange", False):
             # summary path (shared forcing): both predicate words follow from one summary word, include/roger_hip.h
+            if getattr(b, "fused_exchange", False):
+                # the exchange format written / read by the summary and control kernels themselves: per step one
+                # reduction kernel, one 256-byte all-reduce, the control kernel and the fused kernel
+                import torch.distributed as dist
+
+                buf = b.summary_to_buffer()
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+                b.finish_from_buffer(buf)
+                return
             b.summary_phase()
             self._exchange(3)
             b.finish_phase()
@@ -192,11 +202,14 @@ class HipPhases:
     the context's device and all launches go to torch's current stream so that the RCCL
     all-reduce is stream-ordered with the kernels."""
 
-    def __init__(self, ctx, device, one_exchange=True):
+    def __init__(self, ctx, device, one_exchange=True, fused_exchange=True):
         import torch
 
         self.ctx = ctx
         self.one_exchange = one_exchange   # False: the three-phase protocol (needed with per-cell forcing)
+        # the summary / control kernels write and read the 64-int32 exchange format themselves (False: separate
+        # rh_predicates_expand / rh_predicates_compress launches, the generic route also used by the three-phase protocol)
+        self.fused_exchange = fused_exchange
         self.buf = {w: torch.zeros(64, dtype=torch.int32, device=device) for w in (0, 1, 3)}
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
@@ -205,6 +218,13 @@ class HipPhases:
 
     def finish_phase(self):
         self.ctx.step_finish(-1)
+
+    def summary_to_buffer(self):
+        self.ctx.step_summary_expand(self.buf[3].data_ptr())
+        return self.buf[3]
+
+    def finish_from_buffer(self, tensor):
+        self.ctx.step_finish_compress(tensor.data_ptr(), -1)
 
     def hooks_phase(self):
         self.ctx.call("rh_hooks_phase")

@@ -284,19 +284,20 @@ def test_phased_stepper_single_rank(native):
     from roger_amd.distributed import HipPhases, PhasedStepper
 
     g, names, forcing = load_case("svat_hetero_combo")
-    a, b, c = _ctx(native, g, names), _ctx(native, g, names), _ctx(native, g, names)
-    for ctx in (a, b, c):
+    a, b, c, d = (_ctx(native, g, names) for _ in range(4))
+    for ctx in (a, b, c, d):
         ctx.set_forcing_series(forcing)
     dev = torch.device("cuda", 0)
     a.run_steps(120)
     # always_exchange: spread / fold the predicate words through the exchange buffers although there is no peer
-    PhasedStepper(HipPhases(b, dev), always_exchange=True).run(120)                       # one exchange per step
+    PhasedStepper(HipPhases(b, dev), always_exchange=True).run(120)                       # one exchange per step, format folded into the kernels
     PhasedStepper(HipPhases(c, dev, one_exchange=False), always_exchange=True).run(120)   # three-phase protocol
+    PhasedStepper(HipPhases(d, dev, fused_exchange=False), always_exchange=True).run(120)  # one exchange, separate expand / compress
     torch.cuda.synchronize()
-    for other in (b, c):
+    for other in (b, c, d):
         np.testing.assert_array_equal(H.scalars_to_row(a.get_scalars()), H.scalars_to_row(other.get_scalars()))
         np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(other, names))
-    for ctx in (a, b, c):
+    for ctx in (a, b, c, d):
         ctx.close()
 
 
