@@ -44,7 +44,8 @@ typedef struct oc_sas {
     double *stats[5][6];
     /* soil.rescale_SA after the warm-up run */
     const double *S_rz_init, *S_ss_init;
-    /* tracer: 0 oxygen-18 (msa = concentration by age), 1 bromide (anion kernels: msa = solute mass by age) */
+    /* tracer: 0 oxygen-18 (msa = concentration by age), 1 bromide, 2 chloride (anion kernels: msa = solute mass by age;
+     * the two differ in soil.rescale_SA only) */
     int64_t tracer;
     const double *alpha_transp, *alpha_q, *S_sat_rz; /* (n) partition coefficients, saturation storage of the root zone */
     const int32_t *lu_id;                            /* (n) land use: 500 < lu_id < 599 is a crop */
@@ -473,6 +474,20 @@ void oc_sas_rescale(const oc_sas *P) {
         const double t_rz = np_sum(sa_rz, A), t_ss = np_sum(sa_ss, A);
         for (int64_t k = 0; k < A; ++k) sa_rz[k] = P->S_rz_init[i] * (sa_rz[k] / t_rz);
         for (int64_t k = 0; k < A; ++k) sa_ss[k] = P->S_ss_init[i] * (sa_ss[k] / t_ss);
+        if (P->tracer == 2) { /* chloride: rescale_sa_msa_anion_soil_kernel, core/soil.py:1507-1640 -- the solute is scaled
+                               * with the water (by S_init / sum(sa) of the state before the rescaling), M_* stay */
+            const double f_rz = P->S_rz_init[i] / t_rz, f_ss = P->S_ss_init[i] / t_ss;
+            for (int64_t k = 0; k < A; ++k) {
+                msa_rz[k] *= f_rz;
+                msa_ss[k] *= f_ss;
+                P->sa_s[i * A + k] = sa_rz[k] + sa_ss[k];
+                P->msa_s[i * A + k] = msa_rz[k] + msa_ss[k];
+            }
+            P->C_rz[i] = np_sum(msa_rz, A) / np_sum(sa_rz, A);
+            P->C_ss[i] = np_sum(msa_ss, A) / np_sum(sa_ss, A);
+            P->C_s[i] = np_sum(P->msa_s + i * A, A) / np_sum(P->sa_s + i * A, A);
+            continue;
+        }
         if (P->tracer == 1) { /* bromide: rescale_sa_msa_anion_soil_kernel, core/soil.py:1399-1506 -- the soil starts free of bromide */
             for (int64_t k = 0; k < A; ++k) {
                 msa_rz[k] = msa_ss[k] = P->msa_s[i * A + k] = 0;
@@ -508,7 +523,7 @@ void oc_sas_step(const oc_sas *P) {
         const double mk = (double)P->maskCatch[i];
         double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
         double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
-        if (P->tracer == 1) {
+        if (P->tracer != 0) {
             step_anion(P, i, work);
             goto statistics;
         }
@@ -563,7 +578,7 @@ void oc_sas_step(const oc_sas *P) {
                 P->stats[2 + d][5][i] = (np_sum(rt, A) > 0 ? np_sum(prod, A) : NAN);
             }
         }
-        if (P->tracer == 1) {
+        if (P->tracer != 0) {
             ageing_anion(sa_rz, msa_rz, A);
             ageing_anion(sa_ss, msa_ss, A);
             continue;

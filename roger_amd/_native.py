@@ -121,7 +121,7 @@ class RhSasConfig(C.Structure):
                 ("tracer", C.c_int32), ("reserved", C.c_int32)]
 
 
-SAS_TRACERS = {"oxygen18": 0, "bromide": 1}   # RH_SAS_TRACER_*
+SAS_TRACERS = {"oxygen18": 0, "bromide": 1, "chloride": 2}   # RH_SAS_TRACER_*
 
 
 def _declare_sas(lib):

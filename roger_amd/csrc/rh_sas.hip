@@ -179,7 +179,7 @@ static const unsigned char SAS_WHEN[] = {
 struct SasArgs {
     int64_t n;
     int64_t day_off;  // row of the daily inputs * n
-    int ages, substeps, stages, stats, diag;
+    int ages, substeps, stages, stats, diag, tracer;
     double vsmow, dmin, dmax;
     int *unsupported;  // device flag: a column asked for a SAS family this kernel does not implement
     void *a[SA_COUNT];
@@ -1113,13 +1113,30 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             sa_rz[j] = in ? S_rz_init * (sa_rz[j] / t[0]) : 0.0;
             sa_ss[j] = in ? S_ss_init * (sa_ss[j] / t[1]) : 0.0;
             sa_s[j] = sa_rz[j] + sa_ss[j];
-            if constexpr (ANION) {  // rescale_sa_msa_anion_soil_kernel, bromide (core/soil.py:1399-1506): the soil starts free of it
-                msa_rz[j] = 0;
-                msa_ss[j] = 0;
+            if constexpr (ANION) {
+                if (P.tracer == RH_SAS_TRACER_CHLORIDE) {  // rescale_sa_msa_anion_soil_kernel, chloride (core/soil.py:1507-1640):
+                    msa_rz[j] *= S_rz_init / t[0];         // the solute is scaled with the water
+                    msa_ss[j] *= S_ss_init / t[1];
+                } else {  // bromide (:1399-1506): the soil starts free of it
+                    msa_rz[j] = 0;
+                    msa_ss[j] = 0;
+                }
             }
             const double tot = sa_rz[j] + sa_ss[j];
             const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
             msa_s[j] = ((v != v) || (base + j == 0)) ? 0 : v;
+            if constexpr (ANION) {
+                if (P.tracer == RH_SAS_TRACER_CHLORIDE) {   // C = sum(msa) / sum(sa), msa_s = msa_rz + msa_ss
+                    msa_s[j] = msa_rz[j] + msa_ss[j];
+                    s[0] += msa_rz[j];
+                    s[2] += msa_ss[j];
+                    s[4] += msa_s[j];
+                    s[1] += sa_rz[j];
+                    s[3] += sa_ss[j];
+                    s[5] += sa_s[j];
+                    continue;
+                }
+            }
             s[0] += msa_rz[j] * sa_rz[j];
             s[1] += sa_rz[j];
             s[2] += msa_ss[j] * sa_ss[j];
@@ -1130,10 +1147,14 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
         blk_sum<W, 6>(B, s);
         if (B.tid == 0) {
             for (int k = 0; k < 3; ++k) {
-                const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
+                double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
+                if (ANION && P.tracer == RH_SAS_TRACER_CHLORIDE) C = s[2 * k] / s[2 * k + 1];   // unguarded, M_* untouched
                 ((double *)P.a[SA_C_rz + k])[cell] = C;
-                if constexpr (ANION) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
-                else ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+                if constexpr (ANION) {
+                    if (P.tracer != RH_SAS_TRACER_CHLORIDE) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
+                } else {
+                    ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
+                }
             }
         }
         if (P.diag) {
@@ -1215,7 +1236,7 @@ static int64_t sas_elems(const rh_sas_config &c, int a) {
     const int when = SAS_WHEN[a];
     if (when == W_STATS && !c.age_statistics) return 0;
     if (when == W_DIAG && !c.keep_distributions) return 0;
-    if (when == W_ANION && c.tracer != RH_SAS_TRACER_BROMIDE) return 0;
+    if (when == W_ANION && c.tracer == RH_SAS_TRACER_OXYGEN18) return 0;
     switch (SAS_KIND[a]) {
     case K_AGE: return c.n_cells * c.ages;
     case K_NAGE: return c.n_cells * (c.ages + 1);
@@ -1229,7 +1250,7 @@ static int64_t sas_elems(const rh_sas_config &c, int a) {
 
 template <int W, int E>
 static void launch_sas(rh_sas_ctx *ctx, const SasArgs &args) {
-    if (ctx->cfg.tracer == RH_SAS_TRACER_BROMIDE)
+    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18)
         hipLaunchKernelGGL((k_sas<W, E, true>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
     else
         hipLaunchKernelGGL((k_sas<W, E, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
@@ -1267,8 +1288,8 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
     if (cfg->ages < 2 || cfg->ages + 1 > RH_SAS_MAX_NAGES)
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: ages must be in [2, RH_SAS_MAX_NAGES - 1]");
     if (cfg->substeps < 1 || cfg->forcing_days < 1) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: substeps and forcing_days must be >= 1");
-    if (cfg->tracer != RH_SAS_TRACER_OXYGEN18 && cfg->tracer != RH_SAS_TRACER_BROMIDE)
-        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18 or RH_SAS_TRACER_BROMIDE");
+    if (cfg->tracer != RH_SAS_TRACER_OXYGEN18 && cfg->tracer != RH_SAS_TRACER_BROMIDE && cfg->tracer != RH_SAS_TRACER_CHLORIDE)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18, _BROMIDE or _CHLORIDE");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");
@@ -1308,7 +1329,7 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
         std::vector<int32_t> ones((size_t)cfg->n_cells, 1);
         if ((e = hipMemcpyAsync(ctx->arr[SA_maskCatch], ones.data(), ones.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpy(maskCatch)");
-        if (cfg->tracer == RH_SAS_TRACER_BROMIDE) {   // alpha_transp, alpha_q: initial=1 (roger/variables.py:5377-5405)
+        if (cfg->tracer != RH_SAS_TRACER_OXYGEN18) {   // alpha_transp, alpha_q: initial=1 (roger/variables.py:5377-5405)
             std::vector<double> one((size_t)cfg->n_cells, 1.0);
             for (int a : {SA_alpha_transp, SA_alpha_q})
                 if ((e = hipMemcpyAsync(ctx->arr[a], one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
@@ -1435,6 +1456,7 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     args.stages = stages;
     args.stats = c.age_statistics ? 1 : 0;
     args.diag = c.keep_distributions ? 1 : 0;
+    args.tracer = c.tracer;
     args.vsmow = c.vsmow;
     args.dmin = c.d18O_min;
     args.dmax = c.d18O_max;

@@ -90,7 +90,7 @@ _UNSUPPORTED_SWITCHES = (
     "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
-    "enable_chloride", "enable_deuterium", "enable_nitrate", "enable_virtualtracer",
+    "enable_deuterium", "enable_nitrate", "enable_virtualtracer",
 )
 
 
@@ -101,10 +101,10 @@ def check_setting_conflicts(settings):
             raise NotImplementedError(
                 f"settings.{name}=True is outside the hot path of the hip backend (SURVEY.md section 8: out of scope)")
     if settings.enable_offline_transport:
-        # the native transport path: oxygen-18 or bromide with the deterministic SAS solver
-        if settings.enable_oxygen18 == settings.enable_bromide:
-            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18 and for bromide "
-                                      "(exactly one of settings.enable_oxygen18 / settings.enable_bromide must be True)")
+        # the native transport path: oxygen-18, bromide or chloride with the deterministic SAS solver
+        if int(settings.enable_oxygen18) + int(settings.enable_bromide) + int(settings.enable_chloride) != 1:
+            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, bromide and chloride "
+                                      "(exactly one of settings.enable_oxygen18 / enable_bromide / enable_chloride must be True)")
         if settings.sas_solver != "deterministic":
             raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
                                       '"deterministic" SAS solver (Euler / RK4 are out of scope, SURVEY.md section 8)')

@@ -342,7 +342,7 @@ class RogerState:
             self._sas_ctx = _native.SasContext(
                 (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,
                 age_statistics=s.enable_age_statistics, keep_distributions=True,
-                tracer="bromide" if s.enable_bromide else "oxygen18", vsmow=s.VSMOW_conc18O,
+                tracer="bromide" if s.enable_bromide else ("chloride" if s.enable_chloride else "oxygen18"), vsmow=s.VSMOW_conc18O,
                 d18O_min=s.d18O_min, d18O_max=s.d18O_max)
             self._ctx = HostScalars()
             self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)

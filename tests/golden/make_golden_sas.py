@@ -151,7 +151,7 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     rng = np.random.default_rng(seed + 7)
     svat["d18O_prec"] = np.concatenate([[np.nan], rng.uniform(-12, -4, ndays)])
     sas = sas_params(nx, ny, variant, seed)
-    bromide = tracer == "bromide"
+    bromide = tracer in ("bromide", "chloride")   # the anion kernels
     extra = None
     if bromide:   # partition coefficients, a crop column (500 < lu_id < 599) and two bromide pulses in the input
         lu = np.array([8, 550, 10, 5, 8, 560])[np.arange(nx * ny) % 6].reshape(nx, ny)
@@ -160,11 +160,16 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
         C_IN[:, :, 5] = rng.uniform(10, 40, (nx, ny))
         C_IN[:, :, 7] = rng.uniform(5, 20, (nx, ny))
         extra = dict(alpha_transp=rng.uniform(0.2, 1.0, (nx, ny)), alpha_q=rng.uniform(0.4, 1.0, (nx, ny)), lu_id=lu, C_IN=C_IN)
+        if tracer == "chloride":   # chloride comes with every rain and sits in the soil from the start
+            C_IN[:, :, 1:] = rng.uniform(0.5, 3.0, (nx, ny, ndays))
+            extra.update(C_init_rz=4.0, C_init_ss=9.0)
     model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0,
                                  tracer=tracer, extra=extra)
     model.setup()
     vs = model.state.variables
     rec = {"meta": np.array([nx, ny, ndays, ages, substeps, int(age_statistics)])}
+    if bromide:
+        rec["tracer"] = np.array(tracer)
     if warmup:
         # RogerSetup.warmup (roger/roger.py:491-521): one whole run, soil.rescale_SA, itt = time = 0.  The state right
         # before the rescaling is recorded too, so that the rescaling kernel can be pinned on its own.
@@ -219,6 +224,7 @@ def main():
         "sas_gamma_a40": (4, 3, 12, 40, 3, "gamma", False, 37),
         "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
         "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
+        "sas_chloride_warmup_a30": (2, 2, 10, 30, 3, "power", True, 41, True, "chloride"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

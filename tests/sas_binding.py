@@ -73,7 +73,7 @@ class SasState:
         self.n, self.ages, self.substeps = int(n), int(ages), int(substeps)
         self.age_statistics = bool(age_statistics)
         self.tracer = tracer
-        self.anion = tracer == "bromide"   # the reference's anion kernels: msa is solute mass by age
+        self.anion = tracer in ("bromide", "chloride")   # the reference's anion kernels: msa is solute mass by age
         A = self.ages
         z = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
         self.maskCatch = np.ones(n, dtype=np.int32)
@@ -129,7 +129,7 @@ class SasState:
                 for j, q in enumerate(STAT_Q):
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
         s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
-        s.tracer = 1 if self.anion else 0
+        s.tracer = {"oxygen18": 0, "bromide": 1, "chloride": 2}[self.tracer]
         if self.anion:
             for k in ("alpha_transp", "alpha_q", "S_sat_rz"):
                 setattr(s, k, _ptr(self.par[k]))
@@ -155,7 +155,7 @@ class SasGolden:
         self.z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
         self.nx, self.ny, self.ndays, self.ages, self.substeps, self.stats = (int(v) for v in self.z["meta"])
         self.n = self.nx * self.ny
-        self.tracer = "bromide" if "alpha_q" in self.z.files else "oxygen18"
+        self.tracer = str(self.z["tracer"]) if "tracer" in self.z.files else ("bromide" if "alpha_q" in self.z.files else "oxygen18")
 
     def day(self, d, var):
         return self.z[f"d{d:03d}_{var}"]

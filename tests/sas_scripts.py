@@ -21,7 +21,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
     delta_to_conc, conc_to_delta = tr.delta_to_conc, tr.conc_to_delta
 
     nx, ny = svat["S_rz"].shape[:2]
-    bromide = tracer == "bromide"   # anion transport (mass based): models/svat_bromide, deterministic solver
+    chloride = tracer == "chloride"
+    bromide = tracer in ("bromide", "chloride")   # anion transport (mass based): models/svat_bromide, deterministic solver
     extra = extra or {}
 
     class GoldenSAS(RogerSetup):
@@ -44,7 +45,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             s.time_origin = "01-01-2022"
             s.enable_offline_transport = True
             s.enable_oxygen18 = not bromide
-            s.enable_bromide = bromide
+            s.enable_bromide = bromide and not chloride
+            s.enable_chloride = chloride
             s.tm_structure = "power"
             s.enable_age_statistics = bool(age_statistics)
 
@@ -113,6 +115,9 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.sa_s = update(vs.sa_s, at[2:-2, 2:-2, :, :], vs.sa_rz[2:-2, 2:-2, :, :] + vs.sa_ss[2:-2, 2:-2, :, :])
             vs.SA_s = update(vs.SA_s, at[2:-2, 2:-2, :, 1:], npx.cumsum(vs.sa_s[2:-2, 2:-2, :, :], axis=-1))
             if bromide:   # no bromide in the soil at the start (models/svat_bromide/svat_bromide.py:230-260): msa = 0
+                if chloride:   # a background concentration (mg/l) that differs between root zone and subsoil
+                    vs.msa_rz = update(vs.msa_rz, at[2:-2, 2:-2, :, :], vs.sa_rz[2:-2, 2:-2, :, :] * extra["C_init_rz"])
+                    vs.msa_ss = update(vs.msa_ss, at[2:-2, 2:-2, :, :], vs.sa_ss[2:-2, 2:-2, :, :] * extra["C_init_ss"])
                 return
             vs.C_iso_snow = update(vs.C_iso_snow, at[2:-2, 2:-2, : vs.taup1], npx.nan)
             vs.C_iso_rz = update(vs.C_iso_rz, at[2:-2, 2:-2, : vs.taup1], -10)

@@ -84,3 +84,11 @@ def test_bromide_warmup_on_device():
     model = bromide_model(g, warmup_days=g.ndays)
     run_and_compare_bromide(g, model, warmup=1)
     model.state.sas_context.close()
+
+
+def test_chloride_warmup_on_device():
+    g = sb.SasGolden("sas_chloride_warmup_a30")
+    model = bromide_model(g, warmup_days=g.ndays)
+    run_and_compare_bromide(g, model, warmup=1)
+    assert model.state.sas_context.tracer == "chloride"
+    model.state.sas_context.close()

@@ -107,8 +107,10 @@ def bromide_model(g, pkg="roger_amd", warmup_days=0):
         C_IN[:, :, d] = g.day(d, "C_in").reshape(shape)
     extra = {k: g.z[k].reshape(shape) for k in ("alpha_transp", "alpha_q", "lu_id")}
     extra["C_IN"] = C_IN
+    if g.tracer == "chloride":   # the background concentrations tests/golden/make_golden_sas.py starts from
+        extra.update(C_init_rz=4.0, C_init_ss=9.0)
     return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=warmup_days,
-                                tracer="bromide", extra=extra)
+                                tracer=g.tracer, extra=extra)
 
 
 TWO_LEVELS = ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")   # (x, y, timesteps, ...)
@@ -122,10 +124,10 @@ def run_and_compare_bromide(g, model, rtol=1e-9, warmup=0):
     model.setup()
     model.warmup(repeat=warmup)
     vs = model.state.variables
-    if warmup:   # soil.rescale_SA: rescaled age vectors, the soil emptied of bromide
-        for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "M_rz", "C_s"):
-            sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"bromide after warm-up {k}", rtol=rtol, atol=1e-11)
-        assert not np.asarray(vs.msa_rz).any() and vs.itt == 0
+    if warmup:   # soil.rescale_SA: rescaled age vectors, the soil emptied of bromide / chloride scaled with the water
+        for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "C_rz", "C_s"):
+            sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"{g.tracer} after warm-up {k}", rtol=rtol, atol=1e-11)
+        assert np.asarray(vs.msa_rz).any() == (g.tracer == "chloride") and vs.itt == 0
     for d in range(1, g.ndays + 1):
         model.step(model.state)
         assert vs.itt == d
@@ -144,6 +146,12 @@ def test_bromide_setup_through_host_package(oracle_sas):
 
 def test_bromide_warmup_and_run(oracle_sas):
     g = sb.SasGolden("sas_bromide_warmup_a30")
+    run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
+
+
+def test_chloride_warmup_and_run(oracle_sas):
+    """settings.enable_chloride: setup(); warmup(); run() against the reference's chloride run."""
+    g = sb.SasGolden("sas_chloride_warmup_a30")
     run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
 
 

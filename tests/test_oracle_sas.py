@@ -178,3 +178,26 @@ def test_bromide_rescale_after_warmup():
         g.load_inputs(st, d)
         st.step_oracle()
         check_day_bromide(g, st, d, "bromide after warm-up", rtol=1e-9)
+
+
+def test_chloride_rescale_and_run():
+    """settings.enable_chloride: the anion kernels as for bromide; soil.rescale_SA scales the solute with the water
+    (rescale_sa_msa_anion_soil_kernel, core/soil.py:1507-1640).  Reference state after its warm-up run -> rescaled state
+    -> ten days free-running, age statistics on."""
+    g = SasGolden("sas_chloride_warmup_a30")
+    assert g.tracer == "chloride"
+    st = g.new_state()
+    for k in st.state:
+        st.state[k][:] = g.z[f"w000_{k}"]
+    for k in st.S_init:
+        st.S_init[k][:] = g.z[k]
+    st.rescale_oracle()
+    for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss"):
+        compare_sas(st.state[k], g.day(0, k), f"chloride rescale {k}")
+    for k in ("sa_s", "msa_s", "C_rz", "C_ss", "C_s"):
+        compare_sas(st.out[k], g.day(0, k), f"chloride rescale {k}")
+    assert st.state["msa_rz"].any()
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        st.step_oracle()
+        check_day_bromide(g, st, d, "chloride after warm-up", rtol=1e-9)
