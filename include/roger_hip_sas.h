@@ -69,7 +69,8 @@ typedef struct rh_sas_config {
     int32_t forcing_days;      /* number of days of daily input resident on the device (>= 1) */
     int32_t age_statistics;    /* settings.enable_age_statistics */
     int32_t keep_distributions;/* also write tt_*, mtt_*, TT_*, sa_s, msa_s (diagnostics) */
-    double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78) */
+    double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78); for
+                                       * settings.enable_deuterium: VSMOW_conc2H, d2H_min, d2H_max (:79-81), same kernels */
     int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 | _BROMIDE | _CHLORIDE (settings.enable_oxygen18 / enable_bromide / enable_chloride) */
     int32_t reserved;
 } rh_sas_config;

@@ -121,7 +121,10 @@ class RhSasConfig(C.Structure):
                 ("tracer", C.c_int32), ("reserved", C.c_int32)]
 
 
-SAS_TRACERS = {"oxygen18": 0, "bromide": 1, "chloride": 2}   # RH_SAS_TRACER_*
+# RH_SAS_TRACER_*.  Deuterium runs the isotope kernels of oxygen-18 with its own constants in the vsmow / d18O_min /
+# d18O_max fields of rh_sas_config (roger/core/transport.py:315-340, roger/settings.py:79-81)
+SAS_TRACERS = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2}
+DEUTERIUM_DEFAULTS = {"vsmow": 155.76e-6, "d18O_min": -160.0, "d18O_max": 0.0}
 
 
 def _declare_sas(lib):
@@ -183,6 +186,8 @@ class SasContext:
             raise ValueError(f"tracer {tracer!r}: the hip backend transports {sorted(SAS_TRACERS)}")
         cfg.tracer = SAS_TRACERS[tracer]
         self.tracer = tracer
+        if tracer == "deuterium":
+            settings = {**DEUTERIUM_DEFAULTS, **settings}
         cfg.n_cells, cfg.ages, cfg.substeps, cfg.device = int(n_cells), int(ages), int(substeps), int(device)
         cfg.forcing_days = int(forcing_days)
         cfg.age_statistics, cfg.keep_distributions = int(bool(age_statistics)), int(bool(keep_distributions))

@@ -9,20 +9,26 @@ from ..routines import roger_routine
 from ..variables import SAS_FLUXES, SAS_STAT_TARGETS
 
 
+def _isotope_constants(settings):
+    if settings.enable_deuterium:
+        return settings.VSMOW_conc2H, settings.d2H_min, settings.d2H_max
+    return settings.VSMOW_conc18O, settings.d18O_min, settings.d18O_max
+
+
 def delta_to_conc(state, delta_iso):
-    """roger/core/transport.py:315-325 (oxygen-18)."""
-    v = state.settings.VSMOW_conc18O
+    """roger/core/transport.py:315-325 (oxygen-18, deuterium)."""
+    v = _isotope_constants(state.settings)[0]
     delta_iso = np.asarray(delta_iso, dtype=np.float64)
     return v * (delta_iso / 1000. + 1.) / (1. + (delta_iso / 1000. + 1.) * v)
 
 
 def conc_to_delta(state, conc):
-    """roger/core/transport.py:328-340 (oxygen-18)."""
-    st = state.settings
+    """roger/core/transport.py:328-340 (oxygen-18, deuterium)."""
+    v, lo, hi = _isotope_constants(state.settings)
     conc = np.asarray(conc, dtype=np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
-        d = 1000. * (conc / (st.VSMOW_conc18O * (1. - conc)) - 1.)
-        return np.where((d < st.d18O_min) | (d > st.d18O_max), np.nan, d)
+        d = 1000. * (conc / (v * (1. - conc)) - 1.)
+        return np.where((d < lo) | (d > hi), np.nan, d)
 
 
 def _written_by_step(settings):
@@ -47,7 +53,7 @@ def _written_by_step(settings):
 
 @roger_routine
 def calculate_storage_selection(state):
-    """roger/core/transport.py:3136 for `(enable_oxygen18 or enable_bromide) and sas_solver == "deterministic"`:
+    """roger/core/transport.py:3136 for `(enable_oxygen18, enable_deuterium, enable_bromide or enable_chloride) and sas_solver == "deterministic"`:
     svat_transport_model_deterministic (:949-991) as one native launch (rh_sas_step).  What the user's
     set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
     `vs.<name>` is read."""

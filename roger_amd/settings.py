@@ -58,6 +58,9 @@ SETTINGS = {
     "VSMOW_conc18O": Setting(2005.2e-6, float, "oxygen-18 abundancy ratios according to VSMOW in -"),
     "d18O_min": Setting(-20, float, "potentially lowest oxygen-18 value in per mille"),
     "d18O_max": Setting(0, float, "potentially greatest oxygen-18 value in per mille"),
+    "VSMOW_conc2H": Setting(155.76e-6, float, "deuterium abundancy ratios according to VSMOW in -"),
+    "d2H_min": Setting(-160, float, "potentially lowest deuterium value in per mille"),
+    "d2H_max": Setting(0, float, "potentially greatest deuterium value in per mille"),
     "enable_bromide": Setting(False, bool, "enable bromide"),
     "enable_chloride": Setting(False, bool, "enable enable_chloride"),
     "enable_oxygen18": Setting(False, bool, "enable oxygen-18"),
@@ -90,7 +93,7 @@ _UNSUPPORTED_SWITCHES = (
     "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
-    "enable_deuterium", "enable_nitrate", "enable_virtualtracer",
+    "enable_nitrate", "enable_virtualtracer",
 )
 
 
@@ -101,10 +104,12 @@ def check_setting_conflicts(settings):
             raise NotImplementedError(
                 f"settings.{name}=True is outside the hot path of the hip backend (SURVEY.md section 8: out of scope)")
     if settings.enable_offline_transport:
-        # the native transport path: oxygen-18, bromide or chloride with the deterministic SAS solver
-        if int(settings.enable_oxygen18) + int(settings.enable_bromide) + int(settings.enable_chloride) != 1:
-            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, bromide and chloride "
-                                      "(exactly one of settings.enable_oxygen18 / enable_bromide / enable_chloride must be True)")
+        # the native transport path: oxygen-18, deuterium, bromide or chloride with the deterministic SAS solver
+        # 
+        if sum(int(getattr(settings, k)) for k in ("enable_oxygen18", "enable_deuterium", "enable_bromide", "enable_chloride")) != 1:
+            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, deuterium, bromide and "
+                                      "chloride (exactly one of settings.enable_oxygen18 / enable_deuterium / enable_bromide / "
+                                      "enable_chloride must be True)")
         if settings.sas_solver != "deterministic":
             raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
                                       '"deterministic" SAS solver (Euler / RK4 are out of scope, SURVEY.md section 8)')

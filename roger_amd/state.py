@@ -339,11 +339,12 @@ class RogerState:
             # variables tt_*, mtt_*, TT_*, sa_s, msa_s are exposed, hence keep_distributions
             if self._var_meta is None:
                 self._var_meta = var_mod.build_transport_variables(s)
+            tracer = next(t for t in ("oxygen18", "deuterium", "bromide", "chloride") if getattr(s, "enable_" + t))
+            iso = (s.VSMOW_conc2H, s.d2H_min, s.d2H_max) if s.enable_deuterium else (s.VSMOW_conc18O, s.d18O_min, s.d18O_max)
             self._sas_ctx = _native.SasContext(
                 (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,
-                age_statistics=s.enable_age_statistics, keep_distributions=True,
-                tracer="bromide" if s.enable_bromide else ("chloride" if s.enable_chloride else "oxygen18"), vsmow=s.VSMOW_conc18O,
-                d18O_min=s.d18O_min, d18O_max=s.d18O_max)
+                age_statistics=s.enable_age_statistics, keep_distributions=True, tracer=tracer,
+                vsmow=iso[0], d18O_min=iso[1], d18O_max=iso[2])
             self._ctx = HostScalars()
             self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)
             return

@@ -168,7 +168,7 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     model.setup()
     vs = model.state.variables
     rec = {"meta": np.array([nx, ny, ndays, ages, substeps, int(age_statistics)])}
-    if bromide:
+    if tracer != "oxygen18":
         rec["tracer"] = np.array(tracer)
     if warmup:
         # RogerSetup.warmup (roger/roger.py:491-521): one whole run, soil.rescale_SA, itt = time = 0.  The state right
@@ -222,6 +222,7 @@ def main():
         "sas_families_a50": (4, 3, 14, 50, 3, "families", False, 17),
         "sas_warmup_a30": (2, 2, 10, 30, 3, "power", False, 23, True),
         "sas_gamma_a40": (4, 3, 12, 40, 3, "gamma", False, 37),
+        "sas_deuterium_a40": (3, 2, 10, 40, 4, "power", True, 43, False, "deuterium"),
         "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
         "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
         "sas_chloride_warmup_a30": (2, 2, 10, 30, 3, "power", True, 41, True, "chloride"),

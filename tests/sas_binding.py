@@ -15,7 +15,8 @@ FLUXES = ("evap_soil", "transp", "q_rz", "q_ss", "cpr_rz")          # order of t
 INFS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss")
 STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
-SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40")
+SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40",
+             "sas_deuterium_a40")
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 
@@ -63,6 +64,8 @@ def _ptr(a):
 VSMOW = 2005.2e-6
 D18O_MIN = -20.0
 D18O_MAX = 0.0
+# (VSMOW ratio, lowest, greatest delta value): roger/settings.py:76-81
+ISOTOPE_CONSTANTS = {"oxygen18": (VSMOW, D18O_MIN, D18O_MAX), "deuterium": (155.76e-6, -160.0, 0.0)}
 
 
 class SasState:
@@ -106,7 +109,8 @@ class SasState:
                 self.out[k] = z(n)
 
     def struct(self):
-        s = OcSas(n=self.n, ages=self.ages, substeps=self.substeps, vsmow=VSMOW, d18O_min=D18O_MIN, d18O_max=D18O_MAX)
+        v, lo, hi = ISOTOPE_CONSTANTS["deuterium" if self.tracer == "deuterium" else "oxygen18"]
+        s = OcSas(n=self.n, ages=self.ages, substeps=self.substeps, vsmow=v, d18O_min=lo, d18O_max=hi)
         s.maskCatch = self.maskCatch.ctypes.data_as(C.POINTER(C.c_int32))
         for k, a in self.state.items():
             setattr(s, k, _ptr(a))
@@ -129,7 +133,7 @@ class SasState:
                 for j, q in enumerate(STAT_Q):
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
         s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
-        s.tracer = {"oxygen18": 0, "bromide": 1, "chloride": 2}[self.tracer]
+        s.tracer = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2}[self.tracer]
         if self.anion:
             for k in ("alpha_transp", "alpha_q", "S_sat_rz"):
                 setattr(s, k, _ptr(self.par[k]))
@@ -207,7 +211,7 @@ def compare_sas(got, want, what, rtol=1e-10, atol=1e-12):
 # able to deliver it.  Whether the residue is 0 or 1e-16 depends on the last bit of `pow`, which differs
 # between numpy's AVX-512 pow and libm (and the GPU's ocml pow).  From that day on a trajectory is only
 # reproducible to ~1e-3 mm / 1e-4 permil; the per-day tests from reference states stay at 1e-10.
-FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6, "sas_gamma_a40": 3}
+FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6, "sas_gamma_a40": 3, "sas_deuterium_a40": 9}
 # Share of (day, column) pairs that must meet the tight tolerance when every day restarts from the reference's state
 # (oracle; measured: gamma 0.972 = 4 of 144, one column whose power-law capillary rise follows a flux that empties classes)
 MIN_TIGHT = {"sas_gamma_a40": 0.97}

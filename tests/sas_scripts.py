@@ -22,6 +22,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
 
     nx, ny = svat["S_rz"].shape[:2]
     chloride = tracer == "chloride"
+    deuterium = tracer == "deuterium"   # the isotope kernels with the constants of 2H (roger/core/transport.py:315-340)
+    d0 = -70 if deuterium else -10      # initial signal of the soil water in permil
     bromide = tracer in ("bromide", "chloride")   # anion transport (mass based): models/svat_bromide, deterministic solver
     extra = extra or {}
 
@@ -44,7 +46,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             s.y_origin = 0.0
             s.time_origin = "01-01-2022"
             s.enable_offline_transport = True
-            s.enable_oxygen18 = not bromide
+            s.enable_oxygen18 = not bromide and not deuterium
+            s.enable_deuterium = deuterium
             s.enable_bromide = bromide and not chloride
             s.enable_chloride = chloride
             s.tm_structure = "power"
@@ -120,8 +123,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
                     vs.msa_ss = update(vs.msa_ss, at[2:-2, 2:-2, :, :], vs.sa_ss[2:-2, 2:-2, :, :] * extra["C_init_ss"])
                 return
             vs.C_iso_snow = update(vs.C_iso_snow, at[2:-2, 2:-2, : vs.taup1], npx.nan)
-            vs.C_iso_rz = update(vs.C_iso_rz, at[2:-2, 2:-2, : vs.taup1], -10)
-            vs.C_iso_ss = update(vs.C_iso_ss, at[2:-2, 2:-2, : vs.taup1], -10)
+            vs.C_iso_rz = update(vs.C_iso_rz, at[2:-2, 2:-2, : vs.taup1], d0)
+            vs.C_iso_ss = update(vs.C_iso_ss, at[2:-2, 2:-2, : vs.taup1], d0)
             for C, Ciso, msa in (("C_rz", vs.C_iso_rz, "msa_rz"), ("C_ss", vs.C_iso_ss, "msa_ss")):
                 setattr(vs, C, update(getattr(vs, C), at[2:-2, 2:-2, : vs.taup1],
                                       delta_to_conc(state, Ciso[2:-2, 2:-2, vs.tau, npx.newaxis])))
@@ -163,7 +166,9 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
                 vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], extra["C_IN"])
                 return
             vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 0], npx.nan)
-            vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 1:], svat["d18O_prec"][None, None, 1:])
+            # deuterium: the same series on the meteoric water line, d2H = 8 * d18O + 10
+            d_prec = svat["d18O_prec"] * 8 + 10 if deuterium else svat["d18O_prec"]
+            vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 1:], d_prec[None, None, 1:])
             vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], delta_to_conc(state, vs.C_ISO_IN)[2:-2, 2:-2, :])
 
         @roger_routine

@@ -64,11 +64,11 @@ def oracle_sas(monkeypatch):
     monkeypatch.setattr(_native, "SasContext", OracleSasContext)
 
 
-@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70"])
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70", "sas_deuterium_a40"])
 def test_transport_setup_through_host_package(oracle_sas, case):
     g = sb.SasGolden(case)
     svat, sas = golden_inputs(g)
-    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats))
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer)
     run_and_compare(g, model, first_tie=sb.FIRST_TIE.get(case))
 
 
