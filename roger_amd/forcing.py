@@ -104,3 +104,56 @@ def combo_forcing(ndays=30, seed=42, start="2018-01-20"):
             ta[d] = rng.uniform(8, 22)
             pet[d] = rng.uniform(2, 4.5)
     return _pack(prec, ta, pet, ndays, start=start)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# forcing from the reference's text inputs (host part)
+# ---------------------------------------------------------------------------------------------------------------------
+def _read_table(path, column):
+    """One of PREC.txt / TA.txt / PET.txt: whitespace-separated, header `YYYY MM DD hh mm <column> ...`, -9999 = missing
+    (roger/io_tools/csv.py:10-104)."""
+    import pandas as pd
+
+    df = pd.read_csv(path, sep=r"\s+", header=0, na_values=-9999)
+    index = pd.to_datetime(dict(year=df.YYYY, month=df.MM, day=df.DD, hour=df.hh, minute=df.mm))
+    return pd.Series(df[column].to_numpy(dtype=np.float64), index=index, name=column)
+
+
+def forcing_from_txt(input_dir, float_type="float32", ndays=None):
+    """10-minute forcing arrays from a directory with PREC.txt (10-minute sums), TA.txt and PET.txt (daily values) --
+    what `read_meteo` + `write_forcing` put into forcing.nc and the setup scripts read back
+    (roger/io_tools/csv.py:10-104, roger/tools/setup.py:469-620):
+
+      * precipitation on a gap-free 10-minute axis from 00:00 of its first day to 23:50 of its last, missing slots 0;
+      * air temperature interpolated linearly over missing values, then it and PET joined to the precipitation axis and
+        forward-filled; PET / 24 / 6 (mm per 10 minutes);
+      * values rounded through `float_type` (write_forcing stores float32 unless told otherwise) and returned as float64;
+      * YEAR / MONTH / DOY of every slot.
+
+    Returns the dict that `Context.set_forcing_series` and the setup hooks take (PREC, TA, PET, YEAR, MONTH, DOY);
+    `ndays` keeps the first days only."""
+    import os
+
+    import pandas as pd
+
+    prec = _read_table(os.path.join(input_dir, "PREC.txt"), "PREC")
+    ta = _read_table(os.path.join(input_dir, "TA.txt"), "TA").interpolate(method="linear", limit_direction="forward")
+    pet = _read_table(os.path.join(input_dir, "PET.txt"), "PET")
+    first, last = prec.index[0].normalize(), prec.index[-1].normalize()
+    axis = pd.date_range(first, last + pd.Timedelta(hours=23, minutes=50), freq="10min")
+    table = pd.DataFrame({"PREC": 0.0}, index=axis)
+    table.loc[prec.index, "PREC"] = prec.to_numpy()
+    table = table.join([ta.to_frame(), pet.to_frame()]).ffill()
+    for col in ("PREC", "TA", "PET"):
+        bad = ~np.isfinite(table[col].to_numpy())
+        if bad.any():
+            raise ValueError(f"{col}: {int(bad.sum())} non-numeric values (first at {table.index[bad][0]})")
+    table["PET"] = (table["PET"] / 24) / 6
+    if ndays is not None:
+        table = table.iloc[: int(ndays) * SLOTS_PER_DAY]
+    ft = np.dtype(float_type)
+    out = {k: table[k].to_numpy().astype(ft).astype(np.float64) for k in ("PREC", "TA", "PET")}
+    out["YEAR"] = table.index.year.to_numpy().astype(np.int64)
+    out["MONTH"] = table.index.month.to_numpy().astype(np.int64)
+    out["DOY"] = table.index.dayofyear.to_numpy().astype(np.int64)
+    return out

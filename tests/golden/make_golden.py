@@ -105,6 +105,19 @@ def uniform_params(nx, ny):
     )
 
 
+TUTORIAL_INPUT = "/root/reference/examples/plot_scale/svat_tutorial/input"
+
+
+def tutorial_params():
+    """BASELINE configs[0]: examples/plot_scale/svat_tutorial/config.yml (one cell)."""
+    f = lambda v: np.full((1, 1), v)  # noqa: E731
+    return dict(
+        lu_id=f(8), z_soil=f(900.0), dmpv=f(0.0), lmpv=f(500.0), theta_ac=f(0.1), theta_ufc=f(0.1),
+        theta_pwp=f(0.2), ks=f(10.0), kf=f(2500.0), sealing=f(0.0), S_dep_tot=f(0.0),
+        theta_rz0=f(0.3), theta_ss0=f(0.3),
+    )
+
+
 def make_model(roger, params, forcing, ndays, lateral=False):
     from roger import roger_routine
     from roger.models.svat import SVATSetup
@@ -363,6 +376,15 @@ def main():
         "svat_hetero_snowrain": (hetero_params(3, 3, seed=11), toy_forcing("snow+rain", ndays=8), 8, 100000, 20,
                                  {1, 2, 3, 10, 11}),
     }
+    if not args.only or args.only == "svat_tutorial":
+        # BASELINE configs[0]: the tutorial's single cell with its own measured forcing (PREC.txt / TA.txt / PET.txt through
+        # roger_amd.forcing.forcing_from_txt = read_meteo + write_forcing's recipe, float32 as write_forcing stores it);
+        # the whole year October 2010 - September 2011
+        from roger_amd.forcing import forcing_from_txt
+
+        nd = 365
+        cases["svat_tutorial"] = (tutorial_params(), forcing_from_txt(TUTORIAL_INPUT, ndays=nd), nd, 100000, 250,
+                                  {1, 2, 3, 500, 501})
     for name, (params, forcing, ndays, max_steps, snap_every, rsteps) in cases.items():
         if args.only and args.only != name:
             continue

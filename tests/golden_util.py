@@ -4,7 +4,8 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo")
+SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo",
+              "svat_tutorial")   # the last: BASELINE configs[0], one cell, a year of measured forcing
 ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo")   # oneD model: lateral subsurface flow
 CASES = SVAT_CASES + ONED_CASES
 

@@ -29,6 +29,33 @@ def test_setup_step_reproduce_reference(case):
             compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case} step {step}")
 
 
+def test_tutorial_year_on_device():
+    """BASELINE configs[0]: examples/plot_scale/svat_tutorial (one cell, config.yml parameters, a year of measured forcing
+    read by forcing_from_txt in the golden generator): setup() and the whole year through RogerSetup.step with the hooks on
+    the host, and once more with the hooks on the device (run_device)."""
+    import svat_scripts as S
+
+    g, names, forcing = load_case("svat_tutorial")
+    nsteps = int(g["nsteps"])
+    model = S.make_model(S.params_from_golden(g, names), forcing, 365)
+    model.setup()
+    vs = model.state.variables
+    compare(S.snapshot_from_vs(vs, names), g["state0"], names, what="tutorial after setup()")
+    for step in range(1, nsteps + 1):
+        model.step(model.state)
+        key = f"s{step:05d}"
+        if key in g.files:
+            for i, k in enumerate(("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")):
+                assert getattr(vs, k) == g["scal"][step - 1][i], (step, k)
+            compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"tutorial step {step}")
+    assert vs.time == 365 * 86400
+    dev = S.make_model(S.params_from_golden(g, names), forcing, 365)
+    dev.setup()
+    dev.run_device(nsteps)
+    assert dev.state.variables.time == 365 * 86400
+    compare(S.snapshot_from_vs(dev.state.variables, names), g[f"s{nsteps:05d}"], names, what="tutorial, hooks on the device")
+
+
 def test_run_device_matches_reference():
     import svat_scripts as S
 

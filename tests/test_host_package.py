@@ -76,7 +76,7 @@ def test_variables_contract(oracle_backend):
     assert st.backend_context.get_scalars().time == 86400
 
 
-@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain", "oned_hetero_heavyrain"])
+@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain", "oned_hetero_heavyrain", "svat_tutorial"])
 def test_setup_and_run_reproduce_reference(oracle_backend, case):
     """The same setup script the golden generator ran through the reference, run through this
     package: setup() state and the trajectory of step() match the reference."""
@@ -91,6 +91,8 @@ def test_setup_and_run_reproduce_reference(oracle_backend, case):
     vs = model.state.variables
     compare(S.snapshot_from_vs(vs, names), g["state0"], names, what=f"{case} after setup()")
     nsteps = int(g["nsteps"])
+    if case == "svat_tutorial":   # a year of single-cell steps: the first 600 here (25 days, snapshots at 250 and 500);
+        nsteps = 600              # the whole year runs in test_oracle_golden (oracle) and test_hip_host_package (device)
     for step in range(1, nsteps + 1):
         model.step(model.state)
         for i, k in enumerate(("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")):
@@ -98,7 +100,7 @@ def test_setup_and_run_reproduce_reference(oracle_backend, case):
         key = f"s{step:05d}"
         if key in g.files:
             compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case} step {step}")
-    assert vs.time >= model.state.settings.runlen
+    assert vs.time >= model.state.settings.runlen or case == "svat_tutorial"
 
 
 def test_run_and_run_device_agree(oracle_backend):
@@ -158,3 +160,25 @@ def test_restart_round_trip(tmp_path, monkeypatch):
         b.step(b.state)
     for nm in ("S", "theta_rz", "z_wf", "q_ss", "swe", "event_id", "time_event0", "itt_forc"):
         np.testing.assert_array_equal(np.asarray(getattr(a.state.variables, nm)), np.asarray(getattr(b.state.variables, nm)), err_msg=nm)
+
+
+def test_forcing_from_text_inputs():
+    """roger_amd.forcing.forcing_from_txt (read_meteo + write_forcing's recipe, roger/io_tools/csv.py:10-104,
+    roger/tools/setup.py:469-620) on the first 30 days of the tutorial's measured inputs (tests/golden/tutorial_input:
+    data rows of examples/plot_scale/svat_tutorial/input) against the arrays the reference's own pipeline produced for the
+    golden run svat_tutorial."""
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from roger_amd.forcing import SLOTS_PER_DAY, forcing_from_txt
+
+    g = np.load(os.path.join(GOLDEN_DIR, "svat_tutorial.npz"))
+    F = forcing_from_txt(os.path.join(GOLDEN_DIR, "tutorial_input"))
+    n = 30 * SLOTS_PER_DAY
+    for k in ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY"):
+        assert F[k].shape == (n,) and F[k].dtype == g[f"forc_{k}"].dtype, k
+        np.testing.assert_array_equal(F[k], g[f"forc_{k}"][:n], err_msg=k)
+    assert F["PREC"].sum() > 10 and F["DOY"][0] == 274    # 1 October 2010
+    # float64 on request (write_forcing(float_type="float64")): not rounded through float32
+    F64 = forcing_from_txt(os.path.join(GOLDEN_DIR, "tutorial_input"), float_type="float64", ndays=2)
+    assert F64["PREC"].shape == (2 * SLOTS_PER_DAY,) and F64["PREC"][0] == 0.42 and F["PREC"][0] != 0.42
