@@ -202,6 +202,9 @@ def main():
                          "sas: SVATOXYGEN18_benchmark (configs[2]: offline oxygen-18 transport, one step = one day)")
     ap.add_argument("--ages", type=int, default=1000, help="sas: age classes (benchmark: 1000)")
     ap.add_argument("--substeps", type=int, default=6, help="sas: sas_solver_substeps (benchmark: 6)")
+    ap.add_argument("--station-weights", action="store_true",
+                    help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
+                         "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=100000)
     args = ap.parse_args()
@@ -250,6 +253,13 @@ def main():
     total_steps = args.steps + args.warmup
     forcing = combo_forcing(ndays=max(30, total_steps // 20 + 5))
     ctx.set_forcing_series(forcing)
+    if args.station_weights:   # eberbaechle/svat_distributed/svat.py:169-186, 276-296 (synthetic maps, seed 7)
+        import numpy as np
+
+        rng = np.random.default_rng(7 + rank)
+        ctx.set_forcing_weights(rng.uniform(0.8, 1.2, n_local), rng.uniform(-1.5, 1.5, n_local), rng.uniform(0.9, 1.1, n_local))
+    if args.station_weights and world > 1:
+        raise SystemExit("--station-weights: the three-phase exchange of per-cell forcing is not wired into bench.py (single GPU only)")
     if world > 1 or os.environ.get("RH_BENCH_FORCE_PHASED"):   # the env switch rehearses the multi-GPU orchestration on one GPU
         run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run   # one summary all-reduce per step
     else:
@@ -309,7 +319,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{'oneD' if args.model == 'oned' else 'SVAT'}_benchmark synthetic grid nx*ny={n_local} per GPU ({nx}x{ny}), {args.params} "
-                            "benchmark parameters, combo forcing (seed 42), adaptive dt",
+                            "benchmark parameters, combo forcing (seed 42), adaptive dt" + (", per-cell station weights" if args.station_weights else ""),
                 "cells_per_gpu": n_local,
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, one 256-byte predicate all-reduce per step",
