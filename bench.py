@@ -30,8 +30,18 @@ ALGO_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md section 8
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def host_threads():
+    """Threads for the CPU baseline: the CPUs this process may run on, at most 16 (a one-GPU box's share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("RH_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(n_cells, steps, forcing):
-    """Oracle (oracle/svat_oracle.c) on the host: same parameters, same forcing, same steps."""
+    """Oracle (oracle/svat_oracle.c, OpenMP over the columns) on the host: same parameters, same forcing, same steps.
+    Returns (cell-timesteps/s, seconds, threads used)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import numpy as np
 
@@ -39,6 +49,7 @@ def cpu_baseline(n_cells, steps, forcing):
     from roger_amd import lookuptables as lut
     from roger_amd.svat import BENCHMARK_PARAMS
 
+    ob.lib().oc_set_num_threads(host_threads())
     st = ob.OracleState(n_cells)
     st.set_luts(lut.ARR_ILU, lut.ARR_GC, lut.ARR_GCM, lut.ARR_RDLU)
     P = st.planes
@@ -64,7 +75,7 @@ def cpu_baseline(n_cells, steps, forcing):
         pd, td, ed, monthly = drv.before_step(st)
         st.step(pd, td, ed, monthly)
     dt = time.perf_counter() - t0
-    return n_cells * steps / dt, dt
+    return n_cells * steps / dt, dt, int(ob.lib().oc_num_threads())
 
 
 SAS_S_RZ, SAS_S_SS = 90.0, 260.0   # initial root zone / subsoil storage in mm (uniform benchmark soil)
@@ -76,6 +87,7 @@ def cpu_baseline_sas(n_cells, ndays, ages, substeps, daily):
     import sas_binding as sb
     from roger_amd import sas as rsas
 
+    sb.lib().oc_sas_set_num_threads(host_threads())
     st = sb.SasState(n_cells, ages, substeps, age_statistics=True)
     for key, S in (("rz", SAS_S_RZ), ("ss", SAS_S_SS)):
         sa, msa = rsas.initial_age_state([S] * n_cells, ages)
@@ -89,7 +101,7 @@ def cpu_baseline_sas(n_cells, ndays, ages, substeps, daily):
             st.inp[k][:] = daily[k][d, :n_cells]
         st.step_oracle()
     dt = time.perf_counter() - t0
-    return n_cells * ndays / dt, dt
+    return n_cells * ndays / dt, dt, int(sb.lib().oc_sas_num_threads())
 
 
 def bench_sas(args, torch, dist, rank, local_rank, world, device):
@@ -178,13 +190,14 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cells = max(8, min(n, int(args.cpu_cells) // 25))
             days = min(ndays_resident, args.steps + args.warmup, 4)
-            v, secs = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily)
+            v, secs, threads = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "cell-timesteps/s",
-                "cores": 1,
+                "cores": threads,
                 "kind": "port",
-                "sample": f"oracle/sas_oracle.c, {cells} columns x first {days} days of the same inputs, {secs:.1f} s on one host core",
+                "sample": f"oracle/sas_oracle.c (OpenMP over the columns), {cells} columns x first {days} days of the same inputs, "
+                          f"{secs:.1f} s on {threads} host threads",
             }
         print(json.dumps(out))
     ctx.close()
@@ -206,7 +219,8 @@ def main():
                     help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
                          "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=100000)
+    ap.add_argument("--cpu-cells", type=int, default=1000000,
+                    help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
     args = ap.parse_args()
 
     import torch
@@ -348,14 +362,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cpu_steps = min(args.steps + args.warmup, 60)
-            v, secs = cpu_baseline(args.cpu_cells, cpu_steps, forcing)
+            v, secs, threads = cpu_baseline(args.cpu_cells, cpu_steps, forcing)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "cell-timesteps/s",
-                "cores": 1,
+                "cores": threads,
                 "kind": "port",
-                "sample": f"oracle/svat_oracle.c, {args.cpu_cells} cells x first {cpu_steps} steps of the same "
-                          f"forcing, {secs:.1f} s on one host core",
+                "sample": f"oracle/svat_oracle.c (OpenMP over the columns), {args.cpu_cells} cells x first {cpu_steps} steps of "
+                          f"the same forcing, {secs:.1f} s on {threads} host threads",
             }
         print(json.dumps(out))
     ctx.close()

@@ -18,6 +18,9 @@
  * over all families is the selected one.  Also gamma (4; the incomplete gamma function by series / continued
  * fraction instead of scipy's cephes code) and the exponential with reversed age order (52).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -516,9 +519,29 @@ void oc_sas_rescale(const oc_sas *P) {
 }
 
 /* one day of svat_transport_model_deterministic for all columns */
+void oc_sas_set_num_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+int oc_sas_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* one day of svat_transport_model_deterministic for all columns; columns are independent and run on all host threads
+ * once there are enough of them (bench.py's cpu_baseline) */
 void oc_sas_step(const oc_sas *P) {
     const int64_t A = P->ages, NA = A + 1;
+#pragma omp parallel if (P->n >= 256)
+    {
     double *work = (double *)malloc(sizeof(double) * (8 * NA + 4));
+#pragma omp for schedule(static)
     for (int64_t i = 0; i < P->n; ++i) {
         const double mk = (double)P->maskCatch[i];
         double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
@@ -587,4 +610,5 @@ void oc_sas_step(const oc_sas *P) {
         ageing(sa_ss, msa_ss, A, work);
     }
     free(work);
+    }
 }

@@ -21,7 +21,11 @@
  */
 #include "svat_cell.h"
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
+#define OC_PAR_MIN 8192 /* cells from which the column loops fork (OpenMP) */
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -142,6 +146,7 @@ uint64_t oc_adt_pred1(void *const *planes, int64_t n, const double *prec_day, co
             if (!((p <= 0) && (t <= st->ta_fm))) w |= WB(W0_NOT_PLE0_TALE);
         }
     }
+#pragma omp parallel for schedule(static) reduction(| : w) if (n >= OC_PAR_MIN)
     for (int64_t i = 0; i < n; ++i) {
         if (!(swe[i] <= 0)) w |= WB(W0_SWE_NOT_LE0);
         if (swe[i] > 0) w |= WB(W0_SWE_GT0);
@@ -241,6 +246,7 @@ uint64_t oc_adt_select(void *const *planes, int64_t n, const double *prec_day, c
     const double *swe_top = planes[plane_index("swe_top")];
     double *agg = adt_aggregates(n, prec_day, ta_day, pet_day, fstride, s->itt_day);
     uint64_t w = 0;
+#pragma omp parallel for schedule(static) reduction(| : w) if (n >= OC_PAR_MIN)
     for (int64_t i = 0; i < n; ++i) {
         const double *a = agg + 9 * (fstride ? i : 0);
         if (f.sel_daily) { prec[i] = a[0]; ta[i] = a[1]; }
@@ -286,6 +292,7 @@ void oc_adt_finish(void *const *planes, int64_t n, const double *prec_day, const
     /* lines 262-368, applied in order; per-cell pet/ta selection */
     int sel[6] = {cond6, cond7, cond8, cond9, cond10, cond11};
     int which[6] = {2, 1, 0, 2, 1, 0}; /* 0 daily, 1 hourly, 2 10min */
+#pragma omp parallel for schedule(static) if (n >= OC_PAR_MIN)
     for (int64_t i = 0; i < n; ++i) {
         const double *a = agg + 9 * (fstride ? i : 0);
         for (int q = 0; q < 6; ++q)
@@ -310,6 +317,7 @@ void oc_adt_finish(void *const *planes, int64_t n, const double *prec_day, const
     /* lines 371-373 */
     if ((s->event_id[0] > 0) && (s->event_id[1] == 0)) s->event_id_counter += 1;
     /* line 376 */
+#pragma omp parallel for schedule(static) if (n >= OC_PAR_MIN)
     for (int64_t i = 0; i < n; ++i) pet_res[i] = pet[i];
     free(agg);
 }
@@ -1542,14 +1550,36 @@ static void initial_conditions_cell(oc_cell *c) {
 /* ======================================================================== */
 /* drivers over the SoA planes                                               */
 /* ======================================================================== */
-#define FOR_CELLS(body)                      \
-    for (int64_t i = 0; i < n; ++i) {        \
-        oc_cell cell;                        \
-        oc_cell *c = &cell;                  \
-        gather(c, planes, i);                \
-        body;                                \
-        scatter(c, planes, i);               \
+/* Columns are independent: with OpenMP (the default build) the cell loops run on all host threads once a grid is large
+ * enough to pay for the fork (the cpu_baseline of bench.py; the golden-vector tests stay single-threaded).  The
+ * results do not depend on the thread count: every column is computed by one thread, the flags are AND / OR reductions. */
+#define OC_PRAGMA(x) _Pragma(#x)
+#define FOR_CELLS_(clause, body)                                                        \
+    OC_PRAGMA(omp parallel for schedule(static) if (n >= OC_PAR_MIN) clause)            \
+    for (int64_t i = 0; i < n; ++i) {                                                   \
+        oc_cell cell;                                                                   \
+        oc_cell *c = &cell;                                                             \
+        gather(c, planes, i);                                                           \
+        body;                                                                           \
+        scatter(c, planes, i);                                                          \
     }
+#define FOR_CELLS(body) FOR_CELLS_(, body)
+#define FOR_CELLS_OK(body) FOR_CELLS_(reduction(& : ok), body)
+
+int oc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void oc_set_num_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
 
 void oc_interception(void *const *planes, int64_t n, const oc_settings *st) { FOR_CELLS(interception_cell(c, st)) }
 void oc_evapotranspiration(void *const *planes, int64_t n, const oc_settings *st) {
@@ -1614,7 +1644,7 @@ void oc_capillary_rise(void *const *planes, int64_t n, const oc_scalars *s) { FO
 void oc_storage(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(storage_cell(c, s->month[1])) }
 int oc_num_error(void *const *planes, int64_t n, oc_scalars *s, const oc_settings *st) {
     int ok = 1;
-    FOR_CELLS(ok &= sanity_cell(c, st); num_error_cell(c, st))
+    FOR_CELLS_OK(ok &= sanity_cell(c, st); num_error_cell(c, st))
     s->sanity_ok = ok;
     return ok;
 }
@@ -1655,7 +1685,7 @@ int oc_step_after_adt(void *const *planes, int64_t n, oc_scalars *s, const oc_se
     int ok = 1;
     s->itt += 1;
     s->time += s->dt_secs;
-    FOR_CELLS(
+    FOR_CELLS_OK(
         if (monthly) params_surface_cell(c, &L, s->month[1]);
         interception_cell(c, st);
         evapotranspiration_cell(c, st);
