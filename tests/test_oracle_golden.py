@@ -138,3 +138,28 @@ def test_setup_kernels(oracle, case):
     st = _start(oracle, g, names, key="pre_ic")
     st.initial_conditions()
     compare(st.snapshot(), g["state0"], names, what=f"{case} initial conditions")
+
+
+def test_threads_do_not_change_results():
+    """The oracle's column loops fork from 8 192 columns on (OpenMP, the cpu_baseline of bench.py): 16 384 heterogeneous
+    columns, 40 steps, one thread against four -- bit for bit."""
+    import oracle_binding as ob
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    reps = 16384 // g["state0"].shape[1]
+    results = []
+    for threads in (1, 4):
+        ob.lib().oc_set_num_threads(threads)
+        st = ob.OracleState(g["state0"].shape[1] * reps)
+        st.load_snapshot(np.tile(g["state0"], (1, reps)), names)
+        st.load_scalars(g["scal0"])
+        st.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+        drv = ob.ForcingDriver(forcing)
+        for _ in range(40):
+            pd, td, ed, monthly = drv.before_step(st)
+            st.step(pd, td, ed, monthly)
+        results.append((st.snapshot().copy(), st.scal.time, st.scal.sanity_ok))
+    ob.lib().oc_set_num_threads(1)
+    assert results[0][1:] == results[1][1:]
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    np.testing.assert_array_equal(results[0][0][:, :16], results[0][0][:, 16:32])   # the tiles stay identical

@@ -201,3 +201,31 @@ def test_chloride_rescale_and_run():
         g.load_inputs(st, d)
         st.step_oracle()
         check_day_bromide(g, st, d, "chloride after warm-up", rtol=1e-9)
+
+
+def test_threads_do_not_change_results():
+    """oc_sas_step forks over the columns from 256 columns on (OpenMP): one thread against four, bit for bit."""
+    import sas_binding as sb
+
+    g = SasGolden("sas_stats_a30")
+    reps = 80
+    outs = []
+    for threads in (1, 4):
+        sb.lib().oc_sas_set_num_threads(threads)
+        st = sb.SasState(g.n * reps, g.ages, g.substeps, True)
+        st.maskCatch[:] = np.tile(g.z["maskCatch"], reps)
+        for f in FLUXES:
+            st.sas[f][:] = np.tile(g.z[f"sas_{f}"], (reps, 1))
+        one = g.new_state()
+        g.load_state(one, 0)
+        for k in st.state:
+            st.state[k][:] = np.tile(one.state[k], (reps, 1))
+        for d in (1, 2, 3):
+            g.load_inputs(one, d)
+            for k in st.inp:
+                st.inp[k][:] = np.tile(one.inp[k], reps)
+            st.step_oracle()
+        outs.append({**{k: v.copy() for k, v in st.state.items()}, **{k: v.copy() for k, v in st.out.items()}})
+    sb.lib().oc_sas_set_num_threads(1)
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
