@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: the reference evaluates every product and sum separately (NumPy ufuncs);
 # contracting a*b+c into an FMA changes roundings and can flip the model's `>`/`>=` masks.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
 
@@ -32,10 +32,23 @@ def build_native(force=False, verbose=False):
     sources += [os.path.join(REPO, "include", f) for f in ("roger_hip.h", "rh_fields.def", "roger_hip_sas.h",
                                                            "rh_sas_arrays.def")]
     if force or _newer(LIB, sources):
-        cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, "roger_hip.hip"), os.path.join(CSRC, "rh_sas.hip"), "-o", LIB]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        # the two translation units compile side by side (each takes about a minute), then one link
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            jobs = []
+            for unit in ("roger_hip", "rh_sas"):
+                cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, unit + ".hip"), "-o", os.path.join(tmp, unit + ".o")]
+                if verbose:
+                    print(" ".join(cmd))
+                jobs.append((cmd, subprocess.Popen(cmd)))
+            for cmd, job in jobs:
+                if job.wait() != 0:
+                    raise subprocess.CalledProcessError(job.returncode, cmd)
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(tmp, u + ".o") for u in ("roger_hip", "rh_sas")] + ["-o", LIB]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
     return LIB
 
 
