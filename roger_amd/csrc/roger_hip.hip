@@ -794,14 +794,10 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     RH_STAGE(seq, at_rt, at_call)
 #endif
 
+// the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
 template <bool MONTHLY, bool LATERAL>
-__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int guarded) {
-    // device-driven stepping launches both variants; the one that does not apply exits at once
-    if (guarded && (D->monthly != 0) != MONTHLY) return;
-    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    unsigned long long q = 0;   // summary bits of this column for the next step's predicates
-    bool bad = false;
-    if (i < a.n) {
+RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long long &q, bool &bad) {
+    {
     const Consts K = D->K;
     const StepCtx X = D->X;
     Col c;
@@ -826,6 +822,19 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
         RH_STEP_BODY(step, , , , rt_subsurface_runoff, rt_subsurface_runoff(c, X), rt_num_error, rt_num_error(c, K),
                      rt_after_timestep, rt_after_timestep(c))
     }
+    }
+}
+
+// MODE: 0 = the plain step, 1 = with the monthly surface parameters (calc_parameters_surface_kernel first), 2 = decided
+// by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
+template <int MODE, bool LATERAL>
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    unsigned long long q = 0;
+    bool bad = false;
+    if (i < a.n) {
+        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL>(a, D, i, q, bad);
+        else step_column<false, LATERAL>(a, D, i, q, bad);
     }
     if (bad) atomicOr(&D->words[2], 1ull);
     wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], q);
@@ -1397,21 +1406,16 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
     }
     const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
     const bool lat = ctx->cfg.enable_lateral_flow != 0;
-#define RH_LAUNCH_STEP(M, guard)                                                                              \
-    do {                                                                                                      \
-        if (lat)                                                                                              \
-            hipLaunchKernelGGL((k_step<M, true>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, guard);  \
-        else                                                                                                  \
-            hipLaunchKernelGGL((k_step<M, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, guard); \
+#define RH_LAUNCH_STEP(MODE)                                                                          \
+    do {                                                                                              \
+        if (lat)                                                                                      \
+            hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev); \
     } while (0)
-    if (monthly < 0) {  // decided on the device
-        RH_LAUNCH_STEP(false, 1);
-        RH_LAUNCH_STEP(true, 1);
-    } else if (monthly) {
-        RH_LAUNCH_STEP(true, 0);
-    } else {
-        RH_LAUNCH_STEP(false, 0);
-    }
+    if (monthly < 0) RH_LAUNCH_STEP(2);  // decided on the device
+    else if (monthly) RH_LAUNCH_STEP(1);
+    else RH_LAUNCH_STEP(0);
 #undef RH_LAUNCH_STEP
     if (ctx->timing) {
         HIPCHK(ctx, hipEventRecord(ctx->events[ctx->ev_used + 1], ctx->stream));
