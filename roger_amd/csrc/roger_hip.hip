@@ -829,7 +829,18 @@ RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long lo
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
 template <int MODE, bool LATERAL>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D) {
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
+    // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
+    // the arena instead of every XCD touching every page.  Never slower; on one box 6 - 11 % faster at 10^7 columns (21 GB
+    // arena: 3.87 -> 3.44 .. 3.64 ms per step; oneD 4.38 -> 4.12 ms), on another box and up to 4 x 10^6 columns the same
+    // (DESIGN.md section 5 on the speed levels of this kernel).  -DRH_XCD_ROUND_ROBIN: the plain mapping.
+#ifndef RH_XCD_ROUND_ROBIN
+    const unsigned nb = gridDim.x, x = blockIdx.x & 7u, base_cnt = nb >> 3, rem = nb & 7u;
+    const unsigned blk = x * base_cnt + (x < rem ? x : rem) + (blockIdx.x >> 3);
+    const int64_t i = (int64_t)blk * RH_BLOCK + threadIdx.x;
+#else
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+#endif
     unsigned long long q = 0;
     bool bad = false;
     if (i < a.n) {
