@@ -60,6 +60,11 @@ typedef struct rh_config {
     double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
     int64_t end_event, hpi;
     double dx;        /* settings.dx, grid spacing in m (enters the lateral flow rates) */
+    int32_t placement_probes; /* where the arena lands in HBM decides which of three bandwidth levels the fused kernel
+                                 runs at (0.35 / 0.39 / 0.41 ms per step at 10^6 columns): rh_create
+                                 allocates up to this many candidate arenas, times a streaming kernel on each and keeps
+                                 the fastest (default 6; 0 or 1: take the first; never more than free memory allows) */
+    int32_t reserved;
 } rh_config;
 
 /* Per-domain scalars of the reference (roger/variables.py:189-330).  event_id/year/month/doy
@@ -75,6 +80,9 @@ typedef struct rh_ctx rh_ctx;
 
 /* ---- life cycle -------------------------------------------------------------------------- */
 void rh_default_config(rh_config *cfg);
+/* What the placement probing of the last rh_create on this context found: the streaming kernel's time on every
+ * candidate (ms, the chosen one first); returns the number of candidates probed (0: probing was off). */
+int rh_placement_report(const rh_ctx *ctx, double *ms, int cap);
 /* Replaces RogerState.initialize_variables (roger/state.py:369-374): allocates one device arena
  * with RH_NPLANES planes of nx*ny cells, zero-filled, then sets the non-zero `initial=` values of
  * the registry (maskCatch=1, ta=15, z_gw=1000, c_int=1, c_root=1; roger/variables.py). */

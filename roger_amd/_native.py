@@ -18,7 +18,7 @@ class RhConfig(C.Structure):
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min",
             "clay_max", "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max",
             "a_bc", "b_bc")
-    ] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("dx", C.c_double)]
+    ] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("dx", C.c_double), ("placement_probes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RhScalars(C.Structure):
@@ -90,6 +90,7 @@ def load():
         getattr(lib, name).argtypes = [vp]
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
+    lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.rh_step_summary_expand.argtypes = [vp, vp]
     lib.rh_step_finish_compress.argtypes = [vp, i32, vp]
     lib.rh_set_forcing_weights.argtypes = [vp, vp, vp, vp]
@@ -331,7 +332,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
-    "rh_step_summary", "rh_step_finish", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
+    "rh_step_summary", "rh_step_finish", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights",
 )
 
@@ -488,6 +489,12 @@ class Context:
 
     def diag_device_ptr(self, name, slot):
         return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))
+
+    def placement_report(self):
+        """Streaming-kernel time (ms) on every candidate arena rh_create probed, the chosen one first ([]: probing off)."""
+        buf = (C.c_double * 32)()
+        n = self._lib.rh_placement_report(self._h, buf, 32)
+        return [float(buf[k]) for k in range(min(n, 32))]
 
     def step_finish(self, monthly=-1):
         self._check(self._lib.rh_step_finish(self._h, int(monthly)), "rh_step_finish")

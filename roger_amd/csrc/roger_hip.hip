@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,9 @@ struct rh_ctx {
     std::vector<hipEvent_t> events;  // pairs (start, stop) around the fused kernel, one per timed step
     size_t ev_used;
     int *dt_log_buf;
+    std::vector<double> probe_ms;   // placement probing: streaming-kernel time per candidate arena, the chosen one first
+    char *arena_alloc;    // what hipMalloc returned for the arena (arena.base = arena_alloc + arena_offset)
+    size_t arena_offset;
     void *stage_buf;      // one contiguous plane (n * 8 bytes): uploads and downloads pass through it
     std::string err;
 };
@@ -1051,6 +1055,7 @@ void rh_default_config(rh_config *cfg) {
     cfg->hpi = 5;
     cfg->dx = 1;
     cfg->enable_lateral_flow = 0;
+    cfg->placement_probes = 6;
 }
 
 const char *rh_last_error(const rh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -1085,6 +1090,8 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->dt_log_buf = nullptr;
     ctx->dev = nullptr;
     ctx->arena.base = nullptr;
+    ctx->arena_alloc = nullptr;
+    ctx->arena_offset = 0;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
     for (auto &b : ctx->weight_buf) b = nullptr;
     ctx->agg_cell_buf = nullptr;
@@ -1113,8 +1120,69 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     hipError_t e;
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
     ctx->own_stream = true;
-    if ((e = hipMalloc((void **)&ctx->arena.base, arena_bytes)) != hipSuccess) return bail(e, "hipMalloc(arena)");
-    if ((e = hipMemsetAsync(ctx->arena.base, 0, arena_bytes, ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    {   // experiments (tools/placement_diag*.py): RH_ARENA_OFFSET_KB shifts the arena inside a larger allocation
+        const char *off = std::getenv("RH_ARENA_OFFSET_KB");
+        ctx->arena_offset = off ? (size_t)std::atoll(off) * 1024 : 0;
+    }
+    {
+        // Placement probing (rh_config.placement_probes): candidates are allocated one after the other and held until
+        // the choice is made, so that each lands somewhere else; a copy of 96 planes with the fused kernel's access
+        // shape (k_calib_copy) is timed on each (its time tracks the fused kernel's level, tools/placement_diag3.py).
+        int probes = cfg->placement_probes;
+        if (const char *env = std::getenv("RH_PLACEMENT_PROBES")) probes = std::atoi(env);
+        if (probes < 1 || ctx->n < 65536) probes = 1;   // small grids are latency-bound
+        std::vector<char *> cand;
+        std::vector<double> cand_ms;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (probes > 1 && (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)) probes = 1;
+        for (int k = 0; k < probes; ++k) {
+            if (k > 0) {   // never take more than a third of what is still free
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 3 < arena_bytes + ctx->arena_offset) break;
+            }
+            char *p = nullptr;
+            if ((e = hipMalloc((void **)&p, arena_bytes + ctx->arena_offset)) != hipSuccess) {
+                if (k == 0) return bail(e, "hipMalloc(arena)");
+                (void)hipGetLastError();
+                break;
+            }
+            cand.push_back(p);
+            if ((e = hipMemsetAsync(p + ctx->arena_offset, 0, arena_bytes, ctx->stream)) != hipSuccess) {
+                for (char *q : cand) (void)hipFree(q);
+                return bail(e, "hipMemset");
+            }
+            double ms = 0;
+            if (probes > 1) {
+                Arena probe = ctx->arena;
+                probe.base = p + ctx->arena_offset;
+                float best = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {   // the first repetition warms up
+                    (void)hipEventRecord(ev0, ctx->stream);
+                    hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, probe, 0, 100, 96);
+                    (void)hipEventRecord(ev1, ctx->stream);
+                    (void)hipEventSynchronize(ev1);
+                    float t = 0;
+                    if (rep > 0 && hipEventElapsedTime(&t, ev0, ev1) == hipSuccess && t < best) best = t;
+                }
+                ms = best;
+            }
+            cand_ms.push_back(ms);
+        }
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        size_t pick = 0;
+        for (size_t k = 1; k < cand.size(); ++k)
+            if (cand_ms[k] < cand_ms[pick]) pick = k;
+        ctx->arena_alloc = cand[pick];
+        ctx->arena.base = cand[pick] + ctx->arena_offset;
+        if (probes > 1) {
+            ctx->probe_ms.push_back(cand_ms[pick]);
+            for (size_t k = 0; k < cand.size(); ++k)
+                if (k != pick) ctx->probe_ms.push_back(cand_ms[k]);
+        }
+        for (size_t k = 0; k < cand.size(); ++k)
+            if (k != pick) (void)hipFree(cand[k]);
+    }
     if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
     if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -1177,7 +1245,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->sflags_buf) (void)hipFree(ctx->sflags_buf);
     if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
     if (ctx->diag_steps_buf) (void)hipFree(ctx->diag_steps_buf);
-    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->arena_alloc) (void)hipFree(ctx->arena_alloc);
     if (ctx->stage_buf) (void)hipFree(ctx->stage_buf);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1701,6 +1769,13 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) 
     hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
     return RH_OK;
+}
+
+int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
+    if (!ctx) return 0;
+    const int n = (int)ctx->probe_ms.size();
+    for (int k = 0; k < n && k < cap && ms; ++k) ms[k] = ctx->probe_ms[k];
+    return n;
 }
 
 void *rh_predicate_words(rh_ctx *ctx) { return ctx ? (void *)ctx->dev->words : nullptr; }
