@@ -363,3 +363,35 @@ def test_timing_detail_reports_time_step_classes():
     assert set(np.unique(dts)) <= {600, 3600, 86400} and len(np.unique(dts)) >= 2
     assert int(dts.sum()) == s1.time - s0.time
     ctx.close()
+
+
+def test_placement_probing_keeps_the_fastest_candidate():
+    """rh_create with rh_config.placement_probes > 1: the chosen arena is the candidate on which the streaming kernel was
+    fastest; small grids and RH_PLACEMENT_PROBES=1 do not probe; results do not depend on where the arena lands."""
+    import os
+
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.svat import create_svat
+
+    forcing = combo_forcing(ndays=30)
+    ctx = create_svat(512, 512, device=0)
+    rep = ctx.placement_report()
+    assert 2 <= len(rep) <= 6 and rep[0] == min(rep) and min(rep) > 0
+    ctx.set_forcing_series(forcing)
+    ctx.run_steps(40)
+    a = {k: ctx.download(k) for k in ("S_rz", "S_ss", "swe", "q_ss", "aet")}
+    ctx.close()
+    small = create_svat(64, 64, device=0)
+    assert small.placement_report() == []
+    small.close()
+    os.environ["RH_PLACEMENT_PROBES"] = "1"
+    try:
+        ctx = create_svat(512, 512, device=0)
+        assert ctx.placement_report() == []
+        ctx.set_forcing_series(forcing)
+        ctx.run_steps(40)
+        for k, v in a.items():
+            np.testing.assert_array_equal(ctx.download(k), v, err_msg=k)
+        ctx.close()
+    finally:
+        del os.environ["RH_PLACEMENT_PROBES"]
