@@ -336,7 +336,7 @@ def main():
                             "benchmark parameters, combo forcing (seed 42), adaptive dt" + (", per-cell station weights" if args.station_weights else ""),
                 "cells_per_gpu": n_local,
                 "simulated_seconds": int(s1.time - s0.time),
-                "decomposition": f"({world},1) along x, one 256-byte predicate all-reduce per step",
+                "decomposition": f"({world},1) along x, " + ("one 256-byte predicate all-reduce per step" if world > 1 else "single GPU: no exchange"),
                 # per time-step class (kernel time only, rank 0); `value` is the aggregate over the run
                 "dt_classes": {
                     name: {"steps": int((per_dt == secs).sum()),
