@@ -63,7 +63,7 @@ typedef struct rh_config {
     int32_t placement_probes; /* where the arena lands in HBM decides which of three bandwidth levels the fused kernel
                                  runs at (0.35 / 0.39 / 0.41 ms per step at 10^6 columns): rh_create
                                  allocates up to this many candidate arenas, times a streaming kernel on each and keeps
-                                 the fastest (default 6; 0 or 1: take the first; never more than free memory allows) */
+                                 the fastest (default 8; 0 or 1: take the first; never more than free memory allows) */
     int32_t reserved;
 } rh_config;
 

@@ -1056,7 +1056,7 @@ void rh_default_config(rh_config *cfg) {
     cfg->hpi = 5;
     cfg->dx = 1;
     cfg->enable_lateral_flow = 0;
-    cfg->placement_probes = 6;
+    cfg->placement_probes = 8;
 }
 
 const char *rh_last_error(const rh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }

@@ -376,7 +376,7 @@ def test_placement_probing_keeps_the_fastest_candidate():
     forcing = combo_forcing(ndays=30)
     ctx = create_svat(512, 512, device=0)
     rep = ctx.placement_report()
-    assert 2 <= len(rep) <= 6 and rep[0] == min(rep) and min(rep) > 0
+    assert 2 <= len(rep) <= 8 and rep[0] == min(rep) and min(rep) > 0
     ctx.set_forcing_series(forcing)
     ctx.run_steps(40)
     a = {k: ctx.download(k) for k in ("S_rz", "S_ss", "swe", "q_ss", "aet")}
