@@ -1454,6 +1454,8 @@ int rh_step_core(rh_ctx *ctx) {
     else
         LAUNCH_CELLS(ctx, k_step_core);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
+    // the output accumulators follow every step, also in the hook-preserving flow (itt / time were just advanced)
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }

@@ -17,7 +17,7 @@ it uploads vs.PREC/TA/PET/YEAR/MONTH/DOY once and advances with rh_run_steps, no
 """
 import abc
 
-from . import distributed, logger, runtime_settings as rs
+from . import diagnostics, distributed, logger, runtime_settings as rs
 from . import settings as settings_mod
 from .routines import is_roger_routine, roger_routine, run_native
 from .state import RogerState
@@ -134,7 +134,9 @@ class RogerSetup(metaclass=abc.ABCMeta):
             if not offline:
                 surface.calculate_initial_conditions(state)
                 soil.calculate_initial_conditions(state)
+            state.diagnostics.update(diagnostics.create_default_diagnostics(state))   # roger/roger.py:296
             self.set_diagnostics(state)
+            diagnostics.initialize(state)
             self.set_boundary_conditions_setup(state)
             self.set_boundary_conditions(state)
             self.set_forcing_setup(state)
@@ -185,6 +187,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
             with state.timers["processes"]:
                 run_native(state, "rh_step_core")
         self.after_timestep(state)
+        if getattr(state, "_diag_active", None):   # roger/roger.py:458-465: output at the end of the time step
+            diagnostics.output(state)
         if rs.profile_mode:
             state.backend_context.sync()
             logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
@@ -225,6 +229,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
         while vs.time - start_time < runlen:
             self.step(self.state)
         (self.state.sas_context or self.state.backend_context).sync()
+        diagnostics.close(self.state)
 
     # -- fast path --------------------------------------------------------------------------------
     def enable_device_hooks(self):
@@ -245,3 +250,5 @@ class RogerSetup(metaclass=abc.ABCMeta):
         vs.flush_to_device()
         self.state.backend_context.run_steps(nsteps)
         vs.mark_device_newer()
+        if getattr(self.state, "_diag_active", None):
+            diagnostics.output(self.state, final=True)

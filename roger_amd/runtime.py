@@ -40,7 +40,8 @@ _AVAILABLE = {
     "num_proc": (_two_ints, (1, 1), False),
     "profile_mode": (_bool, False, True),
     "loglevel": (str, "info", True),
-    "diskless_mode": (_bool, True, True),
+    "force_overwrite": (_bool, False, True),   # roger/runtime.py:120-121
+    "diskless_mode": (_bool, False, True),
     "monitor_water_balance": (_bool, False, True),
 }
 

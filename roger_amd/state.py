@@ -378,6 +378,11 @@ class RogerState:
         return self._diagnostics
 
     @property
+    def var_meta(self):
+        """roger/state.py: the variable registry (name -> Variable)."""
+        return self._var_meta
+
+    @property
     def backend_context(self):
         return self._ctx
 

@@ -127,6 +127,32 @@ class OracleContext:
         L.oc_step_after_adt.restype = C.c_int
         L.oc_step_after_adt(self.st._ptrs, C.c_int64(self.n), C.byref(self.st.scal), C.byref(self.st.settings),
                             C.c_int(int(monthly)), C.c_int(int(core_only)), C.c_uint64(word1), *self.st._lut_args())
+        self._accumulate()
+
+    # the device-side output accumulators (rh_diag_*), restated: a slot per day of the step's start
+    def diag_configure(self, rate=(), collect=(), n_slots=1):
+        self._diag = dict(rate=list(rate), collect=list(collect), n_slots=int(n_slots),
+                          data={v: np.zeros((int(n_slots), self.n)) for v in list(rate) + list(collect)},
+                          steps=np.zeros(int(n_slots), dtype=np.int64))
+
+    def _accumulate(self):
+        d = getattr(self, "_diag", None)
+        if not d:
+            return
+        s = self.st.scal
+        t0 = s.time - s.dt_secs
+        slot, first = (t0 // 86400) % d["n_slots"], t0 % 86400 == 0
+        d["steps"][slot] = 1 if first else d["steps"][slot] + 1
+        for v in d["rate"]:
+            d["data"][v][slot] = self.st.planes[v] if first else d["data"][v][slot] + self.st.planes[v]
+        for v in d["collect"]:
+            d["data"][v][slot] = self.st.planes[v]
+
+    def diag_download(self, name, slot):
+        return self._diag["data"][name][int(slot)].copy()
+
+    def diag_steps(self, slot):
+        return int(self._diag["steps"][int(slot)])
 
     def _hooks(self):
         s, F = self.st.scal, self.series

@@ -67,3 +67,44 @@ def test_run_device_matches_reference():
     vs = model.state.variables
     assert vs.itt == nsteps and vs.time == g["scal"][nsteps - 1][1]
     compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what="run_device final state")
+
+
+def test_output_diagnostics_on_device(tmp_path):
+    """state.diagnostics (rate / collect / average, daily) on the real context: once with the hooks on the host (a record
+    per completed day while stepping), once with run_device (all days resident on the device, flushed at the end) -- the
+    same files; the daily sums equal the per-step values added up on the host."""
+    from roger_amd import diagnostics, runtime_settings as rs
+    from test_host_package import _diagnostics_model, check_diagnostics_files
+
+    ndays = 3
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        (tmp_path / "a").mkdir()
+        (tmp_path / "b").mkdir()
+        g, names, model = _diagnostics_model("svat_hetero_combo", ndays, tmp_path / "a")
+        model.setup()
+        vs = model.state.variables
+        acc, sums = 0.0, []
+        while vs.time < ndays * 86400:
+            model.step(model.state)
+            acc = acc + np.asarray(vs.aet)[2:-2, 2:-2].T
+            if vs.time % 86400 == 0:
+                sums.append(acc)
+                acc = 0.0
+        nsteps = int(vs.itt)
+        diagnostics.close(model.state)
+        g, names, dev = _diagnostics_model("svat_hetero_combo", ndays, tmp_path / "b")
+        dev.setup()
+        dev.run_device(nsteps)
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    ra, ca, ta = check_diagnostics_files(model, tmp_path / "a", ndays, nx, ny)
+    rb, cb, tb = check_diagnostics_files(dev, tmp_path / "b", ndays, nx, ny)
+    np.testing.assert_allclose(ra["aet"][1:], np.stack(sums), rtol=1e-13, atol=1e-13)
+    for k in ra:
+        np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+    for k in ca:
+        np.testing.assert_array_equal(ca[k], cb[k], err_msg=k)
+    np.testing.assert_array_equal(ta, tb)

@@ -182,3 +182,123 @@ def test_forcing_from_text_inputs():
     # float64 on request (write_forcing(float_type="float64")): not rounded through float32
     F64 = forcing_from_txt(os.path.join(GOLDEN_DIR, "tutorial_input"), float_type="float64", ndays=2)
     assert F64["PREC"].shape == (2 * SLOTS_PER_DAY,) and F64["PREC"][0] == 0.42 and F["PREC"][0] != 0.42
+
+
+def _diagnostics_model(case, ndays, tmp_path, device_hooks=False):
+    import svat_scripts as S
+    from roger_amd import roger_routine
+
+    g, names, forcing = load_case(case)
+    base = S.make_model(S.params_from_golden(g, names), forcing, ndays)
+
+    class WithOutput(type(base)):
+        @roger_routine
+        def set_diagnostics(self, state):   # as the reference's setup scripts do (examples/plot_scale/svat_tutorial/svat.py)
+            d = state.diagnostics
+            d["rate"].output_variables = ["prec", "aet", "q_ss", "inf_mat_rz"]
+            d["rate"].output_frequency = 24 * 60 * 60
+            d["rate"].sampling_frequency = 1
+            d["rate"].base_output_path = str(tmp_path)
+            d["collect"].output_variables = ["S_rz", "S_ss", "theta"]
+            d["collect"].output_frequency = 24 * 60 * 60
+            d["collect"].sampling_frequency = 1
+            d["collect"].base_output_path = str(tmp_path)
+            d["average"].output_variables = ["ta"]
+            d["average"].output_frequency = 24 * 60 * 60
+            d["average"].sampling_frequency = 1
+            d["average"].base_output_path = str(tmp_path)
+
+    model = WithOutput()
+    return g, names, model
+
+
+def check_diagnostics_files(model, tmp_path, ndays, nx, ny, reference_sums=None):
+    from scipy.io import netcdf_file
+
+    ident = model.state.settings.identifier
+    with netcdf_file(str(tmp_path / f"{ident}.rate.nc"), "r", mmap=False) as f:
+        assert f.dimensions["x"] == nx and f.dimensions["y"] == ny and f.dimensions["Time"] is None
+        t = f.variables["Time"]
+        assert t.units == b"days" and list(t[:]) == [float(k) for k in range(ndays + 1)]
+        prec = f.variables["prec"]
+        assert prec.dimensions == ("Time", "y", "x") and prec.shape == (ndays + 1, ny, nx) and prec.units == b"mm/dt"
+        rate = {k: f.variables[k][:].copy() for k in ("prec", "aet", "q_ss", "inf_mat_rz")}
+    with netcdf_file(str(tmp_path / f"{ident}.collect.nc"), "r", mmap=False) as f:
+        collect = {k: f.variables[k][:].copy() for k in ("S_rz", "S_ss", "theta")}
+    with netcdf_file(str(tmp_path / f"{ident}.average.nc"), "r", mmap=False) as f:
+        ta = f.variables["ta"][:].copy()
+    assert (rate["prec"][0] == 0).all() and rate["prec"][1:].sum() > 0          # record 0: initial values
+    assert np.isfinite(ta).all() and collect["S_rz"].shape == (ndays + 1, ny, nx)
+    return rate, collect, ta
+
+
+def test_output_diagnostics_daily_files(oracle_backend, tmp_path):
+    """`state.diagnostics` as in the reference's setup scripts: rate / collect / average with daily output become
+    <identifier>.rate.nc ... in the reference's layout (x, y, unlimited Time; (Time, y, x) variables; record 0 = initial
+    values).  The rate file's daily sums equal the sums of the per-step values of a run without diagnostics."""
+    from roger_amd import runtime_settings as rs
+
+    ndays = 4
+    g, names, model = _diagnostics_model("svat_hetero_combo", ndays, tmp_path)
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)   # (runtime settings are locked once the core modules are imported)
+    try:
+        model.setup()
+        vs = model.state.variables
+        sums = {k: [] for k in ("prec", "aet", "q_ss")}
+        day_acc = {k: 0.0 for k in sums}
+        last = {}
+        while vs.time < ndays * 86400:
+            model.step(model.state)
+            for k in sums:
+                day_acc[k] = day_acc[k] + np.asarray(getattr(vs, k))[2:-2, 2:-2][..., 1].T if np.asarray(getattr(vs, k)).ndim == 3 \
+                    else day_acc[k] + np.asarray(getattr(vs, k))[2:-2, 2:-2].T
+            if vs.time % 86400 == 0:
+                for k in sums:
+                    sums[k].append(day_acc[k])
+                    day_acc[k] = 0.0
+                last = {k: np.asarray(getattr(vs, k))[2:-2, 2:-2, 1].T.copy() for k in ("S_rz", "S_ss", "theta")}
+        from roger_amd import diagnostics
+
+        diagnostics.close(model.state)
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    rate, collect, ta = check_diagnostics_files(model, tmp_path, ndays, nx, ny)
+    for k in sums:
+        np.testing.assert_allclose(rate[k][1:], np.stack(sums[k]), rtol=1e-13, atol=1e-13, err_msg=k)
+    for k in last:
+        np.testing.assert_array_equal(collect[k][-1], last[k], err_msg=k)
+    with pytest.raises(IOError):     # the files exist now: a second setup refuses to overwrite them
+        object.__setattr__(rs, "diskless_mode", False)
+        try:
+            _diagnostics_model("svat_hetero_combo", ndays, tmp_path)[2].setup()
+        finally:
+            object.__setattr__(rs, "diskless_mode", prev)
+
+
+def test_output_diagnostics_scope(oracle_backend, tmp_path):
+    import svat_scripts as S
+    from roger_amd import roger_routine
+
+    g, names, forcing = load_case("svat_uniform_rain")
+    base = S.make_model(S.params_from_golden(g, names), forcing, 1)
+
+    class Hourly(type(base)):
+        @roger_routine
+        def set_diagnostics(self, state):
+            state.diagnostics["rate"].output_variables = ["prec"]
+            state.diagnostics["rate"].output_frequency = 60 * 60
+            state.diagnostics["rate"].sampling_frequency = 1
+
+    with pytest.raises(NotImplementedError, match="indexed by day"):
+        Hourly().setup()
+
+    class Maximum(type(base)):
+        @roger_routine
+        def set_diagnostics(self, state):
+            state.diagnostics["maximum"].output_variables = ["prec"]
+            state.diagnostics["maximum"].output_frequency = 24 * 60 * 60
+
+    with pytest.raises(NotImplementedError, match="native: rate, collect, average"):
+        Maximum().setup()
