@@ -108,3 +108,38 @@ def test_output_diagnostics_on_device(tmp_path):
     for k in ca:
         np.testing.assert_array_equal(ca[k], cb[k], err_msg=k)
     np.testing.assert_array_equal(ta, tb)
+
+
+def test_tutorial_example_from_text_inputs(tmp_path):
+    """examples/svat_tutorial.py end to end on the first 30 days of the tutorial's measured inputs (tests/golden/
+    tutorial_input): text files -> device -> <identifier>.rate.nc / .collect.nc.  The files close the water balance of the
+    soil column day by day, the precipitation record equals the daily sums of PREC.txt, and the final storages equal the
+    reference's trajectory (golden svat_tutorial) at the same time."""
+    import importlib.util
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from roger_amd import runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    spec = importlib.util.spec_from_file_location("svat_tutorial_example", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "svat_tutorial.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        model = ex.main([os.path.join(GOLDEN_DIR, "tutorial_input"), "--days", "30", "--out", str(tmp_path)])
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    with netcdf_file(str(tmp_path / "SVAT.rate.nc"), "r", mmap=False) as f:
+        rate = {k: f.variables[k][:, 0, 0].copy() for k in ex.CONFIG["OUTPUT_RATE"]}
+        assert f.variables["Time"].shape == (31,)
+    with netcdf_file(str(tmp_path / "SVAT.collect.nc"), "r", mmap=False) as f:
+        S = f.variables["S"][:, 0, 0].copy()
+    g, names, forcing = load_case("svat_tutorial")
+    np.testing.assert_allclose(rate["prec"][1:], forcing["PREC"][: 30 * 144].reshape(30, 144).sum(axis=1), rtol=1e-12, atol=1e-12)
+    # water balance of the whole column: dS = prec - aet - q_ss - surface runoff (none leaves a flat, unsealed cell here)
+    dS = np.diff(S)
+    np.testing.assert_allclose(dS, (rate["prec"] - rate["aet"] - rate["q_ss"] - rate["q_hof"] - rate["q_sof"])[1:], atol=1e-9)
+    step = int(np.searchsorted(g["scal"][:, 1], 30 * 86400)) + 1        # the reference's step that ends day 30
+    assert g["scal"][step - 1, 1] == 30 * 86400 and model.state.variables.itt == step
