@@ -13,7 +13,8 @@ and gets `<identifier>.rate.nc`, `<identifier>.collect.nc`, `<identifier>.averag
 (roger/io_tools/netcdf.py): dimensions x, y and the unlimited Time, variables transposed to (Time, y, x), `Time` in days
 with `time_origin`, record 0 holding the initial values, one record per output interval.  What differs: the accumulation
 runs on the device (`rate += var` after every step is a 24-byte-per-cell kernel, nothing is downloaded between outputs);
-only DAILY output is native (the accumulators are indexed by day); the file is classic netCDF
+only DAILY output is native (the accumulators are indexed by day); the offline transport model,
+whose step is a day, is read after every step instead (`output_transport`); the file is classic netCDF
 (64-bit offset, scipy.io.netcdf_file) because neither h5py nor h5netcdf is part of this environment -- xarray / netCDF4
 read it all the same; long names and units come from a short table here, not from the reference's variable registry.
 """
@@ -112,7 +113,7 @@ def initialize(state):
     if not active:
         return
     if state.settings.enable_offline_transport:
-        raise NotImplementedError("output diagnostics of the offline transport model are not native (read vs.<name> after a step)")
+        return _initialize_transport(state, active)
     ctx = state.backend_context
     for d in active:
         if d.output_frequency != DAY:
@@ -140,11 +141,62 @@ def initialize(state):
         _write(state, d)
 
 
+# ---- offline transport: one step = one day = one output interval, nothing to accumulate ----------------------------
+_AGED = ("sa_rz", "sa_ss", "msa_rz", "msa_ss")
+
+
+def _initialize_transport(state, active):
+    """The transport model writes after every (daily) step once the warm-up is done (write_output,
+    roger/core/transport.py:3399-3418): rate, collect and average of one step are that step's values.  They are read from
+    the device after the step.  The reference writes BEFORE it ages the storages, the native step includes the ageing:
+    the age-resolved storages themselves (sa_rz, sa_ss, msa_rz, msa_ss) are therefore not offered; sa_s / msa_s, the
+    distributions, concentrations and age statistics are."""
+    for d in active:
+        if d.output_frequency != DAY:
+            raise NotImplementedError(f'diagnostic "{d.name}": output_frequency {d.output_frequency} s (the transport step is a day)')
+        for v in d.output_variables:
+            meta = state.var_meta.get(v)
+            if meta is None or meta.dims is None or meta.dims[:2] != ("x", "y"):
+                raise NotImplementedError(f'diagnostic "{d.name}": {v!r} is not an (x, y, ...) variable of the transport model')
+            if v in _AGED:
+                raise NotImplementedError(f'diagnostic "{d.name}": {v!r} would be written after the ageing, the reference writes it '
+                                          "before (use sa_s / msa_s, or read vs.<name> from the setup script)")
+    state._diag_transport = True
+    for d in active:
+        d._records, d._times = {v: [] for v in d.output_variables}, []
+        d._path = None if rs.diskless_mode else d.get_output_file_name(state)
+        if d._path and os.path.isfile(d._path) and not getattr(rs, "force_overwrite", False):
+            raise IOError(f'output file {d._path} for diagnostic "{d.name}" exists (change the output path, enable the '
+                          "force_overwrite runtime setting or delete it)")
+
+
+def _transport_record(state, name):
+    """(y, x) or (ages, y, x) of time level tau: the reference's transposed layout."""
+    a = np.asarray(getattr(state.variables, name))[2:-2, 2:-2]
+    meta = state.var_meta[name]
+    if "timesteps" in meta.dims:
+        a = a[:, :, 1]
+    return np.ascontiguousarray(a.T, dtype=np.float64)
+
+
+def output_transport(state):
+    """After the warm-up (record 0: initial values, roger/roger.py:515-521) and after every step of the run proper."""
+    if not getattr(state, "_diag_transport", False) or not state.settings.warmup_done:
+        return
+    for d in state._diag_active:
+        for v in d.output_variables:
+            d._records[v].append(_transport_record(state, v))
+        d._times.append(float(state.variables.time) / DAY)
+        small = sum(len(r) * r[0].nbytes for r in d._records.values()) < (32 << 20)
+        if small or len(d._times) % 30 == 0:
+            _write(state, d)
+
+
 def output(state, final=False):
     """roger/diagnostics/api.py:47-70 for daily output: every completed day that has not been written yet becomes a
     record.  Called after each step of run() (one completed day at most) and after run_device() (all of them)."""
     active = getattr(state, "_diag_active", None)
-    if not active:
+    if not active or getattr(state, "_diag_transport", False):
         return
     ctx = state.backend_context
     now_days = int(state.variables.time // DAY)
@@ -198,9 +250,17 @@ def _write(state, d):
         t.long_name, t.units, t.time_origin = "Time", "days", str(settings.time_origin)
         t[:] = np.asarray(d._times)
         for name in d.output_variables:
-            v = f.createVariable(name, "d", ("Time", "y", "x"))
+            rec = d._records[name]
+            extra = ()
+            if rec and rec[0].ndim == 3:   # (ages | nages, y, x)
+                dim = "ages" if rec[0].shape[0] == settings.ages else "nages"
+                if dim not in f.dimensions:
+                    f.createDimension(dim, rec[0].shape[0])
+                extra = (dim,)
+            v = f.createVariable(name, "d", ("Time",) + extra + ("y", "x"))
             v.long_name, v.units = name, _UNITS.get(name, "")
-            v[:] = np.stack(d._records[name])
+            if rec:
+                v[:] = np.stack(rec)
 
 
 def close(state):

@@ -160,6 +160,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
                     self.state.variables.time = 0
         with self.state.settings.unlock():
             self.state.settings.warmup_done = True
+        diagnostics.output_transport(self.state)   # initial values after the warm-up, roger/roger.py:515-521
 
     def _upload_luts(self):
         vs = self.state.variables
@@ -214,6 +215,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
                     self.set_parameters(state)
                 with state.timers["StorAge selection"]:
                     transport.calculate_storage_selection(state)
+                diagnostics.output_transport(state)    # write_output, roger/core/transport.py:3399-3418
         self.after_timestep(state)
         if rs.profile_mode:
             state.sas_context.sync()

@@ -167,3 +167,54 @@ def test_transport_needs_exactly_one_tracer():
 
     with pytest.raises(NotImplementedError, match="exactly one"):
         Both().setup()
+
+
+def test_transport_output_diagnostics(oracle_sas, tmp_path):
+    """state.diagnostics of the offline transport model: nothing during the warm-up, record 0 = the rescaled initial state,
+    then a record per day with the step's values -- concentrations, age statistics and an age-resolved distribution."""
+    from roger_amd import roger_routine, runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    g = sb.SasGolden("sas_warmup_a30")
+    svat, sas = golden_inputs(g)
+    base = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=g.ndays)
+
+    class WithOutput(type(base)):
+        @roger_routine
+        def set_diagnostics(self, state):
+            d = state.diagnostics
+            d["collect"].output_variables = ["C_iso_q_ss", "C_iso_rz", "tt_q_ss", "sa_s"]
+            d["collect"].output_frequency = 24 * 60 * 60
+            d["collect"].sampling_frequency = 1
+            d["collect"].base_output_path = str(tmp_path)
+
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        model = WithOutput()
+        model.setup()
+        model.warmup()
+        model.run()
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    ident = model.state.settings.identifier
+    with netcdf_file(str(tmp_path / f"{ident}.collect.nc"), "r", mmap=False) as f:
+        assert list(f.variables["Time"][:]) == [float(k) for k in range(g.ndays + 1)]
+        assert f.variables["tt_q_ss"].dimensions == ("Time", "ages", "y", "x") and f.dimensions["ages"] == g.ages
+        C = f.variables["C_iso_q_ss"][:].copy()
+        tt = f.variables["tt_q_ss"][:].copy()
+        C_rz = f.variables["C_iso_rz"][:].copy()
+    for d in range(1, g.ndays + 1):
+        want = g.day(d, "C_iso_q_ss").reshape(g.nx, g.ny).T
+        assert np.allclose(C[d], want, rtol=5e-3, atol=5e-3, equal_nan=True), d
+        assert np.allclose(tt[d], g.day(d, "tt_q_ss").reshape(g.nx, g.ny, g.ages).T, rtol=5e-3, atol=5e-3), d
+    assert np.allclose(C_rz[0], g.day(0, "C_iso_rz").reshape(g.nx, g.ny).T, rtol=1e-9, equal_nan=True)   # after the rescaling
+    with pytest.raises(NotImplementedError, match="before"):
+        class Aged(type(base)):
+            @roger_routine
+            def set_diagnostics(self, state):
+                state.diagnostics["collect"].output_variables = ["sa_rz"]
+                state.diagnostics["collect"].output_frequency = 24 * 60 * 60
+                state.diagnostics["collect"].sampling_frequency = 1
+
+        Aged().setup()
