@@ -60,7 +60,11 @@ class RogerDiagnostic:
         return bool(self.output_variables) and bool(self.output_frequency or self.sampling_frequency)
 
     def get_output_file_name(self, state):
+        from . import runtime_state
+
         name = self.output_path.format(identifier=state.settings.identifier)
+        if runtime_state.proc_num > 1:   # one file per rank with the rank's own block of columns (the reference writes one
+            name = name[:-3] + f".{runtime_state.proc_rank:04d}.nc"   # file through parallel HDF5, which is not available here)
         return os.path.join(self.base_output_path, name) if self.base_output_path else name
 
 
