@@ -92,3 +92,35 @@ def test_chloride_warmup_on_device():
     run_and_compare_bromide(g, model, warmup=1)
     assert model.state.sas_context.tracer == "chloride"
     model.state.sas_context.close()
+
+
+def test_svat_to_transport_example(tmp_path):
+    """examples/svat_oxygen18_tutorial.py end to end on the 30-day data fixture: text inputs -> SVAT on the device -> netCDF
+    -> transport model on the device (warm-up, rescaling, run) -> netCDF."""
+    import importlib.util
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from roger_amd import runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    path = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "svat_oxygen18_tutorial.py")
+    spec = importlib.util.spec_from_file_location("svat_oxygen18_example", path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        model = ex.main([os.path.join(GOLDEN_DIR, "tutorial_input"), "--days", "30", "--ages", "60", "--substeps", "3",
+                         "--out", str(tmp_path)])
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    assert model.state.variables.itt == 30
+    with netcdf_file(str(tmp_path / "SVATOXYGEN18.average.nc"), "r", mmap=False) as f:
+        assert f.variables["Time"].shape == (31,)
+        C = f.variables["C_iso_q_ss"][:, 0, 0].copy()
+        tt50 = f.variables["tt50_q_ss"][:, 0, 0].copy()
+    wet = np.isfinite(C[1:])
+    assert wet.any() and (C[1:][wet] > -12).all() and (C[1:][wet] < -4).all()      # between the soil's -10 and the rain's -5 .. -11
+    assert np.nanmin(tt50[1:]) >= 1 and np.nanmax(tt50[1:]) <= 60
+    model.state.sas_context.close()
