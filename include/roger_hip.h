@@ -236,6 +236,13 @@ void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot);
 /* Number of steps accumulated in a day slot: the divisor of the "average" diagnostic (roger/diagnostics/average.py:
  * `avg += var; n += 1`, output avg / n) for a variable registered as a rate plane.  Synchronises. */
 int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps);
+/* Output intervals other than a day: 3600 or 600 seconds (the step classes; a step never straddles a boundary it does not
+ * start on).  Slots are then indexed by the interval of the step's start; an interval that a longer step covers is never
+ * started and its slot stays untouched.  rh_diag_slot_times tells which interval a slot holds: the start time of its first
+ * step (-1: never touched) and the end time of its last one -- the reference writes a record whenever `time % frequency
+ * == 0` (roger/diagnostics/api.py:47-70), i.e. at that end time.  Call rh_diag_set_interval before the first step. */
+int rh_diag_set_interval(rh_ctx *ctx, int64_t seconds);
+int rh_diag_slot_times(rh_ctx *ctx, int slot, int64_t *t_start, int64_t *t_end);
 
 /* HIP-event timing of the fused per-cell kernel.  rh_enable_timing(ctx, 1) starts a new
  * measurement: every following step records an event pair around the kernel on the context's

@@ -91,6 +91,8 @@ def load():
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
     lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
+    lib.rh_diag_set_interval.argtypes = [vp, i64]
+    lib.rh_diag_slot_times.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.rh_step_summary_expand.argtypes = [vp, vp]
     lib.rh_step_finish_compress.argtypes = [vp, i32, vp]
     lib.rh_set_forcing_weights.argtypes = [vp, vp, vp, vp]
@@ -332,7 +334,7 @@ DECLARED_SYMBOLS = (
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
-    "rh_step_summary", "rh_step_finish", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
+    "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights",
 )
 
@@ -486,6 +488,15 @@ class Context:
         n = C.c_int64()
         self._check(self._lib.rh_diag_steps(self._h, int(slot), C.byref(n)), "rh_diag_steps")
         return n.value
+
+    def diag_set_interval(self, seconds):
+        self._check(self._lib.rh_diag_set_interval(self._h, C.c_int64(int(seconds))), "rh_diag_set_interval")
+
+    def diag_slot_times(self, slot):
+        """(start time of the interval's first step or -1, end time of its last step) of a slot."""
+        t0, t1 = C.c_int64(), C.c_int64()
+        self._check(self._lib.rh_diag_slot_times(self._h, int(slot), C.byref(t0), C.byref(t1)), "rh_diag_slot_times")
+        return t0.value, t1.value
 
     def diag_device_ptr(self, name, slot):
         return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))

@@ -55,7 +55,9 @@ struct DevState {
     int sflag_blocks;
     // device-side output accumulators (rh_diag_configure): (diag_slots, diag_rate + diag_collect, n) float64
     double *diag;
-    long long *diag_steps;         // steps accumulated per day slot (the divisor of the "average" diagnostic)
+    long long *diag_steps;         // per slot: {steps accumulated (the divisor of the "average" diagnostic), start time of the
+                                   // interval's first step, end time of its last step}
+    long long diag_interval;       // output interval in seconds (86400, 3600 or 600)
     int diag_rate, diag_collect, diag_slots;
     int diag_planes[32];
     // rh_enable_timing: dt_secs of every step since then (the time-step class of each timed launch)
@@ -95,6 +97,7 @@ struct rh_ctx {
     bool summary_valid;   // D->sflags describe the columns as they are in the arena now
     double *diag_buf;
     long long *diag_steps_buf;
+    long long diag_interval;
     int diag_n, diag_slots;
     unsigned long long *sflags_buf;
     int pred_blocks;
@@ -667,12 +670,17 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
 __global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const int64_t t0 = D->S.time - D->S.dt_secs;
-    const int64_t slot = (t0 / 86400) % D->diag_slots;
-    const bool first = (t0 % 86400) == 0;
+    const int64_t t0 = D->S.time - D->S.dt_secs, iv = D->diag_interval;
+    const int64_t slot = (t0 / iv) % D->diag_slots;
+    const bool first = (t0 % iv) == 0;   // steps never straddle an interval boundary they do not start on (adaptive_time_stepping)
     const int nr = D->diag_rate, nv = D->diag_rate + D->diag_collect;
     double *base = D->diag + (size_t)slot * nv * a.n;
-    if (i == 0) D->diag_steps[slot] = first ? 1 : D->diag_steps[slot] + 1;
+    if (i == 0) {
+        long long *m = D->diag_steps + 3 * slot;
+        m[0] = first ? 1 : m[0] + 1;
+        if (first) m[1] = t0;
+        m[2] = D->S.time;
+    }
     for (int j = 0; j < nv; ++j) {
         double v;
         rh_ld(a, D->diag_planes[j], i, v);
@@ -1101,6 +1109,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->sflags_buf = nullptr;
     ctx->diag_buf = nullptr;
     ctx->diag_steps_buf = nullptr;
+    ctx->diag_interval = 86400;
     ctx->diag_n = 0;
     ctx->diag_slots = 0;
     ctx->per_cell = false;
@@ -1724,10 +1733,15 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         const size_t bytes = (size_t)n_slots * nv * ctx->n * sizeof(double);
         HIPCHK(ctx, hipMalloc((void **)&ctx->diag_buf, bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->diag_buf, 0, bytes, ctx->stream));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->diag_steps_buf, (size_t)n_slots * sizeof(long long)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->diag_steps_buf, 0, (size_t)n_slots * sizeof(long long), ctx->stream));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->diag_steps_buf, (size_t)n_slots * 3 * sizeof(long long)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->diag_steps_buf, 0xff, (size_t)n_slots * 3 * sizeof(long long), ctx->stream));   // -1: never touched
     }
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_steps, &ctx->diag_steps_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const long long day = 86400;
+        if (ctx->diag_interval <= 0) ctx->diag_interval = day;
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_interval, &ctx->diag_interval, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag, &ctx->diag_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_rate, &n_rate, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_collect, &n_collect, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1755,9 +1769,32 @@ int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps) {
     if (rc) return rc;
     if (!steps) return fail(ctx, RH_ERR_ARG, "rh_diag_steps: null pointer");
     long long v = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&v, ctx->diag_steps_buf + slot, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&v, ctx->diag_steps_buf + 3 * slot, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *steps = (int64_t)v;
+    *steps = (int64_t)(v < 0 ? 0 : v);
+    return RH_OK;
+}
+int rh_diag_set_interval(rh_ctx *ctx, int64_t seconds) {
+    if (!ctx) return RH_ERR_ARG;
+    if (seconds != 86400 && seconds != 3600 && seconds != 600)
+        return fail(ctx, RH_ERR_ARG, "rh_diag_set_interval: the output interval is a day, an hour or ten minutes (the step classes)");
+    ctx->diag_interval = seconds;
+    if (ctx->diag_n) {
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->diag_interval, &ctx->diag_interval, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->diag_steps_buf, 0xff, (size_t)ctx->diag_slots * 3 * sizeof(long long), ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RH_OK;
+}
+int rh_diag_slot_times(rh_ctx *ctx, int slot, int64_t *t_start, int64_t *t_end) {
+    const int rc = diag_check(ctx, 0, slot);
+    if (rc) return rc;
+    if (!t_start || !t_end) return fail(ctx, RH_ERR_ARG, "rh_diag_slot_times: null pointer");
+    long long v[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(v, ctx->diag_steps_buf + 3 * slot, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *t_start = (int64_t)v[1];
+    *t_end = (int64_t)v[2];
     return RH_OK;
 }
 void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot) {

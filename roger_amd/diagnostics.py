@@ -13,7 +13,8 @@ and gets `<identifier>.rate.nc`, `<identifier>.collect.nc`, `<identifier>.averag
 (roger/io_tools/netcdf.py): dimensions x, y and the unlimited Time, variables transposed to (Time, y, x), `Time` in days
 with `time_origin`, record 0 holding the initial values, one record per output interval.  What differs: the accumulation
 runs on the device (`rate += var` after every step is a 24-byte-per-cell kernel, nothing is downloaded between outputs);
-only DAILY output is native (the accumulators are indexed by day); the offline transport model,
+one output interval -- a day, an hour or ten minutes -- serves all diagnostics (the accumulators are indexed by the
+interval of a step's start); the offline transport model,
 whose step is a day, is read after every step instead (`output_transport`); the file is classic netCDF
 (64-bit offset, scipy.io.netcdf_file) because neither h5py nor h5netcdf is part of this environment -- xarray / netCDF4
 read it all the same; long names and units come from a short table here, not from the reference's variable registry.
@@ -119,22 +120,26 @@ def initialize(state):
     if state.settings.enable_offline_transport:
         return _initialize_transport(state, active)
     ctx = state.backend_context
+    freqs = {int(d.output_frequency) for d in active}
+    if len(freqs) != 1 or not freqs <= {DAY, 60 * 60, 10 * 60}:
+        raise NotImplementedError(f"output frequencies {sorted(freqs)}: the device-side accumulators serve ONE output interval "
+                                  "of a day, an hour or ten minutes (the step classes) for all diagnostics")
+    state._diag_interval = freqs.pop()
     for d in active:
-        if d.output_frequency != DAY:
-            raise NotImplementedError(f'diagnostic "{d.name}": output_frequency {d.output_frequency} s; the device-side '
-                                      "accumulators are indexed by day (output_frequency = 86400)")
         for v in d.output_variables:
             meta = state.var_meta.get(v)
             if meta is None or meta.plane is None or meta.dtype is not None:
                 raise NotImplementedError(f'diagnostic "{d.name}": {v!r} is not a float64 (x, y) variable of the device arena')
     rate = list(dict.fromkeys(diags["rate"].output_variables + diags["average"].output_variables))
     collect = list(dict.fromkeys(diags["collect"].output_variables))
-    ndays = int(state.settings.runlen // DAY) + 2
+    nint = int(state.settings.runlen // state._diag_interval) + 2
     per_slot = (len(rate) + len(collect)) * ctx.n * 8
-    state._diag_slots = max(2, min(ndays, int((1 << 31) // max(per_slot, 1))))   # at most 2 GiB of resident days
+    state._diag_slots = max(2, min(nint, int((1 << 31) // max(per_slot, 1))))   # at most 2 GiB of resident intervals
     state.variables.flush_to_device()
     ctx.diag_configure(rate=rate, collect=collect, n_slots=state._diag_slots)
-    state._diag_written_day = 0
+    if state._diag_interval != DAY:
+        ctx.diag_set_interval(state._diag_interval)
+    state._diag_written_day = 0      # index of the last output interval that was looked at
     for d in active:
         d._records = {v: [_interior(state, v)] for v in d.output_variables}   # record 0: initial values
         d._times = [0.0]
@@ -203,15 +208,21 @@ def output(state, final=False):
     if not active or getattr(state, "_diag_transport", False):
         return
     ctx = state.backend_context
-    now_days = int(state.variables.time // DAY)
+    iv = state._diag_interval
+    now_days = int(state.variables.time // iv)        # completed output intervals
     first = state._diag_written_day + 1
     if now_days < first:
         return
     if now_days - first + 1 > state._diag_slots:
-        raise RuntimeError(f"{now_days - first + 1} days completed since the last output but only {state._diag_slots} are "
-                           "resident on the device: call run_device() in shorter pieces")
-    for day in range(first, now_days + 1):
-        slot = (day - 1) % state._diag_slots
+        raise RuntimeError(f"{now_days - first + 1} output intervals completed since the last output but only {state._diag_slots} "
+                           "are resident on the device: call run_device() in shorter pieces")
+    for k in range(first, now_days + 1):
+        slot = (k - 1) % state._diag_slots
+        t0, t1 = (k - 1) * iv, k * iv
+        if iv != DAY:   # an interval inside a longer step was never started: the reference writes at the END of that step
+            t0_slot, t1 = ctx.diag_slot_times(slot)
+            if t0_slot != t0:
+                continue
         steps = None
         for d in active:
             for v in d.output_variables:
@@ -220,7 +231,7 @@ def output(state, final=False):
                     steps = steps or ctx.diag_steps(slot)
                     a = a / steps
                 d._records[v].append(np.ascontiguousarray(a.T))
-            d._times.append(float(day))
+            d._times.append(t1 / DAY)
     state._diag_written_day = now_days
     for d in active:
         small = sum(len(r) * r[0].nbytes for r in d._records.values()) < (32 << 20)

@@ -131,18 +131,28 @@ class OracleContext:
 
     # the device-side output accumulators (rh_diag_*), restated: a slot per day of the step's start
     def diag_configure(self, rate=(), collect=(), n_slots=1):
-        self._diag = dict(rate=list(rate), collect=list(collect), n_slots=int(n_slots),
+        self._diag = dict(rate=list(rate), collect=list(collect), n_slots=int(n_slots), interval=86400,
                           data={v: np.zeros((int(n_slots), self.n)) for v in list(rate) + list(collect)},
-                          steps=np.zeros(int(n_slots), dtype=np.int64))
+                          steps=np.zeros(int(n_slots), dtype=np.int64), t0=np.full(int(n_slots), -1, dtype=np.int64),
+                          t1=np.full(int(n_slots), -1, dtype=np.int64))
+
+    def diag_set_interval(self, seconds):
+        self._diag["interval"] = int(seconds)
+
+    def diag_slot_times(self, slot):
+        return int(self._diag["t0"][int(slot)]), int(self._diag["t1"][int(slot)])
 
     def _accumulate(self):
         d = getattr(self, "_diag", None)
         if not d:
             return
         s = self.st.scal
-        t0 = s.time - s.dt_secs
-        slot, first = (t0 // 86400) % d["n_slots"], t0 % 86400 == 0
+        t0, iv = s.time - s.dt_secs, d["interval"]
+        slot, first = (t0 // iv) % d["n_slots"], t0 % iv == 0
         d["steps"][slot] = 1 if first else d["steps"][slot] + 1
+        if first:
+            d["t0"][slot] = t0
+        d["t1"][slot] = s.time
         for v in d["rate"]:
             d["data"][v][slot] = self.st.planes[v] if first else d["data"][v][slot] + self.st.planes[v]
         for v in d["collect"]:

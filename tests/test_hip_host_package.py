@@ -143,3 +143,51 @@ def test_tutorial_example_from_text_inputs(tmp_path):
     np.testing.assert_allclose(dS, (rate["prec"] - rate["aet"] - rate["q_ss"] - rate["q_hof"] - rate["q_sof"])[1:], atol=1e-9)
     step = int(np.searchsorted(g["scal"][:, 1], 30 * 86400)) + 1        # the reference's step that ends day 30
     assert g["scal"][step - 1, 1] == 30 * 86400 and model.state.variables.itt == step
+
+
+def test_output_diagnostics_hourly_on_device(tmp_path):
+    """rh_diag_set_interval(3600) on the real context, hooks on the device: the same records as stepping with the hooks on
+    the host (one per hour while stepping hourly or finer, one per daily step)."""
+    import svat_scripts as S
+    from roger_amd import diagnostics, roger_routine, runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    g, names, forcing = load_case("svat_hetero_combo")
+
+    def build(out):
+        base = S.make_model(S.params_from_golden(g, names), forcing, 3)
+
+        class Hourly(type(base)):
+            @roger_routine
+            def set_diagnostics(self, state):
+                d = state.diagnostics["rate"]
+                d.output_variables, d.output_frequency, d.sampling_frequency, d.base_output_path = ["prec", "aet", "q_ss"], 3600, 1, str(out)
+
+        return Hourly()
+
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        (tmp_path / "a").mkdir()
+        (tmp_path / "b").mkdir()
+        host = build(tmp_path / "a")
+        host.setup()
+        vs = host.state.variables
+        while vs.time < 3 * 86400:
+            host.step(host.state)
+        diagnostics.close(host.state)
+        dev = build(tmp_path / "b")
+        dev.setup()
+        dev.run_device(int(vs.itt))
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    files = [netcdf_file(str(tmp_path / d / f"{host.state.settings.identifier}.rate.nc"), "r", mmap=False) for d in ("a", "b")]
+    try:
+        ta, tb = (f.variables["Time"][:].copy() for f in files)
+        np.testing.assert_array_equal(ta, tb)
+        assert len(ta) > 10 and np.isclose(np.diff(ta) * 24, 1).any()
+        for k in ("prec", "aet", "q_ss"):
+            np.testing.assert_array_equal(files[0].variables[k][:], files[1].variables[k][:], err_msg=k)
+    finally:
+        for f in files:
+            f.close()

@@ -284,15 +284,18 @@ def test_output_diagnostics_scope(oracle_backend, tmp_path):
     g, names, forcing = load_case("svat_uniform_rain")
     base = S.make_model(S.params_from_golden(g, names), forcing, 1)
 
-    class Hourly(type(base)):
+    class TwoFrequencies(type(base)):
         @roger_routine
         def set_diagnostics(self, state):
             state.diagnostics["rate"].output_variables = ["prec"]
             state.diagnostics["rate"].output_frequency = 60 * 60
             state.diagnostics["rate"].sampling_frequency = 1
+            state.diagnostics["collect"].output_variables = ["S_rz"]
+            state.diagnostics["collect"].output_frequency = 24 * 60 * 60
+            state.diagnostics["collect"].sampling_frequency = 1
 
-    with pytest.raises(NotImplementedError, match="indexed by day"):
-        Hourly().setup()
+    with pytest.raises(NotImplementedError, match="ONE output interval"):
+        TwoFrequencies().setup()
 
     class Maximum(type(base)):
         @roger_routine
@@ -302,3 +305,45 @@ def test_output_diagnostics_scope(oracle_backend, tmp_path):
 
     with pytest.raises(NotImplementedError, match="native: rate, collect, average"):
         Maximum().setup()
+
+
+def test_output_diagnostics_hourly(oracle_backend, tmp_path):
+    """output_frequency = 3600: a record whenever a step ends on the hour (roger/diagnostics/api.py:56-58) -- one per hour
+    while the model steps hourly or in ten-minute steps, ONE at the end of a daily step.  The records add up to the daily
+    file's sums and carry the reference's time stamps."""
+    import svat_scripts as S
+    from roger_amd import diagnostics, roger_routine, runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    base = S.make_model(S.params_from_golden(g, names), forcing, 4)
+
+    class Hourly(type(base)):
+        @roger_routine
+        def set_diagnostics(self, state):
+            d = state.diagnostics["rate"]
+            d.output_variables, d.output_frequency, d.sampling_frequency, d.base_output_path = ["prec", "aet"], 60 * 60, 1, str(tmp_path)
+
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        model = Hourly()
+        model.setup()
+        vs = model.state.variables
+        want_t, want_prec, acc = [0.0], [], 0.0
+        while vs.time < 4 * 86400:
+            model.step(model.state)
+            acc = acc + np.asarray(vs.prec)[2:-2, 2:-2, 1].T
+            if vs.time % 3600 == 0:
+                want_t.append(vs.time / 86400)
+                want_prec.append(acc)
+                acc = 0.0
+        diagnostics.close(model.state)
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    with netcdf_file(str(tmp_path / f"{model.state.settings.identifier}.rate.nc"), "r", mmap=False) as f:
+        t, prec = f.variables["Time"][:].copy(), f.variables["prec"][:].copy()
+    np.testing.assert_allclose(t, want_t, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(prec[1:], np.stack(want_prec), rtol=1e-13, atol=1e-13)
+    steps = np.diff(t) * 24
+    assert np.isclose(steps, 1).any() and np.isclose(steps, 24).any()     # hourly records and whole-day records
