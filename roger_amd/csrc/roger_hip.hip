@@ -95,6 +95,9 @@ struct rh_ctx {
     double *mlms_buf;
     bool per_cell;
     bool summary_valid;   // D->sflags describe the columns as they are in the arena now
+    // lazy tau -> taum1 rotation (k_step<.,.,LAZY>): rot_consistent = the last thing that touched the planes was a complete
+    // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
+    bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
     double *diag_buf;
     long long *diag_steps_buf;
     long long diag_interval;
@@ -737,8 +740,23 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // every routine stores the planes it is the last to assign right away, and the planes the NEXT
 // routine is the first to mention are requested before the current routine computes, so their
 // latency hides behind its arithmetic.
-#define RH_LOADS(seq, rt) RH_SEQ_##seq##_LOAD_##rt(LD)
-#define RH_STORES(seq, rt) RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)
+// LAZY (template parameter of step_column): the previous operation was a complete step, so X_m1 == X for every rotation
+// pair of after_timestep.  Then the X_m1 planes are neither loaded (the register is filled from X's, AL) nor stored;
+// they are materialised from the X planes when somebody else needs them (materialise_m1).  Per column and step this
+// saves the 30 rotation stores and the 11 X_m1 loads of the step: 328 of 1 986 bytes.
+#define AL(xm1, x) c.xm1 = c.x;
+#define RH_LOADS(seq, rt)                                          \
+    if constexpr (LAZY) {                                          \
+        RH_SEQ_##seq##_LLOAD_##rt(LD) RH_SEQ_##seq##_ALIAS_##rt(AL) \
+    } else {                                                       \
+        RH_SEQ_##seq##_LOAD_##rt(LD)                               \
+    }
+#define RH_STORES(seq, rt)                                               \
+    if constexpr (LAZY) {                                                \
+        RH_SEQ_##seq##_LSTORE_##rt(ST)                                   \
+    } else {                                                             \
+        RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)       \
+    }
 #if RH_STEP_PREFETCH
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
     RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)  \
@@ -808,7 +826,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 #endif
 
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
-template <bool MONTHLY, bool LATERAL>
+template <bool MONTHLY, bool LATERAL, bool LAZY>
 RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long long &q, bool &bad) {
     {
     const Consts K = D->K;
@@ -840,7 +858,7 @@ RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long lo
 
 // MODE: 0 = the plain step, 1 = with the monthly surface parameters (calc_parameters_surface_kernel first), 2 = decided
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
-template <int MODE, bool LATERAL>
+template <int MODE, bool LATERAL, bool LAZY>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
     // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
@@ -857,8 +875,8 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     unsigned long long q = 0;
     bool bad = false;
     if (i < a.n) {
-        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL>(a, D, i, q, bad);
-        else step_column<false, LATERAL>(a, D, i, q, bad);
+        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY>(a, D, i, q, bad);
+        else step_column<false, LATERAL, LAZY>(a, D, i, q, bad);
     }
     if (bad) atomicOr(&D->words[2], 1ull);
     wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], q);
@@ -972,6 +990,15 @@ __global__ __launch_bounds__(RH_BLOCK) void k_plane_scatter(Arena a, int plane, 
     if (i < a.n) *rh_cell<T>(a, plane, i) = src[i];
 }
 
+// X_m1 = X for every rotation pair of after_timestep: what the lazy steps left undone (materialise_m1)
+__global__ __launch_bounds__(RH_BLOCK) void k_rotate_all(Arena a) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    Col c;
+    RH_ROTATION_FIELDS(LD)
+    RH_ROTATION_FIELDS(ROT)
+}
+
 // initial values of the variable registry that are not zero (roger/variables.py `initial=`)
 __global__ __launch_bounds__(RH_BLOCK) void k_init_registry(Arena a) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -1024,9 +1051,22 @@ static int fail(rh_ctx *ctx, int code, const std::string &msg) {
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RH_BLOCK - 1) / RH_BLOCK); }
 // any per-column kernel other than the fused step may change what the summary words describe
+// The X_m1 planes from the X planes, if lazy steps left them behind (anything but the fused kernel that looks at the
+// planes calls this first).
+static void materialise_m1(rh_ctx *ctx) {
+    if (!ctx->m1_stale) return;
+    hipLaunchKernelGGL(k_rotate_all, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena);
+    ctx->m1_stale = false;
+}
+// somebody other than the fused kernel is about to change planes: X_m1 == X cannot be taken for granted afterwards
+static void planes_touched(rh_ctx *ctx) {
+    materialise_m1(ctx);
+    ctx->rot_consistent = false;
+    ctx->summary_valid = false;
+}
 #define LAUNCH_CELLS(ctx, kern)                                                                                          \
     do {                                                                                                                 \
-        (ctx)->summary_valid = false;                                                                                    \
+        planes_touched(ctx);                                                                                             \
         hipLaunchKernelGGL(kern, dim3(grid_for((ctx)->n)), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
     } while (0)
 #define LAUNCH_ONE(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, (ctx)->stream, __VA_ARGS__)
@@ -1101,6 +1141,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->arena.base = nullptr;
     ctx->arena_alloc = nullptr;
     ctx->arena_offset = 0;
+    ctx->rot_consistent = false;
+    ctx->m1_stale = false;
+    ctx->diag_reads_m1 = false;
+    ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
     for (auto &b : ctx->weight_buf) b = nullptr;
     ctx->agg_cell_buf = nullptr;
@@ -1291,6 +1335,7 @@ int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_upload: null host pointer");
+    planes_touched(ctx);
     HIPCHK(ctx, hipMemcpyAsync(ctx->stage_buf, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (elem == sizeof(double))
         hipLaunchKernelGGL(k_plane_scatter<double>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (const double *)ctx->stage_buf);
@@ -1307,6 +1352,7 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_download: null host pointer");
+    materialise_m1(ctx);
     if (elem == sizeof(double))
         hipLaunchKernelGGL(k_plane_gather<double>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (double *)ctx->stage_buf);
     else
@@ -1319,7 +1365,7 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
 
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
     if (!ctx || plane < 0 || plane >= RH_NPLANES) return nullptr;
-    ctx->summary_valid = false;  // the caller may write through the pointer
+    planes_touched(ctx);  // the caller may write through the pointer
 #if RH_TILED
     return ctx->arena.base + (size_t)plane * RH_SLOT_BYTES;   // cell i: + (i / 64) * tile_bytes + (i % 64) * element size
 #else
@@ -1482,7 +1528,7 @@ int rh_after_timestep(rh_ctx *ctx) {
 
 #define LAUNCH_PRED(ctx, kern)                                                                                           \
     do {                                                                                                                 \
-        (ctx)->summary_valid = false;                                                                                    \
+        planes_touched(ctx);                                                                                             \
         hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
     } while (0)
 
@@ -1510,16 +1556,25 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
 #else
 #define RH_LAUNCH_K(K) hipExtLaunchKernelGGL(K, grid, block, 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev)
 #endif
-#define RH_LAUNCH_STEP(MODE)                              \
-    do {                                                  \
-        if (lat)                                          \
-            RH_LAUNCH_K((k_step<MODE, true>));            \
-        else                                              \
-            RH_LAUNCH_K((k_step<MODE, false>));           \
+    // lazy rotation: the planes were last touched by a complete fused step (X_m1 == X) and nobody who reads X_m1 planes
+    // follows inside this call (the accumulator kernel may, if it was given an X_m1 plane)
+    const bool lazy = ctx->lazy_ok && ctx->rot_consistent && !ctx->diag_reads_m1;
+#define RH_LAUNCH_STEP(MODE)                                          \
+    do {                                                              \
+        if (lat && lazy)                                              \
+            RH_LAUNCH_K((k_step<MODE, true, true>));                  \
+        else if (lat)                                                 \
+            RH_LAUNCH_K((k_step<MODE, true, false>));                 \
+        else if (lazy)                                                \
+            RH_LAUNCH_K((k_step<MODE, false, true>));                 \
+        else                                                          \
+            RH_LAUNCH_K((k_step<MODE, false, false>));                \
     } while (0)
     if (monthly < 0) RH_LAUNCH_STEP(2);  // decided on the device
     else if (monthly) RH_LAUNCH_STEP(1);
     else RH_LAUNCH_STEP(0);
+    ctx->rot_consistent = true;   // a complete step: after_timestep's X_m1 = X holds, physically (eager) or logically (lazy)
+    ctx->m1_stale = lazy;
 #undef RH_LAUNCH_STEP
 #undef RH_LAUNCH_K
     if (ctx->timing) {
@@ -1717,6 +1772,12 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         if (planes[j] < 0 || planes[j] >= RH_NPLANES || PLANE_IS_INT[planes[j]])
             return fail(ctx, RH_ERR_ARG, "rh_diag_configure: plane ids must name float64 planes");
     }
+    ctx->diag_reads_m1 = false;   // an accumulated X_m1 plane keeps the fused kernel from skipping its stores
+    for (int j = 0; j < n_rate + n_collect; ++j) {
+        const size_t len = std::strlen(PLANE_NAMES[planes[j]]);
+        if (len > 3 && !std::strcmp(PLANE_NAMES[planes[j]] + len - 3, "_m1")) ctx->diag_reads_m1 = true;
+    }
+    materialise_m1(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->diag_buf) {
         HIPCHK(ctx, hipFree(ctx->diag_buf));
@@ -1821,7 +1882,7 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) 
         return RH_ERR_ARG;
     for (int p = 0; p < nplanes; ++p)
         if (PLANE_IS_INT[src_plane0 + p] || PLANE_IS_INT[dst_plane0 + p]) return fail(ctx, RH_ERR_ARG, "calibration planes must be float64");
-    ctx->summary_valid = false;
+    planes_touched(ctx);
     hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
     return RH_OK;

@@ -395,3 +395,44 @@ def test_placement_probing_keeps_the_fastest_candidate():
         ctx.close()
     finally:
         del os.environ["RH_PLACEMENT_PROBES"]
+
+
+def test_lazy_rotation_equals_eager(native):
+    """Device-driven steps skip the tau -> taum1 stores (and the X_m1 loads) while nothing but the fused kernel touches the
+    planes, and materialise the X_m1 planes on demand: every plane, X_m1 included, equals the eager run's
+    (RH_NO_LAZY_ROTATION) at any point -- also with uploads, per-routine calls and downloads in between."""
+    import os
+
+    import hip_util as H
+
+    g, names, forcing = load_case("svat_hetero_combo")
+
+    def run(lazy):
+        if lazy:
+            os.environ.pop("RH_NO_LAZY_ROTATION", None)
+        else:
+            os.environ["RH_NO_LAZY_ROTATION"] = "1"
+        try:
+            ctx = _ctx(native, g, names)
+        finally:
+            os.environ.pop("RH_NO_LAZY_ROTATION", None)
+        ctx.set_forcing_series(forcing)
+        snaps = []
+        ctx.run_steps(37)
+        snaps.append(H.download_snapshot(ctx, names))            # materialises
+        ctx.run_steps(5)
+        ctx.upload("S_dep", ctx.download("S_dep") * 0.5)           # the host changes a plane: the next step is eager again
+        ctx.run_steps(40)
+        snaps.append(H.download_snapshot(ctx, names))
+        ctx.call("rh_interception")                               # a per-routine entry point in between
+        ctx.run_steps(30)
+        snaps.append(H.download_snapshot(ctx, names))
+        snaps.append(H.scalars_to_row(ctx.get_scalars()))
+        ctx.close()
+        return snaps
+
+    a, b = run(True), run(False)
+    for k, (x, y) in enumerate(zip(a, b)):
+        np.testing.assert_array_equal(x, y, err_msg=f"snapshot {k}")
+    for xm1 in ("S_rz_m1", "swe_m1", "theta_m1"):     # after a complete step the rotation holds in what the host sees
+        np.testing.assert_array_equal(a[2][names.index(xm1)], a[2][names.index(xm1[:-3])], err_msg=xm1)

@@ -221,10 +221,33 @@ def main():
             all_m |= mention
             all_w |= write
             recs.append(dict(rt=rt, ld=ld, st=set(st), rot=rot_need.get(i, set())))
+        # Lazy rotation (the fused kernel when the previous operation was a complete step, so that X_m1 == X holds for
+        # every rotation pair at the start): X_m1 planes are neither loaded nor stored.  Where the step reads an X_m1, the
+        # register is filled from the register of X (ALIAS) at the first stage that needs X_m1 -- or, if X is assigned
+        # earlier than that, at the first stage that assigns X, while its register still holds the loaded value.
+        if EVICT_BEFORE:
+            sys.exit("the lazy-rotation sets are not generated together with RH_EVICT")
+        rotated = {xm1 for xm1, _ in pairs}
+        alias_at = {}
+        for xm1, x in pairs:
+            need = next((i for i, rt in enumerate(stages[:last]) if xm1 in sets[rt][0]), None)
+            if need is None:
+                continue
+            first_write = next((i for i, rt in enumerate(stages) if x in sets[rt][1]), last)
+            alias_at.setdefault(min(need, first_write), []).append((xm1, x))
+        resident_l = set()
+        for i, rec in enumerate(recs):
+            mention, write = sets[rec["rt"]]
+            need_l = (mention - rotated) | {x for _, x in alias_at.get(i, [])}
+            rec["lld"] = need_l - resident_l
+            resident_l |= need_l
+            rec["lst"] = rec["st"] - rotated
+            rec["alias"] = sorted(alias_at.get(i, []), key=lambda p: order.get(p[0]))
         for rec in recs:
             rt = rec["rt"]
-            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st")):
+            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st"), ("LLOAD", "lld"), ("LSTORE", "lst")):
                 lines.append(f"#define RH_SEQ_{seq}_{kind}_{rt}(X) " + " ".join(f"X({n})" for n in sorted(rec[key], key=order.get)))
+            lines.append(f"#define RH_SEQ_{seq}_ALIAS_{rt}(A) " + " ".join(f"A({xm1}, {x})" for xm1, x in rec["alias"]))
         # the fused kernel samples the summary bits of the next step's predicates (roger_hip.hip, k_step): prec and ta
         # after rt_select_pet, swe and swe_top after rt_snow -- nothing later may assign them
         for fld, after in (("prec", "rt_select_pet"), ("ta", "rt_select_pet"), ("swe", "rt_snow"), ("swe_top", "rt_snow")):
@@ -235,6 +258,13 @@ def main():
         if all_m != ref_m or all_w != ref_w:
             sys.exit(f"sequence {seq} does not match {SEQUENCE_CHECK[seq]}")
         lines.append("")
+    # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x
+    lines.append("// tau -> taum1 rotation of after_timestep (h_rotate): " + str(len(pairs)) + " pairs")
+    lines.append("#define RH_ROTATION_FIELDS(X) " + " ".join(f"X({x})" for _, x in sorted(pairs, key=lambda p: order.get(p[1]))))
+    for xm1, x in pairs:
+        if xm1 != x + "_m1":
+            sys.exit(f"rotation pair {xm1} = {x} does not follow the <name>_m1 convention")
+    lines.append("")
     txt = "\n".join(lines)
     if not os.path.exists(OUT) or open(OUT).read() != txt:
         open(OUT, "w").write(txt)
