@@ -25,7 +25,7 @@ def per_kernel(dirname, counter):
     return rows
 
 
-def main(fetch_dir, write_dir, n_cells, out, kernel="k_step<", calib_cells=None):
+def main(fetch_dir, write_dir, n_cells, out, kernel="k_step<2, false, true>", calib_cells=None):
     """kernel: substring of the kernel name to report; calib_cells: cells of the context the calibration copy ran
     on (default: n_cells)."""
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
@@ -57,5 +57,5 @@ def main(fetch_dir, write_dir, n_cells, out, kernel="k_step<", calib_cells=None)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], *(sys.argv[5:6] or ["k_step<"]),
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], *(sys.argv[5:6] or ["k_step<2, false, true>"]),
          *([int(sys.argv[6])] if len(sys.argv) > 6 else []))
