@@ -481,6 +481,22 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
                 if (code == 61) k = p3 + ((1 - S_rel) * p4);
                 if (code == 62) k = p3 + (S_rel * p4);
             }
+            // Exponents with a closed form -- the benchmark's own: 0.5 for transpiration, 1.5 for percolation
+            // (benchmarks/SVATOXYGEN18_benchmark.py:129-138) -- go through a correctly rounded square root instead of
+            // exp2(k * log2 .): 15 instead of 42 instructions per evaluation.  Uniform over the column.
+            const int kmode = (k == 0.5) ? 1 : ((k == 1.5) ? 2 : ((k == 1.0) ? 3 : 0));
+            if (kmode != 0) {
+                const double rS = 1.0 / S;
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double x = SA_hi[j];
+                    const double r = (x == S) ? 1.0 : x * rS;   // exactly 1 at the top edge, as (S / S) ** k is
+                    const double sq = sqrt(r);
+                    const double v = (kmode == 1) ? sq : ((kmode == 2) ? r * sq : r);
+                    const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
+                    Om[j] = (S <= 0 ? 0 : o) * mk;
+                }
+            } else {
             const double log2S = sas_log2(C, S);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -490,6 +506,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
                 const double v = sas_pow_ratio(C, x, S, log2S, k);
                 const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
                 Om[j] = (S <= 0 ? 0 : o) * mk;
+            }
             }
         } else if (dirac) {  // piston flow, sas.py:43-64: the edge index (vs.nages) against the age threshold p1
             const double S = Smax * mk;

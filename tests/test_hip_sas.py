@@ -353,3 +353,27 @@ def test_hoisted_division_is_ieee_division():
     got = _native.sas_selftest_div(a, d)
     want = a / d
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {n} quotients differ"
+
+
+def test_closed_form_exponents_against_oracle():
+    """Power-law exponents 0.5, 1.5 and 1 (the benchmark's 0.5 / 1.5 among them) take the square-root path of the kernel
+    instead of exp2(k * log2 .): same results as the oracle's pow within the usual bounds, on every workgroup shape."""
+    for n, ages, substeps in ((160, 1000, 6), (200, 90, 3), (64, 2100, 2)):
+        st = random_problem(n, ages, substeps, seed=7 + ages, stats=True)
+        rng = np.random.default_rng(ages)
+        for f in FLUXES:
+            st.sas[f][:, 0] = 6
+            st.sas[f][:, 1] = rng.choice([0.5, 1.5, 1.0, 0.2], n)
+        ref = clone(st)
+        ctx = make_ctx(st)
+        push(ctx, st)
+        ctx.step(0)
+        ctx.sync()
+        pull(ctx, st)
+        ref.step_oracle()
+        tight = column_deviation(st, lambda k: ref.state[k] if k in ref.state else ref.out[k], n, True)
+        assert tight.mean() >= 0.9, (ages, tight.mean())
+        for f in FLUXES:   # every distribution still sums to at most 1 and takes no more than the flux
+            s = st.out[f"tt_{f}"].sum(axis=1)
+            assert (s <= 1 + 1e-12).all()
+        ctx.close()
