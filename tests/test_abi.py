@@ -77,6 +77,22 @@ def test_generated_sets_are_current():
     # which the summary path selects inside the fused kernel instead of in a pass of its own
     m = re.search(r"// rt_step: loads (\d+) planes, stores (\d+) planes", before)
     assert m and int(m.group(2)) == 154
+    # lazy rotation: over the stages of a sequence the lazy sets store the same planes but the 30 X_m1 of the rotation
+    # pairs, load none of them, and fill exactly the X_m1 that the step reads from X's register
+    rot = set(re.search(r"#define RH_ROTATION_FIELDS\(X\) (.*)", before).group(1).replace("X(", "").replace(")", "").split())
+    assert len(rot) == 30
+    for seq in ("step", "step_monthly", "step_lateral", "step_lateral_monthly"):
+        def planes(kind):
+            out = []
+            for line in re.findall(rf"#define RH_SEQ_{seq}_{kind}_\w+\(\w\)(.*)", before):
+                out += re.findall(r"\w\((\w+)(?:, \w+)?\)", line)
+            return out
+        eager = set(planes("STORE")) | {x + "_m1" for x in planes("ROT")}
+        lazy = set(planes("LSTORE"))
+        assert eager - lazy == {x + "_m1" for x in rot}, seq
+        assert not {p for p in planes("LLOAD") if p in {x + "_m1" for x in rot}}, seq
+        assert set(planes("LLOAD")) <= set(planes("LOAD")) and len(planes("LLOAD")) == len(set(planes("LLOAD"))), seq
+        assert set(planes("ALIAS")) <= {x + "_m1" for x in rot} and len(planes("ALIAS")) == 11, seq
 
 
 def test_no_gpu_means_loud_failure():
