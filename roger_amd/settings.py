@@ -1,93 +1,52 @@
-"""Model settings of the SVAT path, mirroring roger/settings.py (same names, defaults, types)."""
+"""Model settings: the names, types and defaults of roger/settings.py that the SVAT / oneD / offline-transport path uses
+(setup scripts assign them in `set_settings`), and the scope check of the native backend."""
 from collections import namedtuple
 
-Setting = namedtuple("setting", ("default", "type", "description"))
+Setting = namedtuple("Setting", ("default", "type", "group"))
 
 
 def optional(type_):
-    def wrapped(arg):
-        return arg if arg is None else type_(arg)
-
-    return wrapped
+    """None stays None, anything else is converted."""
+    return lambda arg: arg if arg is None else type_(arg)
 
 
 PI = 3.14159265358979323846264338327950588
 
-SETTINGS = {
-    "identifier": Setting("UNNAMED", str, "Identifier of the current simulation"),
-    "nx": Setting(1, int, "Grid points in zonal (x) direction"),
-    "ny": Setting(1, int, "Grid points in meridional (y) direction"),
-    "nz": Setting(1, int, "Grid points in vertical (z) direction"),
-    "dx": Setting(1, int, "Zonal grid spacing"),
-    "dy": Setting(1, int, "Meridional grid spacing"),
-    "dz": Setting(1, int, "Vertical grid spacing"),
-    "nitt": Setting(1, int, "Number of total iterations"),
-    "nitt_forc": Setting(1, int, "Number of total iterations of forcing"),
-    "ages": Setting(1, int, "Number of water ages"),
-    "nages": Setting(2, int, "Number of water ages to calculate cumulated distributions"),
-    "nsas": Setting(8, int, "Number of entries per grid cell containing SAS parameters"),
-    "runlen": Setting(0.0, float, "Length of simulation in seconds"),
-    "runlen_warmup": Setting(0.0, float, "Length of warmup simulation in seconds"),
-    "x_origin": Setting(0, float, "Grid origin in x-direction"),
-    "y_origin": Setting(0, float, "Grid origin in y-direction"),
-    "time_origin": Setting("1900-01-01 00:00:00", str, "time origin"),
-    "output_frequency": Setting(0.0, float, "Time between output"),
-    # physical constants used by the kernels (roger/settings.py:52-80)
-    "pi": Setting(PI, float, "Pi"),
-    "r_mp": Setting(2.5, float, "Macropore radius in mm"),
-    "l_sc": Setting(10000, float, "Total length of shrinkage cracks in mm/m^2"),
-    "sf": Setting(3, float, "Degree-day factor in -"),
-    "ta_fm": Setting(0, float, "freeze-melt threshold in degC"),
-    "rmax": Setting(30, float, "Retention capacity of liquid water in snow cover in %"),
-    "end_event": Setting(21600, int, "Time after which no rainfall/snow melt occurs in seconds"),
-    "hpi": Setting(5, int, "threshold for classification of heavy rainfall event in mm/10min"),
-    "a_bc": Setting(2, int, "a parameter for Brooks-Corey"),
-    "b_bc": Setting(2, int, "b parameter for Brooks-Corey"),
-    "clay_min": Setting(0.01, float, "minimum clay content of soil"),
-    "clay_max": Setting(0.71, float, "maximum clay content of soil"),
-    "theta_rew_min": Setting(0.02, float, "minimum soil water content at permanent wilting point in -"),
-    "theta_rew_max": Setting(0.24, float, "maximum soil water content at permanent wilting point in -"),
-    "zroot_to_zsoil_max": Setting(0.7, float, "maximum ratio of root zone depth to soil depth in -"),
-    "rew_min": Setting(2, float, "minimum readily evaporable water in mm"),
-    "rew_max": Setting(12, float, "maximum readily evaporable water in mm"),
-    "z_evap_max": Setting(150, float, "maximum soil evaporation depth in mm"),
-    "transp_water_stress": Setting(0.75, float, "fraction of fine pore storage in -"),
-    "atol": Setting(1e-2, float, "absolute tolerance of solutions"),
-    "rtol": Setting(1e-2, float, "relative tolerance of solutions"),
-    # offline transport (roger/settings.py:76-78, 102-120)
-    "VSMOW_conc18O": Setting(2005.2e-6, float, "oxygen-18 abundancy ratios according to VSMOW in -"),
-    "d18O_min": Setting(-20, float, "potentially lowest oxygen-18 value in per mille"),
-    "d18O_max": Setting(0, float, "potentially greatest oxygen-18 value in per mille"),
-    "VSMOW_conc2H": Setting(155.76e-6, float, "deuterium abundancy ratios according to VSMOW in -"),
-    "d2H_min": Setting(-160, float, "potentially lowest deuterium value in per mille"),
-    "d2H_max": Setting(0, float, "potentially greatest deuterium value in per mille"),
-    "enable_bromide": Setting(False, bool, "enable bromide"),
-    "enable_chloride": Setting(False, bool, "enable enable_chloride"),
-    "enable_oxygen18": Setting(False, bool, "enable oxygen-18"),
-    "enable_deuterium": Setting(False, bool, "enable deuterium"),
-    "enable_nitrate": Setting(False, bool, "enable nitrate"),
-    "enable_virtualtracer": Setting(False, bool, "enable virtual tracer"),
-    "tm_structure": Setting("UNNAMED", str, "transport model structure"),
-    "enable_age_statistics": Setting(False, bool, "enable calculation of age statistics"),
-    "sas_solver": Setting(None, optional(str), "numerical solver scheme for StorAge selection"),
-    "sas_solver_substeps": Setting(1, int, "substeps to solver for StorAge selection numerically"),
-    # process switches: only the SVAT path is implemented natively; the others must stay off
-    "enable_distributed_input": Setting(False, bool, "enable distributed input"),
-    "enable_film_flow": Setting(False, bool, "enable film flow process"),
-    "enable_lateral_flow": Setting(False, bool, "enable lateral flow"),
-    "enable_crop_phenology": Setting(False, bool, "enable crop phenology"),
-    "enable_net_irrigation": Setting(False, bool, "enable net crop irrigation"),
-    "enable_soil_compaction": Setting(False, bool, "enable soil compaction"),
-    "enable_offline_transport": Setting(False, bool, "enable offline transport"),
-    "enable_groundwater_boundary": Setting(False, bool, "enable groundwater boundary"),
-    "enable_groundwater": Setting(False, bool, "enable groundwater"),
-    "enable_routing_1D": Setting(False, bool, "enable unidirectional routing"),
-    "enable_routing_2D": Setting(False, bool, "enable bidirectional routing"),
-    "enable_macropore_lower_boundary_condition": Setting(False, bool, "enable lower boundary condition of macropores"),
-    "enable_adaptive_time_stepping": Setting(False, bool, "enable_adaptive_time_stepping"),
-    "warmup_done": Setting(False, bool, "True if after model warmup"),
-    "restart_input_filename": Setting(None, optional(str), "File name of restart input."),
+# name: (default, type); grouped by what they are for
+_GROUPS = {
+    "run": {   # grid, run length, clock
+        "identifier": ("UNNAMED", str), "nx": (1, int), "ny": (1, int), "nz": (1, int), "dx": (1, int),
+        "dy": (1, int), "dz": (1, int), "nitt": (1, int), "nitt_forc": (1, int), "ages": (1, int), "nages": (2, int),
+        "nsas": (8, int), "runlen": (0.0, float), "runlen_warmup": (0.0, float), "x_origin": (0, float),
+        "y_origin": (0, float), "time_origin": ("1900-01-01 00:00:00", str), "output_frequency": (0.0, float),
+    },
+    "const": {   # constants the kernels use (device copy: rh_config)
+        "pi": (PI, float), "r_mp": (2.5, float), "l_sc": (10000, float), "sf": (3, float), "ta_fm": (0, float),
+        "rmax": (30, float), "end_event": (21600, int), "hpi": (5, int), "a_bc": (2, int), "b_bc": (2, int),
+        "clay_min": (0.01, float), "clay_max": (0.71, float), "theta_rew_min": (0.02, float),
+        "theta_rew_max": (0.24, float), "zroot_to_zsoil_max": (0.7, float), "rew_min": (2, float),
+        "rew_max": (12, float), "z_evap_max": (150, float), "transp_water_stress": (0.75, float),
+        "atol": (1e-2, float), "rtol": (1e-2, float),
+    },
+    "tracer": {   # offline transport: isotope constants, tracer switches, SAS solver
+        "VSMOW_conc18O": (2005.2e-6, float), "d18O_min": (-20, float), "d18O_max": (0, float),
+        "VSMOW_conc2H": (155.76e-6, float), "d2H_min": (-160, float), "d2H_max": (0, float),
+        "enable_bromide": (False, bool), "enable_chloride": (False, bool), "enable_oxygen18": (False, bool),
+        "enable_deuterium": (False, bool), "enable_nitrate": (False, bool), "enable_virtualtracer": (False, bool),
+        "tm_structure": ("UNNAMED", str), "enable_age_statistics": (False, bool),
+        "sas_solver": (None, optional(str)), "sas_solver_substeps": (1, int),
+    },
+    "switch": {   # process switches (what is native: check_setting_conflicts)
+        "enable_distributed_input": (False, bool), "enable_film_flow": (False, bool),
+        "enable_lateral_flow": (False, bool), "enable_crop_phenology": (False, bool),
+        "enable_net_irrigation": (False, bool), "enable_soil_compaction": (False, bool),
+        "enable_offline_transport": (False, bool), "enable_groundwater_boundary": (False, bool),
+        "enable_groundwater": (False, bool), "enable_routing_1D": (False, bool), "enable_routing_2D": (False, bool),
+        "enable_macropore_lower_boundary_condition": (False, bool), "enable_adaptive_time_stepping": (False, bool),
+        "warmup_done": (False, bool), "restart_input_filename": (None, optional(str)),
+    },
 }
+SETTINGS = {name: Setting(default, type_, group) for group, table in _GROUPS.items() for name, (default, type_) in table.items()}
 
 _UNSUPPORTED_SWITCHES = (
     "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
