@@ -9,7 +9,6 @@ own chunk, `<stem>.<rank>.npz` when more than one process runs).
 """
 import numpy as np
 
-from . import variables as var_mod
 
 
 def _path(path, rank, world):

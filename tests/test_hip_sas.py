@@ -9,8 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from sas_binding import (FLUXES, GOLDEN, INFS, SAS_CASES, STAT_Q, STAT_TARGETS, TIE_WIPED, SasGolden, SasState, column_deviation,
-                         compare_sas)
+from sas_binding import FLUXES, GOLDEN, SAS_CASES, TIE_WIPED, SasGolden, SasState, column_deviation, compare_sas
 from test_oracle_sas import compare_msa
 
 pytestmark = pytest.mark.gpu
