@@ -98,6 +98,7 @@ struct rh_ctx {
     // lazy tau -> taum1 rotation (k_step<.,.,LAZY>): rot_consistent = the last thing that touched the planes was a complete
     // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
     bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
+    bool agg_daily_stale;   // per-cell daily forcing sums must be re-formed (new weights; first use)
     double *diag_buf;
     long long *diag_steps_buf;
     long long diag_interval;
@@ -200,29 +201,62 @@ RH_DEV double np_sum144(Get get) {
 
 // aggregates {prec, ta, pet} x {daily, hourly, 10 min} of one forcing series (stride between
 // consecutive slots given, so the same code serves the shared vector and per-cell rows)
+// np.sum over the 144 slots of a series that is 0 outside the hourly window [itd, itd + 6) (the masked sums of
+// adaptive_time_stepping.py:400-420), in numpy's pairwise order without walking the 138 zeros: the window's six
+// consecutive slots fall into six different lanes of the two 72-blocks (lane = slot mod 8), every lane also receives
+// zeros (v + 0.0: a negative zero becomes positive, as in the full sum), and the lanes are combined as np_sum72 does.
+// itd is uniform over the grid, so the lane selection is scalar work.
+template <class Get>
+RH_DEV double np_sum144_window(Get get, int64_t itd) {
+    double lane[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lane[h][j] = 0.0;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        const int64_t k = itd + w;
+        if (k < 0 || k >= RH_SLOTS_PER_DAY) continue;
+        const double v = get((int)k) + 0.0;
+        const int h = k >= 72 ? 1 : 0, j = (int)((k - 72 * h) & 7);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (hh == h && jj == j) lane[hh][jj] = v;
+    }
+    const double h0 = ((lane[0][0] + lane[0][1]) + (lane[0][2] + lane[0][3])) + ((lane[0][4] + lane[0][5]) + (lane[0][6] + lane[0][7]));
+    const double h1 = ((lane[1][0] + lane[1][1]) + (lane[1][2] + lane[1][3])) + ((lane[1][4] + lane[1][5]) + (lane[1][6] + lane[1][7]));
+    return 0.0 + (h0 + h1);
+}
+
+// aggregates {prec, ta, pet} x {daily, hourly, 10 min} of one forcing series given by accessors (per-cell rows, or the
+// weighted station forcing: PREC[k] * w, TA[k] + offset, PET[k] * w).  daily = false leaves a[0..2] alone: the daily
+// sums only change with the day.
 template <class P, class T, class E>
-RH_DEV void forcing_aggregates_of(P p_of, T t_of, E e_of, int64_t itd, double *a);
+RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily = true);
 RH_DEV void forcing_aggregates(const double *p, const double *t, const double *e, int64_t itd, double *a) {
     forcing_aggregates_of([&](int k) { return p[k]; }, [&](int k) { return t[k]; }, [&](int k) { return e[k]; }, itd, a);
 }
-// the same for a series given by accessors (weighted station forcing: PREC[k] * w, TA[k] + offset, PET[k] * w)
 template <class P, class T, class E>
-RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a) {
-    a[0] = np_sum144([&](int k) { return p(k); });
-    {
+RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily) {
+    if (daily) {
+        a[0] = np_sum144([&](int k) { return p(k); });
         int cnt = 0;
         for (int k = 0; k < 144; ++k) cnt += !isnan(t(k));
         a[1] = np_sum144([&](int k) { const double v = t(k); return isnan(v) ? 0.0 : v; }) / (double)cnt;
+        a[2] = np_sum144([&](int k) { return e(k); });
     }
-    a[2] = np_sum144([&](int k) { return e(k); });
-    auto in = [&](int k) { return (k >= itd) && (k < itd + 6); };
-    a[3] = np_sum144([&](int k) { return in(k) ? p(k) : 0.0; });
+    a[3] = np_sum144_window([&](int k) { return p(k); }, itd);
     {
         int cnt = 0;
-        for (int k = 0; k < 144; ++k) cnt += in(k) && !isnan(t(k));
-        a[4] = np_sum144([&](int k) { const double v = t(k); return (in(k) && !isnan(v)) ? v : 0.0; }) / (double)cnt;
+        for (int w = 0; w < 6; ++w) {
+            const int64_t k = itd + w;
+            cnt += (k >= 0 && k < 144) && !isnan(t((int)k));
+        }
+        a[4] = np_sum144_window([&](int k) { const double v = t(k); return isnan(v) ? 0.0 : v; }, itd) / (double)cnt;
     }
-    a[5] = np_sum144([&](int k) { return in(k) ? e(k) : 0.0; });
+    a[5] = np_sum144_window([&](int k) { return e(k); }, itd);
     int64_t k = itd < 0 ? itd + 144 : itd;
     k = k > 143 ? 143 : k;
     a[6] = p((int)k);
@@ -431,21 +465,24 @@ __global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int
 
 // Per-cell forcing only: aggregates of every column's own 144-slot series, once per step, into
 // nine SoA planes (so the per-column kernels stay free of the 144-element loops).
-__global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D) {
+__global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int force_daily) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const bool weighted = D->weights[0] != nullptr;
     __shared__ DaySeries day;
     if (weighted) stage_day(D, day);
     if (i >= a.n) return;
     double agg[9];
+    // the station series of the day changes at midnight only (device-side hooks): its daily sums are formed once a day,
+    // the first step of the day has itt_day == 0; rows uploaded by the host may change at any time
+    const bool daily = !weighted || force_daily || D->S.itt_day == 0;
     if (weighted) {
         const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
         forcing_aggregates_of([&](int k) { return day.f[0][k] * pw; }, [&](int k) { return day.f[1][k] + toff; },
-                              [&](int k) { return day.f[2][k] * ew; }, D->S.itt_day, agg);
+                              [&](int k) { return day.f[2][k] * ew; }, D->S.itt_day, agg, daily);
     } else
         forcing_aggregates(D->forc_cell[0] + i * RH_SLOTS_PER_DAY, D->forc_cell[1] + i * RH_SLOTS_PER_DAY,
                            D->forc_cell[2] + i * RH_SLOTS_PER_DAY, D->S.itt_day, agg);
-    for (int k = 0; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
+    for (int k = daily ? 0 : 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
 
@@ -1143,6 +1180,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->arena_offset = 0;
     ctx->rot_consistent = false;
     ctx->m1_stale = false;
+    ctx->agg_daily_stale = true;
     ctx->diag_reads_m1 = false;
     ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
@@ -1599,7 +1637,10 @@ int rh_step_phase1(rh_ctx *ctx) {
 int rh_step_phase2(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     LAUNCH_WG(ctx, k_agg, ctx->dev, 0, 0);
-    if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
+    if (ctx->per_cell) {   // (does not touch the planes: no LAUNCH_CELLS)
+        hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
+        ctx->agg_daily_stale = false;
+    }
     LAUNCH_PRED(ctx, k_select);
     LAUNCH_WG(ctx, k_reduce, ctx->dev, 1);
     CHECK_LAUNCH(ctx);
@@ -1633,7 +1674,10 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     }
     LAUNCH_PRED(ctx, k_pred1);
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
-    if (ctx->per_cell) LAUNCH_CELLS(ctx, k_cell_agg);
+    if (ctx->per_cell) {   // (does not touch the planes: no LAUNCH_CELLS)
+        hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
+        ctx->agg_daily_stale = false;
+    }
     LAUNCH_PRED(ctx, k_select);
     LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1);
     int rc = launch_fused_kernel(ctx, monthly);
@@ -1749,6 +1793,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->weights, dptr, sizeof(dptr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
+    ctx->agg_daily_stale = true;
     return RH_OK;
 }
 
