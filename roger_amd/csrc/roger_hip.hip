@@ -48,6 +48,7 @@ struct DevState {
     // single-workgroup kernel that follows (a single word hammered by atomics from every wave
     // costs ~100 us per pass: one address sustains ~90 atomics/us)
     unsigned long long bflags[2][RH_PRED_BLOCKS];
+    unsigned long long day_bflags[RH_PRED_BLOCKS];   // k_pred1, weighted station forcing: the forcing bits of the day per workgroup
     int pred_blocks;               // workgroups launched for k_pred1 / k_select
     // summary path: one word per wavefront of the fused kernel (QB_* bits of its columns at the end of the step),
     // OR-reduced by k_ctrl at the start of the next step
@@ -99,6 +100,7 @@ struct rh_ctx {
     // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
     bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
     bool agg_daily_stale;   // per-cell daily forcing sums must be re-formed (new weights; first use)
+    bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
     double *diag_buf;
     long long *diag_steps_buf;
     long long diag_interval;
@@ -318,12 +320,15 @@ RH_DEV void stage_day(const DevState *D, DaySeries &s) {
     __syncthreads();
 }
 // start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
-__global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
+__global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D, int force_daily) {
     const Consts K = D->K;
     unsigned long long b = 0;
     const bool per_cell = D->per_cell != 0, weighted = D->weights[0] != nullptr;
+    // weighted station forcing: the day's series changes at midnight only, so the forcing bits of a workgroup's columns
+    // (the same columns every step: the grid-stride mapping is fixed) are formed once a day and kept
+    const bool daily = force_daily || D->S.itt_day == 0;
     __shared__ DaySeries day;
-    if (per_cell && weighted) stage_day(D, day);
+    if (per_cell && weighted && daily) stage_day(D, day);
     for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * RH_BLOCK) {
         double swe, swe_top;
         rh_ld(a, RH_P_swe, i, swe);
@@ -333,11 +338,25 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D) {
         b |= !(swe_top <= 0) ? BIT(PB_SWETOP_NOT_LE0) : 0;
         b |= (swe_top > 0) ? BIT(PB_SWETOP_GT0) : 0;
         if (per_cell && weighted) {
-            const double pw = D->weights[0][i], toff = D->weights[1][i];
-            for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(day.f[0][k] * pw, day.f[1][k] + toff, K);
+            if (daily) {
+                const double pw = D->weights[0][i], toff = D->weights[1][i];
+                for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(day.f[0][k] * pw, day.f[1][k] + toff, K);
+            }
         } else if (per_cell) {
             const double *p = D->forc_cell[0] + i * RH_SLOTS_PER_DAY, *t = D->forc_cell[1] + i * RH_SLOTS_PER_DAY;
             for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p[k], t[k], K);
+        }
+    }
+    if (per_cell && weighted) {   // keep / reuse the day's forcing bits of this workgroup
+        const unsigned long long cols = BIT(PB_SWE_NOT_LE0) | BIT(PB_SWE_GT0) | BIT(PB_SWETOP_NOT_LE0) | BIT(PB_SWETOP_GT0);
+        __shared__ unsigned long long s_day;
+        if (daily) {
+            block_or_store(&D->day_bflags[blockIdx.x], b & ~cols);
+            __syncthreads();   // block_or_store's scratch is used again below
+        } else {
+            if (threadIdx.x == 0) s_day = D->day_bflags[blockIdx.x];
+            __syncthreads();
+            b |= s_day;
         }
     }
     block_or_store(&D->bflags[0][blockIdx.x], b);
@@ -1181,6 +1200,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->rot_consistent = false;
     ctx->m1_stale = false;
     ctx->agg_daily_stale = true;
+    ctx->pred_daily_stale = true;
     ctx->diag_reads_m1 = false;
     ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
@@ -1629,7 +1649,9 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
 int rh_step_phase1(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
-    LAUNCH_PRED(ctx, k_pred1);
+    planes_touched(ctx);
+    hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
+    ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_reduce, ctx->dev, 0);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -1672,7 +1694,9 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         launch_hooks(ctx);
         hooks = 0;
     }
-    LAUNCH_PRED(ctx, k_pred1);
+    planes_touched(ctx);
+    hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
+    ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
     if (ctx->per_cell) {   // (does not touch the planes: no LAUNCH_CELLS)
         hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
@@ -1794,6 +1818,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
     ctx->agg_daily_stale = true;
+    ctx->pred_daily_stale = true;
     return RH_OK;
 }
 
