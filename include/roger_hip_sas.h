@@ -32,7 +32,7 @@
  *   calc_ageing_sa_kernel, calc_ageing_msa_kernel  core/transport.py:623-680, 743-778
  * with calc_mtt's anion branch (transport.py:583-596); RH_SAS_RESCALE then follows rescale_sa_msa_anion_soil_kernel's
  * bromide branch (core/soil.py:1399-1506) or, with RH_SAS_TRACER_CHLORIDE (settings.enable_chloride), its chloride
- * branch (:1507-1640).  Nitrate and the virtual tracer are not implemented.
+ * branch (:1507-1640), which RH_SAS_TRACER_VIRTUAL shares.  Nitrate is not implemented.
  *
  * Same conventions as roger_hip.h: plain pointers and sizes, 0 / negative rh_status returns,
  * rh_sas_last_error for the text, one context = one HIP device + one stream, asynchronous
@@ -59,6 +59,8 @@ extern "C" {
 #define RH_SAS_TRACER_OXYGEN18 0
 #define RH_SAS_TRACER_BROMIDE 1
 #define RH_SAS_TRACER_CHLORIDE 2 /* the anion kernels as for bromide; RH_SAS_RESCALE scales the solute with the water */
+#define RH_SAS_TRACER_VIRTUAL 3  /* settings.enable_virtualtracer: as chloride, and the soil evaporation takes the tracer along
+                                    (calc_evaporation_transport_virtualtracer_kernel, core/evapotranspiration.py:722-791) */
 #define RH_SAS_MAX_NAGES 4096 /* ages + 1 <= this (benchmark: ages = 1000, SVATOXYGEN18_benchmark.py:28-44) */
 
 typedef struct rh_sas_config {
@@ -71,7 +73,7 @@ typedef struct rh_sas_config {
     int32_t keep_distributions;/* also write tt_*, mtt_*, TT_*, sa_s, msa_s (diagnostics) */
     double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78); for
                                        * settings.enable_deuterium: VSMOW_conc2H, d2H_min, d2H_max (:79-81), same kernels */
-    int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 | _BROMIDE | _CHLORIDE (settings.enable_oxygen18 / enable_bromide / enable_chloride) */
+    int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 | _BROMIDE | _CHLORIDE | _VIRTUAL (settings.enable_oxygen18 / enable_bromide / enable_chloride / enable_virtualtracer) */
     int32_t reserved;
 } rh_sas_config;
 

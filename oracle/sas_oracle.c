@@ -47,8 +47,9 @@ typedef struct oc_sas {
     double *stats[5][6];
     /* soil.rescale_SA after the warm-up run */
     const double *S_rz_init, *S_ss_init;
-    /* tracer: 0 oxygen-18 (msa = concentration by age), 1 bromide, 2 chloride (anion kernels: msa = solute mass by age;
-     * the two differ in soil.rescale_SA only) */
+    /* tracer: 0 oxygen-18 (msa = concentration by age), 1 bromide, 2 chloride, 3 virtual tracer (anion kernels: msa =
+     * solute mass by age; bromide and chloride differ in soil.rescale_SA only, the virtual tracer is chloride that also
+     * leaves with the soil evaporation) */
     int64_t tracer;
     const double *alpha_transp, *alpha_q, *S_sat_rz; /* (n) partition coefficients, saturation storage of the root zone */
     const int32_t *lu_id;                            /* (n) land use: 500 < lu_id < 599 is a crop */
@@ -369,7 +370,9 @@ static void step_anion(const oc_sas *P, int64_t i, double *work) {
         sa_rz[0] += im + ip * mk;
         msa_rz[0] += P->M_inf[0][i] + P->M_inf[1][i] * mk;
     }
-    outflux_anion(P, i, 0, P->evap_soil[i], 0, 1, sa_rz, msa_rz, NULL, NULL, mk, work);
+    /* soil evaporation: water only (calc_evaporation_transport_kernel), but the virtual tracer leaves with it at alpha = 1
+     * (calc_evaporation_transport_virtualtracer_kernel, evapotranspiration.py:722-791) */
+    outflux_anion(P, i, 0, P->evap_soil[i], 1.0, P->tracer == 3 ? 0 : 1, sa_rz, msa_rz, NULL, NULL, mk, work);
     {   /* crop solute uptake stops above 80 % saturation: evapotranspiration.py:932-939 */
         const int crop = (P->lu_id[i] > 500) && (P->lu_id[i] < 599) && (np_sum(sa_rz, A) >= 0.8 * P->S_sat_rz[i]);
         const double alpha = (crop ? 0 : P->alpha_transp[i]) * mk;
@@ -477,7 +480,7 @@ void oc_sas_rescale(const oc_sas *P) {
         const double t_rz = np_sum(sa_rz, A), t_ss = np_sum(sa_ss, A);
         for (int64_t k = 0; k < A; ++k) sa_rz[k] = P->S_rz_init[i] * (sa_rz[k] / t_rz);
         for (int64_t k = 0; k < A; ++k) sa_ss[k] = P->S_ss_init[i] * (sa_ss[k] / t_ss);
-        if (P->tracer == 2) { /* chloride: rescale_sa_msa_anion_soil_kernel, core/soil.py:1507-1640 -- the solute is scaled
+        if (P->tracer == 2 || P->tracer == 3) { /* chloride, virtual tracer: rescale_sa_msa_anion_soil_kernel, core/soil.py:1507-1640 -- the solute is scaled
                                * with the water (by S_init / sum(sa) of the state before the rescaling), M_* stay */
             const double f_rz = P->S_rz_init[i] / t_rz, f_ss = P->S_ss_init[i] / t_ss;
             for (int64_t k = 0; k < A; ++k) {

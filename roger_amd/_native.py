@@ -126,7 +126,7 @@ class RhSasConfig(C.Structure):
 
 # RH_SAS_TRACER_*.  Deuterium runs the isotope kernels of oxygen-18 with its own constants in the vsmow / d18O_min /
 # d18O_max fields of rh_sas_config (roger/core/transport.py:315-340, roger/settings.py:79-81)
-SAS_TRACERS = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2}
+SAS_TRACERS = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2, "virtualtracer": 3}
 DEUTERIUM_DEFAULTS = {"vsmow": 155.76e-6, "d18O_min": -160.0, "d18O_max": 0.0}
 
 

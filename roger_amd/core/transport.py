@@ -32,10 +32,10 @@ def conc_to_delta(state, conc):
 
 
 def _written_by_step(settings):
-    if settings.enable_bromide or settings.enable_chloride:   # the anion kernels: solute masses instead of delta values, no signal of the soil evaporation
+    if settings.enable_bromide or settings.enable_chloride or settings.enable_virtualtracer:   # the anion kernels: solute masses instead of delta values, no signal of the soil evaporation
         names = ["sa_rz", "msa_rz", "sa_ss", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s"]
         for f in SAS_FLUXES:
-            names += [f"tt_{f}", f"TT_{f}"] + ([f"mtt_{f}", f"C_{f}", f"M_{f}"] if f != "evap_soil" else [])
+            names += [f"tt_{f}", f"TT_{f}"] + ([f"mtt_{f}", f"C_{f}", f"M_{f}"] if f != "evap_soil" or settings.enable_virtualtracer else [])
         for f in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
             names += [f"C_{f}", f"M_{f}"]
         if settings.enable_age_statistics:

@@ -1004,8 +1004,12 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
     if constexpr (ANION) {
         const double alpha_q = ((const double *)P.a[SA_alpha_q])[cell];
         if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, sa_rz, msa_rz, mk, base);
-        if (P.stages & RH_SAS_EVAP)
-            outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+        if (P.stages & RH_SAS_EVAP) {   // water only -- but the virtual tracer leaves with it at alpha = 1
+            if (P.tracer == RH_SAS_TRACER_VIRTUAL)
+                outflux_anion<W, E, false, false, false>(B, P, cell, 0, 1.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+            else
+                outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+        }
         if (P.stages & RH_SAS_TRANSP) {
             // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
             const int lu = ((const int *)P.a[SA_lu_id])[cell];
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             sa_ss[j] = in ? S_ss_init * (sa_ss[j] / t[1]) : 0.0;
             sa_s[j] = sa_rz[j] + sa_ss[j];
             if constexpr (ANION) {
-                if (P.tracer == RH_SAS_TRACER_CHLORIDE) {  // rescale_sa_msa_anion_soil_kernel, chloride (core/soil.py:1507-1640):
+                if (P.tracer != RH_SAS_TRACER_BROMIDE) {  // rescale_sa_msa_anion_soil_kernel, chloride / virtual tracer (core/soil.py:1507-1640):
                     msa_rz[j] *= S_rz_init / t[0];         // the solute is scaled with the water
                     msa_ss[j] *= S_ss_init / t[1];
                 } else {  // bromide (:1399-1506): the soil starts free of it
@@ -1143,7 +1147,7 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
             const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
             msa_s[j] = ((v != v) || (base + j == 0)) ? 0 : v;
             if constexpr (ANION) {
-                if (P.tracer == RH_SAS_TRACER_CHLORIDE) {   // C = sum(msa) / sum(sa), msa_s = msa_rz + msa_ss
+                if (P.tracer != RH_SAS_TRACER_BROMIDE) {   // C = sum(msa) / sum(sa), msa_s = msa_rz + msa_ss
                     msa_s[j] = msa_rz[j] + msa_ss[j];
                     s[0] += msa_rz[j];
                     s[2] += msa_ss[j];
@@ -1165,10 +1169,10 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
         if (B.tid == 0) {
             for (int k = 0; k < 3; ++k) {
                 double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
-                if (ANION && P.tracer == RH_SAS_TRACER_CHLORIDE) C = s[2 * k] / s[2 * k + 1];   // unguarded, M_* untouched
+                if (ANION && P.tracer != RH_SAS_TRACER_BROMIDE) C = s[2 * k] / s[2 * k + 1];   // unguarded, M_* untouched
                 ((double *)P.a[SA_C_rz + k])[cell] = C;
                 if constexpr (ANION) {
-                    if (P.tracer != RH_SAS_TRACER_CHLORIDE) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
+                    if (P.tracer == RH_SAS_TRACER_BROMIDE) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
                 } else {
                     ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
                 }
@@ -1305,8 +1309,8 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
     if (cfg->ages < 2 || cfg->ages + 1 > RH_SAS_MAX_NAGES)
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: ages must be in [2, RH_SAS_MAX_NAGES - 1]");
     if (cfg->substeps < 1 || cfg->forcing_days < 1) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: substeps and forcing_days must be >= 1");
-    if (cfg->tracer != RH_SAS_TRACER_OXYGEN18 && cfg->tracer != RH_SAS_TRACER_BROMIDE && cfg->tracer != RH_SAS_TRACER_CHLORIDE)
-        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18, _BROMIDE or _CHLORIDE");
+    if (cfg->tracer < RH_SAS_TRACER_OXYGEN18 || cfg->tracer > RH_SAS_TRACER_VIRTUAL)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18, _BROMIDE, _CHLORIDE or _VIRTUAL");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");

@@ -56,10 +56,11 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
     delta_to_conc, conc_to_delta = tr.delta_to_conc, tr.conc_to_delta
 
     nx, ny = svat["S_rz"].shape[:2]
-    chloride = tracer == "chloride"
+    virtual = tracer == "virtualtracer"   # as chloride, and the soil evaporation takes the tracer along
+    chloride = tracer in ("chloride", "virtualtracer")
     deuterium = tracer == "deuterium"   # the isotope kernels with the constants of 2H (roger/core/transport.py:315-340)
     d0 = -70 if deuterium else -10      # initial signal of the soil water in permil
-    bromide = tracer in ("bromide", "chloride")   # anion transport (mass based): models/svat_bromide, deterministic solver
+    bromide = tracer in ("bromide", "chloride", "virtualtracer")   # anion transport (mass based): models/svat_bromide, deterministic solver
     extra = extra or {}
 
     class GoldenSAS(RogerSetup):
@@ -84,7 +85,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             s.enable_oxygen18 = not bromide and not deuterium
             s.enable_deuterium = deuterium
             s.enable_bromide = bromide and not chloride
-            s.enable_chloride = chloride
+            s.enable_chloride = chloride and not virtual
+            s.enable_virtualtracer = virtual
             s.tm_structure = "power"
             s.enable_age_statistics = bool(age_statistics)
 
@@ -198,7 +200,8 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.S_S = update(vs.S_S, at[2:-2, 2:-2, :], vs.S_RZ[2:-2, 2:-2, :] + vs.S_SS[2:-2, 2:-2, :])
             vs.S_SNOW = update(vs.S_SNOW, at[2:-2, 2:-2, :], svat["S_snow"])
             if bromide:   # bromide concentration of the input in mg/l, a pulse on selected days (extra["C_IN"]: (nx, ny, t))
-                vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], extra["C_IN"])
+                if not virtual:   # (the reference has no C_IN series for the virtual tracer: set_forcing assigns C_in itself)
+                    vs.C_IN = update(vs.C_IN, at[2:-2, 2:-2, :], extra["C_IN"])
                 return
             vs.C_ISO_IN = update(vs.C_ISO_IN, at[2:-2, 2:-2, 0], npx.nan)
             # deuterium: the same series on the meteoric water line, d2H = 8 * d18O + 10
@@ -220,7 +223,7 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
             vs.S_ss = update(vs.S_ss, at[2:-2, 2:-2, vs.tau], vs.S_SS[2:-2, 2:-2, i])
             vs.S_s = update(vs.S_s, at[2:-2, 2:-2, vs.tau], vs.S_rz[2:-2, 2:-2, vs.tau] + vs.S_ss[2:-2, 2:-2, vs.tau])
             vs.S_snow = update(vs.S_snow, at[2:-2, 2:-2, vs.tau], vs.S_SNOW[2:-2, 2:-2, i])
-            vs.C_in = update(vs.C_in, at[2:-2, 2:-2], vs.C_IN[2:-2, 2:-2, i])
+            vs.C_in = update(vs.C_in, at[2:-2, 2:-2], extra["C_IN"][:, :, i] if virtual else vs.C_IN[2:-2, 2:-2, i])
             if bromide:   # models/svat_bromide/svat_bromide.py:343-347
                 vs.M_in = update(vs.M_in, at[2:-2, 2:-2], vs.C_in[2:-2, 2:-2] * vs.prec[2:-2, 2:-2, vs.tau])
                 return

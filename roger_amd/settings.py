@@ -52,7 +52,7 @@ _UNSUPPORTED_SWITCHES = (
     "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
-    "enable_nitrate", "enable_virtualtracer",
+    "enable_nitrate",
 )
 
 
@@ -65,10 +65,11 @@ def check_setting_conflicts(settings):
     if settings.enable_offline_transport:
         # the native transport path: oxygen-18, deuterium, bromide or chloride with the deterministic SAS solver
         # 
-        if sum(int(getattr(settings, k)) for k in ("enable_oxygen18", "enable_deuterium", "enable_bromide", "enable_chloride")) != 1:
-            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, deuterium, bromide and "
-                                      "chloride (exactly one of settings.enable_oxygen18 / enable_deuterium / enable_bromide / "
-                                      "enable_chloride must be True)")
+        if sum(int(getattr(settings, k)) for k in ("enable_oxygen18", "enable_deuterium", "enable_bromide", "enable_chloride",
+                                                   "enable_virtualtracer")) != 1:
+            raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, deuterium, bromide, chloride "
+                                      "and the virtual tracer (exactly one of settings.enable_oxygen18 / enable_deuterium / "
+                                      "enable_bromide / enable_chloride / enable_virtualtracer must be True)")
         if settings.sas_solver != "deterministic":
             raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
                                       '"deterministic" SAS solver (Euler / RK4 are out of scope, SURVEY.md section 8)')

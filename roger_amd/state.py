@@ -339,7 +339,7 @@ class RogerState:
             # variables tt_*, mtt_*, TT_*, sa_s, msa_s are exposed, hence keep_distributions
             if self._var_meta is None:
                 self._var_meta = var_mod.build_transport_variables(s)
-            tracer = next(t for t in ("oxygen18", "deuterium", "bromide", "chloride") if getattr(s, "enable_" + t))
+            tracer = next(t for t in ("oxygen18", "deuterium", "bromide", "chloride", "virtualtracer") if getattr(s, "enable_" + t))
             iso = (s.VSMOW_conc2H, s.d2H_min, s.d2H_max) if s.enable_deuterium else (s.VSMOW_conc18O, s.d18O_min, s.d18O_max)
             self._sas_ctx = _native.SasContext(
                 (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,

@@ -169,7 +169,7 @@ def build_transport_variables(settings):
         for w, p in SAS_STAT_TARGETS:
             for q in ("10", "25", "50", "75", "90", "avg"):
                 V[f"{p}{q}_{w}"] = Variable(f"{p}{q}_{w}", CATCH_GRID, sas=f"{p}{q}_{w}")
-    if settings.enable_bromide or settings.enable_chloride:
+    if settings.enable_bromide or settings.enable_chloride or settings.enable_virtualtracer:
         # the anion kernels' variables (roger/variables.py:534, 2114-2122, 2474, 2536, 4071, 4324, 4666, 5377-5405, 5602)
         V["S_sat_rz"] = Variable("S_sat_rz", CATCH_GRID, sas="S_sat_rz")
         V["lu_id"] = Variable("lu_id", CATCH_GRID, dtype=i64, sas="lu_id")

@@ -77,7 +77,7 @@ def make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics
 
 # bromide (anion) transport: what is recorded instead of the isotope variables
 BR_CELL_VARS = ("C_in", "M_in", "C_inf_mat_rz", "C_inf_pf_rz", "C_inf_pf_ss", "M_inf_mat_rz", "M_inf_pf_rz", "M_inf_pf_ss", "C_transp",
-                "C_q_rz", "C_q_ss", "C_cpr_rz", "M_transp", "M_q_rz", "M_q_ss", "M_cpr_rz")
+                "C_q_rz", "C_q_ss", "C_cpr_rz", "M_transp", "M_q_rz", "M_q_ss", "M_cpr_rz", "C_evap_soil", "M_evap_soil")
 BR_CELL2_VARS = ("C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")
 
 
@@ -151,7 +151,7 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
     rng = np.random.default_rng(seed + 7)
     svat["d18O_prec"] = np.concatenate([[np.nan], rng.uniform(-12, -4, ndays)])
     sas = sas_params(nx, ny, variant, seed)
-    bromide = tracer in ("bromide", "chloride")   # the anion kernels
+    bromide = tracer in ("bromide", "chloride", "virtualtracer")   # the anion kernels
     extra = None
     if bromide:   # partition coefficients, a crop column (500 < lu_id < 599) and two bromide pulses in the input
         lu = np.array([8, 550, 10, 5, 8, 560])[np.arange(nx * ny) % 6].reshape(nx, ny)
@@ -160,7 +160,7 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
         C_IN[:, :, 5] = rng.uniform(10, 40, (nx, ny))
         C_IN[:, :, 7] = rng.uniform(5, 20, (nx, ny))
         extra = dict(alpha_transp=rng.uniform(0.2, 1.0, (nx, ny)), alpha_q=rng.uniform(0.4, 1.0, (nx, ny)), lu_id=lu, C_IN=C_IN)
-        if tracer == "chloride":   # chloride comes with every rain and sits in the soil from the start
+        if tracer in ("chloride", "virtualtracer"):   # comes with every rain and sits in the soil from the start
             C_IN[:, :, 1:] = rng.uniform(0.5, 3.0, (nx, ny, ndays))
             extra.update(C_init_rz=4.0, C_init_ss=9.0)
     model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0,
@@ -226,6 +226,7 @@ def main():
         "sas_bromide_a40": (3, 2, 12, 40, 4, "power", True, 29, False, "bromide"),
         "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
         "sas_chloride_warmup_a30": (2, 2, 10, 30, 3, "power", True, 41, True, "chloride"),
+        "sas_virtualtracer_a30": (2, 2, 10, 30, 3, "power", False, 47, True, "virtualtracer"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

@@ -76,7 +76,7 @@ class SasState:
         self.n, self.ages, self.substeps = int(n), int(ages), int(substeps)
         self.age_statistics = bool(age_statistics)
         self.tracer = tracer
-        self.anion = tracer in ("bromide", "chloride")   # the reference's anion kernels: msa is solute mass by age
+        self.anion = tracer in ("bromide", "chloride", "virtualtracer")   # the reference's anion kernels: msa is solute mass by age
         A = self.ages
         z = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
         self.maskCatch = np.ones(n, dtype=np.int32)
@@ -105,7 +105,7 @@ class SasState:
         # bromide: partition coefficients, land use, saturation storage; solute masses of fluxes and storages
         self.par = {"alpha_transp": np.ones(n), "alpha_q": np.ones(n), "S_sat_rz": z(n), "lu_id": np.zeros(n, dtype=np.int32)}
         if self.anion:
-            for k in ANION_MASSES:
+            for k in ANION_MASSES + (("M_evap_soil",) if tracer == "virtualtracer" else ()):
                 self.out[k] = z(n)
 
     def struct(self):
@@ -133,13 +133,14 @@ class SasState:
                 for j, q in enumerate(STAT_Q):
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
         s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
-        s.tracer = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2}[self.tracer]
+        s.tracer = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2, "virtualtracer": 3}[self.tracer]
         if self.anion:
             for k in ("alpha_transp", "alpha_q", "S_sat_rz"):
                 setattr(s, k, _ptr(self.par[k]))
             s.lu_id = self.par["lu_id"].ctypes.data_as(C.POINTER(C.c_int32))
-            for i, f in enumerate(FLUXES[1:], start=1):
-                s.M[i] = _ptr(self.out[f"M_{f}"])
+            for i, f in enumerate(FLUXES):
+                if f"M_{f}" in self.out:
+                    s.M[i] = _ptr(self.out[f"M_{f}"])
             for i, f in enumerate(INFS):
                 s.M_inf[i] = _ptr(self.out[f"M_{f}"])
             s.M_rz, s.M_ss, s.M_s = (_ptr(self.out[k]) for k in ("M_rz", "M_ss", "M_s"))

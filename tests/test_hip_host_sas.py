@@ -124,3 +124,11 @@ def test_svat_to_transport_example(tmp_path):
     assert wet.any() and (C[1:][wet] > -12).all() and (C[1:][wet] < -4).all()      # between the soil's -10 and the rain's -5 .. -11
     assert np.nanmin(tt50[1:]) >= 1 and np.nanmax(tt50[1:]) <= 60
     model.state.sas_context.close()
+
+
+def test_virtualtracer_warmup_on_device():
+    g = sb.SasGolden("sas_virtualtracer_a30")
+    model = bromide_model(g, warmup_days=g.ndays)
+    run_and_compare_bromide(g, model, warmup=1)
+    assert model.state.sas_context.tracer == "virtualtracer"
+    model.state.sas_context.close()

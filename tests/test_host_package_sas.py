@@ -107,7 +107,7 @@ def bromide_model(g, pkg="roger_amd", warmup_days=0):
         C_IN[:, :, d] = g.day(d, "C_in").reshape(shape)
     extra = {k: g.z[k].reshape(shape) for k in ("alpha_transp", "alpha_q", "lu_id")}
     extra["C_IN"] = C_IN
-    if g.tracer == "chloride":   # the background concentrations tests/golden/make_golden_sas.py starts from
+    if g.tracer in ("chloride", "virtualtracer"):   # the background concentrations tests/golden/make_golden_sas.py starts from
         extra.update(C_init_rz=4.0, C_init_ss=9.0)
     return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=warmup_days,
                                 tracer=g.tracer, extra=extra)
@@ -127,7 +127,7 @@ def run_and_compare_bromide(g, model, rtol=1e-9, warmup=0):
     if warmup:   # soil.rescale_SA: rescaled age vectors, the soil emptied of bromide / chloride scaled with the water
         for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "C_rz", "C_s"):
             sb.compare_sas(interior(getattr(vs, k), 1), g.day(0, k), f"{g.tracer} after warm-up {k}", rtol=rtol, atol=1e-11)
-        assert np.asarray(vs.msa_rz).any() == (g.tracer == "chloride") and vs.itt == 0
+        assert np.asarray(vs.msa_rz).any() == (g.tracer != "bromide") and vs.itt == 0
     for d in range(1, g.ndays + 1):
         model.step(model.state)
         assert vs.itt == d
@@ -152,6 +152,12 @@ def test_bromide_warmup_and_run(oracle_sas):
 def test_chloride_warmup_and_run(oracle_sas):
     """settings.enable_chloride: setup(); warmup(); run() against the reference's chloride run."""
     g = sb.SasGolden("sas_chloride_warmup_a30")
+    run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
+
+
+def test_virtualtracer_warmup_and_run(oracle_sas):
+    """settings.enable_virtualtracer through the host package (no C_IN series in the reference: set_forcing assigns C_in)."""
+    g = sb.SasGolden("sas_virtualtracer_a30")
     run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
 
 

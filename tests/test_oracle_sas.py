@@ -229,3 +229,28 @@ def test_threads_do_not_change_results():
     sb.lib().oc_sas_set_num_threads(1)
     for k in outs[0]:
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+
+
+def test_virtualtracer_rescale_and_run():
+    """settings.enable_virtualtracer: the anion kernels, the soil evaporation takes the tracer along at alpha = 1
+    (calc_evaporation_transport_virtualtracer_kernel), rescaling as for chloride."""
+    g = SasGolden("sas_virtualtracer_a30")
+    assert g.tracer == "virtualtracer"
+    st = g.new_state()
+    for k in st.state:
+        st.state[k][:] = g.z[f"w000_{k}"]
+    for k in st.S_init:
+        st.S_init[k][:] = g.z[k]
+    st.rescale_oracle()
+    for k in ("sa_rz", "sa_ss", "msa_rz", "msa_ss"):
+        compare_sas(st.state[k], g.day(0, k), f"virtual tracer rescale {k}")
+    names = bromide_names(bool(g.stats)) + ["mtt_evap_soil", "C_evap_soil", "M_evap_soil"]
+    took = 0.0
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        st.step_oracle()
+        for k in names:
+            got = st.state[k] if k in st.state else st.out[k]
+            compare_sas(got, g.day(d, k), f"virtual tracer day {d} {k}", rtol=1e-9, atol=1e-11)
+        took += st.out["M_evap_soil"].sum()
+    assert took > 0      # the evaporation did take tracer
