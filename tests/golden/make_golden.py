@@ -106,6 +106,7 @@ def uniform_params(nx, ny):
 
 
 TUTORIAL_INPUT = "/root/reference/examples/plot_scale/svat_tutorial/input"
+EBERBAECHLE_INPUT = "/root/reference/examples/catchment_scale/eberbaechle/svat_distributed/input"
 
 
 def tutorial_params():
@@ -118,7 +119,7 @@ def tutorial_params():
     )
 
 
-def make_model(roger, params, forcing, ndays, lateral=False):
+def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
     from roger import roger_routine
     from roger.models.svat import SVATSetup
     from roger.models.oneD import ONEDSetup
@@ -163,6 +164,10 @@ def make_model(roger, params, forcing, ndays, lateral=False):
                 vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
                 vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)
                 vs.dmph = update(vs.dmph, at[2:-2, 2:-2], params["dmph"])
+            if weights is not None:   # examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186
+                vs.prec_weight = update(vs.prec_weight, at[2:-2, 2:-2], weights["prec_weight"])
+                vs.ta_offset = update(vs.ta_offset, at[2:-2, 2:-2], weights["ta_offset"])
+                vs.pet_weight = update(vs.pet_weight, at[2:-2, 2:-2], weights["pet_weight"])
 
         @roger_routine
         def set_initial_conditions(self, state):
@@ -186,9 +191,17 @@ def make_model(roger, params, forcing, ndays, lateral=False):
                 vs.month = update(vs.month, at[1], F["MONTH"][vs.itt_forc])
                 vs.doy = update(vs.doy, at[1], F["DOY"][vs.itt_forc])
                 sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
-                vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
-                vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
-                vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
+                if weights is not None:   # station series x per-cell weight (eberbaechle/svat_distributed/svat.py:276-296)
+                    vs.prec_day = update(vs.prec_day, at[2:-2, 2:-2, :],
+                                         vs.PREC[npx.newaxis, npx.newaxis, sl] * vs.prec_weight[2:-2, 2:-2, npx.newaxis])
+                    vs.ta_day = update(vs.ta_day, at[2:-2, 2:-2, :],
+                                       vs.TA[npx.newaxis, npx.newaxis, sl] + vs.ta_offset[2:-2, 2:-2, npx.newaxis])
+                    vs.pet_day = update(vs.pet_day, at[2:-2, 2:-2, :],
+                                        vs.PET[npx.newaxis, npx.newaxis, sl] * vs.pet_weight[2:-2, 2:-2, npx.newaxis])
+                else:
+                    vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
+                    vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
+                    vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
                 vs.itt_forc = vs.itt_forc + 6 * 24
 
     return GoldenSVAT()
@@ -255,10 +268,10 @@ ROUTINES = (
 
 
 def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine_steps, outdir, lateral=False,
-             pair_every=0):
+             pair_every=0, weights=None):
     import importlib
 
-    model = make_model(roger, params, forcing, ndays, lateral=lateral)
+    model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights)
     planes = plane_names()
     rec = {}
     routine_log = {}
@@ -327,6 +340,9 @@ def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine
             rec["lut_mlms"] = np.asarray(vs.lut_mlms, dtype=np.float64)[:200]  # slopes 1..200 %
         for k, v in forcing.items():
             rec[f"forc_{k}"] = v
+        if weights is not None:
+            for k, v in weights.items():
+                rec[f"weight_{k}"] = np.asarray(v, dtype=np.float64).ravel()
         scal_rows = []
         snaps = {}
         step = 0
@@ -389,6 +405,19 @@ def main():
         if args.only and args.only != name:
             continue
         run_case(roger, name, params, forcing, ndays, max_steps, snap_every, rsteps, args.out)
+    if not args.only or args.only == "svat_eberbaechle_weights":
+        # BASELINE configs[4] (catchment_scale/eberbaechle/svat_distributed): the station's measured series -- the first 40 days of
+        # the shipped PREC/TA/PET.txt, 2019-11-01 .. 2019-12-10, month change included -- times / plus per-cell prec_weight,
+        # ta_offset, pet_weight in the setup's own set_forcing; parameters.nc is not shipped, so heterogeneous synthetic maps
+        nd = 40
+        nx, ny = 4, 3
+        rng = np.random.default_rng(2019)
+        weights = dict(prec_weight=rng.uniform(0.8, 1.3, (nx, ny)), ta_offset=rng.uniform(-5.5, 1.5, (nx, ny)),
+                       pet_weight=rng.uniform(0.85, 1.15, (nx, ny)))
+        from roger_amd.forcing import forcing_from_txt
+
+        run_case(roger, "svat_eberbaechle_weights", hetero_params(nx, ny, seed=2019), forcing_from_txt(EBERBAECHLE_INPUT, ndays=nd),
+                 nd, 100000, 100, {1, 2, 3, 300, 301}, args.out, weights=weights)
     # oneD model (lateral subsurface flow, benchmarks/oneD_benchmark.py): wet start so that a perched
     # water table forms and the lateral branches are taken
     def oned_params(nx, ny, seed):
@@ -408,6 +437,15 @@ def main():
                               {1, 2, 3, 40, 41, 120, 121}),
         "oned_hetero_heavyrain": (oned_params(3, 2, 22), toy_forcing("heavyrain", ndays=4), 4, 100000, 25, {1, 2, 20, 21}),
     }
+    def oned_benchmark_params(nx, ny):
+        """benchmarks/oneD_benchmark.py:99-135, 160-163 (BASELINE configs[3]): uniform columns."""
+        p = uniform_params(nx, ny)
+        f = lambda v: np.full((nx, ny), v)  # noqa: E731
+        p.update(z_soil=f(1000.0), lmpv=f(600.0), slope=f(0.05), dmph=f(50.0))
+        return p
+
+    # configs[3]'s own parameter set: the start state of the full-size property test (3200 x 3125 columns vs one oracle column)
+    oned["oned_uniform_benchmark"] = (oned_benchmark_params(3, 2), toy_forcing("heavyrain", ndays=4), 4, 100000, 25, {1, 2, 20, 21})
     for name, (params, forcing, ndays, max_steps, snap_every, rsteps) in oned.items():
         if args.only and args.only != name:
             continue

@@ -115,6 +115,8 @@ def sas_params(nx, ny, variant, seed):
         p = np.zeros((nx, ny, 8))
         p[..., 0] = 6
         p[..., 1] = k * rng.uniform(0.7, 1.4, (nx, ny))
+        if variant == "benchmark":   # BASELINE configs[2]: exactly the benchmark's exponents (SVATOXYGEN18_benchmark.py:129-138)
+            p[..., 1] = k
         if variant == "families":   # dirac, kumaraswami (plain and storage-dependent variants), exponential, power
             code = rng.choice([2, 3, 31, 32, 33, 34, 35, 36, 37, 51, 6], (nx, ny))
             p[..., 0] = code
@@ -227,6 +229,9 @@ def main():
         "sas_bromide_warmup_a30": (2, 2, 10, 30, 3, "power", False, 31, True, "bromide"),
         "sas_chloride_warmup_a30": (2, 2, 10, 30, 3, "power", True, 41, True, "chloride"),
         "sas_virtualtracer_a30": (2, 2, 10, 30, 3, "power", False, 47, True, "virtualtracer"),
+        # BASELINE configs[2] at its own shape: ages = 1000, 6 sub-steps, the benchmark's exponents, age statistics on
+        # (SVATOXYGEN18_benchmark.py:28-44,59,129-138); three columns, the days 3-7 of the combo forcing (rain, heavy rain, dry)
+        "sas_benchmark_a1000": (3, 1, 7, 1000, 6, "benchmark", True, 53),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

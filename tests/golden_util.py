@@ -6,8 +6,11 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrain", "svat_hetero_combo",
               "svat_tutorial")   # the last: BASELINE configs[0], one cell, a year of measured forcing
-ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo")   # oneD model: lateral subsurface flow
+# oneD model: lateral subsurface flow; the last: BASELINE configs[3]'s own uniform parameter set (benchmarks/oneD_benchmark.py:99-135)
+ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo", "oned_uniform_benchmark")
 CASES = SVAT_CASES + ONED_CASES
+# BASELINE configs[4] (Eberbaechle, svat_distributed): the station's measured series x per-cell prec_weight / ta_offset / pet_weight
+WEIGHTED_CASES = ("svat_eberbaechle_weights",)
 
 # Tolerance of the oracle against the reference NumPy backend, and of the HIP path against the
 # oracle.  fp64 throughout; differences come only from libm `pow/log/exp` implementations
@@ -23,6 +26,13 @@ def load_case(name):
     names = [str(x) for x in g["plane_names"]]
     forcing = {k[5:]: g[k] for k in g.files if k.startswith("forc_")}
     return g, names, forcing
+
+
+def load_weights(g):
+    """Per-cell forcing weights of a golden case (None for the cases whose columns share one series)."""
+    if "weight_prec_weight" not in g.files:
+        return None
+    return {k: np.asarray(g[f"weight_{k}"], dtype=np.float64) for k in ("prec_weight", "ta_offset", "pet_weight")}
 
 
 def is_lateral(g):

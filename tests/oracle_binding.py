@@ -191,9 +191,18 @@ class ForcingDriver:
     """Host-side `set_forcing` / `set_parameters` hooks of the benchmark setup
     (benchmarks/SVAT_benchmark.py:105-110,151-171) for the oracle."""
 
-    def __init__(self, forcing):
+    def __init__(self, forcing, weights=None):
         self.F = forcing
         self.day = None
+        self.weights = weights   # dict(prec_weight, ta_offset, pet_weight) per column: the distributed catchment setups' set_forcing
+
+    def day_slice(self, i):
+        day = tuple(self.F[k][i:i + 144].copy() for k in ("PREC", "TA", "PET"))
+        if self.weights is not None:   # examples/catchment_scale/eberbaechle/svat_distributed/svat.py:276-296
+            w = self.weights
+            day = (day[0][None, :] * w["prec_weight"][:, None], day[1][None, :] + w["ta_offset"][:, None],
+                   day[2][None, :] * w["pet_weight"][:, None])
+        return day
 
     def before_step(self, st):
         """Returns (prec_day, ta_day, pet_day, monthly)."""
@@ -204,8 +213,7 @@ class ForcingDriver:
             s.year[1] = int(self.F["YEAR"][i])
             s.month[1] = int(self.F["MONTH"][i])
             s.doy[1] = int(self.F["DOY"][i])
-            self.day = (self.F["PREC"][i:i + 144].copy(), self.F["TA"][i:i + 144].copy(),
-                        self.F["PET"][i:i + 144].copy())
+            self.day = self.day_slice(i)
             s.itt_forc = i + 144
         monthly = (s.month[1] != s.month[0]) and (s.itt > 1)
         return (*self.day, monthly)

@@ -16,7 +16,7 @@ INFS = ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss")
 STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("s", "rt"))
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
 SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40",
-             "sas_deuterium_a40")
+             "sas_deuterium_a40", "sas_benchmark_a1000")
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 

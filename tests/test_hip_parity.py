@@ -3,7 +3,7 @@ against the oracle.  Needs a real MI355X: `pytest -m gpu`."""
 import numpy as np
 import pytest
 
-from golden_util import ATOL, CASES, ONED_CASES, RTOL, compare, compare_bulk, is_lateral, load_case
+from golden_util import ATOL, CASES, ONED_CASES, RTOL, WEIGHTED_CASES, compare, compare_bulk, is_lateral, load_case, load_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -215,30 +215,35 @@ def test_vs_oracle_hetero_4096(native, oracle, per_cell):
     ctx.close()
 
 
-@pytest.mark.parametrize("nx,ny", [(1000, 1000), (3200, 3125)])
-def test_full_size_properties(native, oracle, nx, ny):
-    """BASELINE configs[1] size (nx*ny = 10^6) and the north-star size (10^7), uniform benchmark
-    parameters: size-independent properties -- every column equals the single-column oracle run
-    bit-for-tolerance, the mass balance closes, the sanity flag holds."""
+@pytest.mark.parametrize("nx,ny,lateral", [(1000, 1000, False), (3200, 3125, False), (3200, 3125, True)])
+def test_full_size_properties(native, oracle, nx, ny, lateral):
+    """BASELINE configs[1] size (nx*ny = 10^6), the north-star size (10^7), and BASELINE configs[3] -- the oneD model with lateral
+    subsurface flow at 3200 x 3125 columns, its own uniform parameters (the reference's start state of oned_uniform_benchmark) and
+    heavy rain so that a perched water table forms and the lateral branches run: size-independent properties -- every column equals
+    the single-column oracle run bit-for-tolerance, the mass balance closes, the sanity flag holds."""
     import hip_util as H
     from roger_amd.forcing import toy_forcing
 
-    g, names, _ = load_case("svat_uniform_rain")
+    g, names, _ = load_case("oned_uniform_benchmark" if lateral else "svat_uniform_rain")
     luts = (g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
     # oracle: the 6-cell uniform golden start state, one column is enough
     st = oracle.OracleState(6)
     st.load_snapshot(g["state0"], names)
     st.load_scalars(g["scal0"])
     st.set_luts(*luts)
-    ctx = native.Context(nx, ny)
+    st.settings.enable_lateral_flow = int(lateral)
+    ctx = native.Context(nx, ny, enable_lateral_flow=int(lateral))
     for row, nm in zip(g["state0"], names):
-        ctx.upload(nm, np.full(nx * ny, row[0]))
+        if nm in ctx.index:
+            ctx.upload(nm, np.full(nx * ny, row[0]))
     ctx.set_scalars(H.scalars_from_row(g["scal0"]))
     ctx.set_luts(*luts)
-    F = toy_forcing("rain", ndays=3)
+    if lateral:
+        ctx.set_lut_mlms(g["lut_mlms"])
+    F = toy_forcing("heavyrain" if lateral else "rain", ndays=4 if lateral else 3)
     odrv = oracle.ForcingDriver(F)
     hdrv = H.HipForcingDriver(ctx, F)
-    for step in range(30):
+    for step in range(90 if lateral else 30):
         pd, td, ed, monthly = odrv.before_step(st)
         st.step(pd, td, ed, monthly)
         ctx.step(hdrv.before_step())
@@ -246,7 +251,11 @@ def test_full_size_properties(native, oracle, nx, ny):
     assert s.sanity_ok == 1
     np.testing.assert_array_equal(H.scalars_to_row(s), st.scalars_row())
     ref = st.snapshot()
-    for nm in ("S", "S_rz", "S_ss", "theta_rz", "theta_ss", "z0", "q_ss", "aet", "inf_mat_rz", "z_wf", "dS_num_error"):
+    check = ("S", "S_rz", "S_ss", "theta_rz", "theta_ss", "z0", "q_ss", "aet", "inf_mat_rz", "z_wf", "dS_num_error")
+    if lateral:
+        check += ("q_sub", "q_sub_rz", "q_sub_ss", "q_sub_mp_ss", "z_sat", "z_sat_layer_3", "S_zsat")
+        assert ref[names.index("q_sub")][0] > 0.05 and ref[names.index("z_sat")][0] > 100   # the lateral branches did run
+    for nm in check:
         col = ctx.download(nm)
         assert col.min() == col.max(), nm  # identical inputs -> identical columns
         r = ref[names.index(nm)][0]
@@ -342,6 +351,48 @@ def test_weighted_station_forcing_on_device(native, oracle):
     compare_bulk(H.download_snapshot(ctx, onames), st.snapshot(), onames, what=f"weighted forcing, {steps} steps")
     assert len({600, 3600, 86400} & {int(st.scal.dt_secs)}) == 1 and steps > 40
     ctx.close()
+
+
+@pytest.mark.parametrize("case", WEIGHTED_CASES)
+def test_weighted_station_forcing_golden(native, case):
+    """BASELINE configs[4] pinned by the reference itself: the golden run's set_forcing multiplies / offsets the station's measured
+    series (first 40 days of the shipped Eberbaechle PREC/TA/PET.txt) by per-cell prec_weight / ta_offset / pet_weight
+    (examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186, 276-296).  The device forms every column's day from
+    the resident series and the three weight planes (rh_set_forcing_weights) and steps without the host: integer scalars exact,
+    all planes at the stored steps; snow falls on part of the grid only, so the per-cell predicates decide the step length."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    w = load_weights(g)
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_series(forcing)
+    ctx.set_forcing_weights(w["prec_weight"], w["ta_offset"], w["pet_weight"])
+    done = 0
+    for step in sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit()):
+        ctx.run_steps(step - done)
+        done = step
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][step - 1], err_msg=f"step {step}")
+        compare(H.download_snapshot(ctx, names), g[f"s{step:05d}"], names, what=f"{case} step {step}")
+    assert done == int(g["nsteps"]) and ctx.get_scalars().sanity_ok == 1
+    # ... and with the per-cell day handed over by the host hook each midnight (rh_set_forcing_day(per_cell=1)), step by step
+    ctx2 = _ctx(native, g, names)
+    for step in range(1, 120):
+        s = ctx2.get_scalars()
+        if s.time % 86400 == 0:
+            i = s.itt_forc
+            s.itt_day = 0
+            s.year[1], s.month[1], s.doy[1] = int(forcing["YEAR"][i]), int(forcing["MONTH"][i]), int(forcing["DOY"][i])
+            s.itt_forc = i + 144
+            ctx2.set_scalars(s)
+            ctx2.set_forcing_day(forcing["PREC"][i:i + 144][None, :] * w["prec_weight"][:, None],
+                                 forcing["TA"][i:i + 144][None, :] + w["ta_offset"][:, None],
+                                 forcing["PET"][i:i + 144][None, :] * w["pet_weight"][:, None])
+        ctx2.step((s.month[1] != s.month[0]) and (s.itt > 1))
+        np.testing.assert_array_equal(H.scalars_to_row(ctx2.get_scalars()), g["scal"][step - 1], err_msg=f"host hook, step {step}")
+        if f"s{step:05d}" in g.files:
+            compare(H.download_snapshot(ctx2, names), g[f"s{step:05d}"], names, what=f"{case} host hook, step {step}")
+    ctx.close()
+    ctx2.close()
 
 
 def test_timing_detail_reports_time_step_classes():

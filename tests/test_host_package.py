@@ -184,6 +184,23 @@ def test_forcing_from_text_inputs():
     assert F64["PREC"].shape == (2 * SLOTS_PER_DAY,) and F64["PREC"][0] == 0.42 and F["PREC"][0] != 0.42
 
 
+def test_forcing_from_text_inputs_eberbaechle():
+    """The same reader on BASELINE configs[4]'s measured station series (tests/golden/eberbaechle_input: the first 40 days of
+    examples/catchment_scale/eberbaechle/svat_distributed/input, 2019-11-01 .. 2019-12-10) against the arrays the golden run
+    svat_eberbaechle_weights was driven with."""
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from roger_amd.forcing import SLOTS_PER_DAY, forcing_from_txt
+
+    g = np.load(os.path.join(GOLDEN_DIR, "svat_eberbaechle_weights.npz"))
+    F = forcing_from_txt(os.path.join(GOLDEN_DIR, "eberbaechle_input"))
+    for k in ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY"):
+        assert F[k].shape == (40 * SLOTS_PER_DAY,), k
+        np.testing.assert_array_equal(F[k], g[f"forc_{k}"], err_msg=k)
+    assert F["DOY"][0] == 305 and F["MONTH"][-1] == 12
+
+
 def _diagnostics_model(case, ndays, tmp_path, device_hooks=False):
     import svat_scripts as S
     from roger_amd import roger_routine

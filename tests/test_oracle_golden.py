@@ -3,7 +3,7 @@ backend (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import CASES, ONED_CASES, compare, is_lateral, load_case
+from golden_util import CASES, ONED_CASES, WEIGHTED_CASES, compare, is_lateral, load_case, load_weights
 
 
 def _start(ob, g, names, key="state0"):
@@ -55,13 +55,14 @@ def test_single_steps_from_reference_states(oracle, case):
         compare(st.snapshot(), g[f"s{k:05d}"], st.names, what=f"{case} single step {k}")
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + WEIGHTED_CASES)
 def test_trajectory(oracle, case):
-    """Full steps (all routines fused per cell) reproduce the reference trajectory."""
+    """Full steps (all routines fused per cell) reproduce the reference trajectory.  The weighted case pins the oracle's per-cell
+    forcing path (a (n, 144) day per variable, `fstride = 144`) against the reference's own per-cell prec_day / ta_day / pet_day."""
     g, names, forcing = load_case(case)
     first_tie = {"oned_hetero_combo": 44, "oned_hetero_heavyrain": 10 ** 9}.get(case, 10 ** 9)
     st = _start(oracle, g, names)
-    drv = oracle.ForcingDriver(forcing)
+    drv = oracle.ForcingDriver(forcing, weights=load_weights(g))
     nsteps = int(g["nsteps"])
     checked = 0
     for step in range(1, nsteps + 1):
