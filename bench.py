@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--station-weights", action="store_true",
                     help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
                          "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")
+    ap.add_argument("--placement-probes", type=int, default=4,
+                    help="svat / oned: candidate arenas rh_create times a streaming copy on before keeping the fastest (DESIGN.md section 5; "
+                         "the library's default is 1 = take the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
@@ -263,9 +266,9 @@ def main():
         params = dict(params or {})
         for k, v in dict(z_soil=1000.0, lmpv=600.0, slope=0.05, slope_per=5, dmph=50.0).items():
             params.setdefault(k, v)
-    ctx = create_svat(nx, ny, params=params, device=local_rank, lateral=(args.model == "oned"))
+    ctx = create_svat(nx, ny, params=params, device=local_rank, lateral=(args.model == "oned"), placement_probes=args.placement_probes)
     total_steps = args.steps + args.warmup
-    forcing = combo_forcing(ndays=max(30, total_steps // 20 + 5))
+    forcing = combo_forcing(ndays=max(30, total_steps + 5))   # a dry day is ONE step: the series must outlast one step per day
     ctx.set_forcing_series(forcing)
     if args.station_weights:   # eberbaechle/svat_distributed/svat.py:169-186, 276-296 (synthetic maps, seed 7)
         import numpy as np

@@ -96,6 +96,7 @@ struct StepCtx {
     int64_t dt_secs_prelim;
     int64_t itt_day;
     int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 0: k_select did
+    int forc_exhausted;   // the device-side set_forcing hook found midnight beyond the end of the resident series
 };
 
 // predicate bit positions, word 0 (start of step) and word 1 (after prec/ta selection)

@@ -29,6 +29,14 @@
 
 #define RH_BLOCK 256
 #define RH_PRED_BLOCKS 1024  // grid of the grid-stride predicate kernels
+#define RH_DONE_GROUPS 1024  // completion counters of the fused kernel (two levels: workgroup -> group -> grid)
+#define RH_DEVERR_FORCING 1u // a step began a day beyond the end of the resident forcing series
+// flags of k_step / sources of k_ctrl
+#define RH_TAIL_USE_NEXT 1   // this step runs on S_next / X_next (the previous kernel's tail formed them); its tail commits them
+#define RH_TAIL_CTRL 2       // the tail forms the next step's S_next / X_next
+#define RH_TAIL_HOOKS 4      // ... including the device-side set_forcing / set_parameters hooks
+#define RH_SRC_WORD3 0       // the summary word sits in words[3] (a fused kernel ran last)
+#define RH_SRC_SUMW 1        // ... in sumw[] (k_summary rebuilt it from the arena)
 #ifndef RH_STEP_PREFETCH
 #define RH_STEP_PREFETCH 0  // 1: request the next stage's planes before computing the current one (measured slower: spills)
 #endif
@@ -50,10 +58,16 @@ struct DevState {
     unsigned long long bflags[2][RH_PRED_BLOCKS];
     unsigned long long day_bflags[RH_PRED_BLOCKS];   // k_pred1, weighted station forcing: the forcing bits of the day per workgroup
     int pred_blocks;               // workgroups launched for k_pred1 / k_select
-    // summary path: one word per wavefront of the fused kernel (QB_* bits of its columns at the end of the step),
-    // OR-reduced by k_ctrl at the start of the next step
-    unsigned long long *sflags;
-    int sflag_blocks;
+    // summary path: the QB_* bits of every column at the end of a step, OR-ed by the fused kernel's wavefronts into 64 words
+    // (device-scope atomics, word = workgroup mod 64: ~250 atomics per address and step at 10^6 columns); the last wavefront
+    // to finish folds them into words[3] and runs the control part of the NEXT step on S_next / X_next (step_tail)
+    unsigned long long sumw[64];
+    unsigned int done_grp[RH_DONE_GROUPS];   // workgroups finished per group of 2^grp_shift workgroups
+    unsigned int done_top;                   // groups finished
+    unsigned long long sanity_last;          // words[2] of the last fused step (the tail clears words[2] for the next one)
+    unsigned int err_flags;                  // RH_DEVERR_*
+    rh_scalars S_next;                       // scalars / step context of the next step, formed by the tail of the last fused kernel;
+    StepCtx X_next;                          // committed to S / X by the tail of the kernel that runs that step
     // device-side output accumulators (rh_diag_configure): (diag_slots, diag_rate + diag_collect, n) float64
     double *diag;
     long long *diag_steps;         // per slot: {steps accumulated (the divisor of the "average" diagnostic), start time of the
@@ -95,7 +109,11 @@ struct rh_ctx {
     void *series_buf;
     double *mlms_buf;
     bool per_cell;
-    bool summary_valid;   // D->sflags describe the columns as they are in the arena now
+    bool summary_valid;   // the summary word (words[3]) describes the columns as they are in the arena now
+    bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
+    int pending_hooks;    // ... formed with / without the device-side hooks
+    bool tail_ok;         // RH_NO_TAIL_CTRL unset
+    int grp_shift;        // fused kernel: 2^grp_shift workgroups per completion group
     // lazy tau -> taum1 rotation (k_step<.,.,LAZY>): rot_consistent = the last thing that touched the planes was a complete
     // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
     bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
@@ -105,7 +123,6 @@ struct rh_ctx {
     long long *diag_steps_buf;
     long long diag_interval;
     int diag_n, diag_slots;
-    unsigned long long *sflags_buf;
     int pred_blocks;
     bool forcing_set;
     bool timing;
@@ -304,6 +321,7 @@ RH_DEV void hooks_set_forcing(DevState *D) {
             D->per_cell = D->weights[0] ? 1 : 0;
         }
         D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
+        if (midnight && !have) D->err_flags |= RH_DEVERR_FORCING;   // the step would run on yesterday's forcing: reported by rh_sync / rh_get_scalars
     }
     __threadfence();
     __syncthreads();
@@ -560,19 +578,22 @@ __global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce
     if (!do_reduce) w = D->words[1];
     scalars_body(D, w, do_finish, 0);
 }
-// one thread
-RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel) {
-    // one burst of loads, the bookkeeping in registers, one burst of stores: working on D->S / D->X in place costs a
-    // global-memory round trip per field for this single thread (the control kernel took 20 us that way)
-    rh_scalars S = D->S;
-    StepCtx X = D->X;
+// agg[3 * sel + off] without a dynamic index (which would put the whole step context into scratch memory)
+RH_DEV double agg_pick(const StepCtx &X, int sel, int off) {
+    const double a0 = off == 0 ? X.agg[0] : (off == 1 ? X.agg[1] : X.agg[2]);
+    const double a1 = off == 0 ? X.agg[3] : (off == 1 ? X.agg[4] : X.agg[5]);
+    const double a2 = off == 0 ? X.agg[6] : (off == 1 ? X.agg[7] : X.agg[8]);
+    return sel == 0 ? a0 : (sel == 1 ? a1 : a2);
+}
+// the bookkeeping itself, on copies of the scalars and of the step context
+RH_DEV int64_t scalars_update(rh_scalars &S, StepCtx &X, unsigned long long w, int do_finish, int apply_sel, bool per_cell, int64_t ee) {
     X.apply_sel = apply_sel;
     const bool ev_start = bit(w, PC_RAIN) || bit(w, PC_SNOWMELT);
     const bool ev_end = !bit(w, PC_PREC_NOT_LE0) || !bit(w, PC_NOT_PGT0_TALE) || (bit(w, PC_SWEM1_GT0) && !bit(w, PC_SWE_NOT_LE0));
     int64_t dts = X.dt_secs_prelim;
     if (ev_start) S.time_event0 = 0;
     if (ev_end) S.time_event0 = S.time_event0 + dts;
-    const int64_t te0 = S.time_event0, tm = S.time, ee = D->K.end_event;
+    const int64_t te0 = S.time_event0, tm = S.time;
     const bool c6 = (te0 <= ee) && (dts == 600), c7 = (te0 <= ee) && (dts == 3600), c8 = (te0 <= ee) && (dts == 86400);
     const bool c9 = (te0 > ee) && (tm % 3600 != 0) && (dts == 600);
     const bool c10 = (te0 > ee) && (tm % 3600 == 0) && ((dts == 600) || (dts == 3600));
@@ -591,16 +612,13 @@ RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int a
     S.itt_day = itd;
     if ((S.event_id[0] > 0) && (S.event_id[1] == 0)) S.event_id_counter += 1;
     X.sel_w = w_sel;
-    if (w_sel >= 0 && !D->per_cell) {
-        X.pet_sel_w = X.agg[3 * w_sel + 2];
-        X.ta_sel_w = X.agg[3 * w_sel + 1];
+    if (w_sel >= 0 && !per_cell) {
+        X.pet_sel_w = agg_pick(X, w_sel, 2);
+        X.ta_sel_w = agg_pick(X, w_sel, 1);
     }
     X.dt = dt;
     X.month_tau = S.month[1];
     infiltration_conds(S, X, w);
-    D->words[0] = 0;
-    D->words[1] = 0;
-    D->words[2] = 0;
     if (do_finish) {
         // roger.py:449-450 and the scalar half of after_timestep (svat.py:352-366).  Nothing below
         // this kernel reads these scalars during the step (k_step works from StepCtx), so they are
@@ -612,13 +630,28 @@ RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int a
         S.month[0] = S.month[1];
         S.doy[0] = S.doy[1];
     }
-    D->S = S;
-    D->X = X;
+    return dts;
+}
+RH_DEV void log_dt(DevState *D, int64_t dts) {
     if (D->dt_log) {
         const int k = D->dt_log_n;
         if (k < D->dt_log_cap) D->dt_log[k] = (int)dts;
         D->dt_log_n = k + 1;
     }
+}
+// one thread
+RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel) {
+    // one burst of loads, the bookkeeping in registers, one burst of stores: working on D->S / D->X in place costs a
+    // global-memory round trip per field for this single thread (the control kernel took 20 us that way)
+    rh_scalars S = D->S;
+    StepCtx X = D->X;
+    const int64_t dts = scalars_update(S, X, w, do_finish, apply_sel, D->per_cell != 0, D->K.end_event);
+    D->words[0] = 0;
+    D->words[1] = 0;
+    D->words[2] = 0;
+    D->S = S;
+    D->X = X;
+    log_dt(D, dts);
 }
 
 // ---- summary path (shared forcing): the whole control part of a step in ONE single-workgroup kernel ----------
@@ -677,38 +710,198 @@ RH_DEV unsigned long long summary_bits_sw(unsigned long long b, double swe, doub
 RH_DEV unsigned long long summary_bits(double swe, double swe_top, double prec, double ta, const Consts &K) {
     return summary_bits_sw(summary_bits_pt(prec, ta, K), swe, swe_top);
 }
-// from_word3 != 0: the summary was reduced (and exchanged between ranks) before, it sits in words[3]
-// src64 != null: the exchanged summary arrives as 64 int32 (0 / 1) and is folded here (k_words_compress folded in)
-__global__ __launch_bounds__(RH_BLOCK) void k_ctrl(DevState *D, int do_hooks, int from_word3, const int *src64) {
-    if (do_hooks) hooks_set_forcing(D);
-    __shared__ unsigned long long s_sum;
+// ---- the control part of a step by ONE wavefront (no workgroup barrier): k_ctrl, and the tail of the fused kernel ----------
+RH_DEV void wave_sync() {   // LDS written by some lanes of a wavefront, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+RH_DEV unsigned long long wave_or(unsigned long long b) {
+    for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
+    return b;
+}
+struct CtrlLds {
+    double f[3][RH_SLOTS_PER_DAY];   // prec, ta, pet of the day
+    double part[6][16];              // numpy's eight partial sums of both halves, six sums
+};
+// [Device-side hooks,] predicate word 0, forcing aggregates in numpy's order, dt and event bookkeeping -- what k_agg + k_select +
+// k_scalars do for the predicate-kernel generation -- on the copies S / X every lane holds (uniform); `cells` = OR of the
+// summary bits of all columns (of all ranks).  The caller stores S / X.  Shared forcing only (the summary path).
+RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks) {
+    const int lane = threadIdx.x & 63;
+    const double ta_fm = D->K.ta_fm;
+    const int64_t hpi_i = D->K.hpi, end_event = D->K.end_event;
+    Consts Kf;   // forcing_bits / derive_word1 read hpi and ta_fm only
+    Kf.hpi = hpi_i;
+    Kf.ta_fm = ta_fm;
+    bool fresh_day = false;
+    X.forc_exhausted = 0;
+    if (do_hooks) {   // hooks_set_forcing: benchmarks/SVAT_benchmark.py:105-110, 151-171
+        const bool midnight = (S.time % 86400 == 0);
+        const int64_t i0 = S.itt_forc;
+        const bool have = midnight && (i0 + RH_SLOTS_PER_DAY <= D->nitt_forc);
+        X.forc_exhausted = (midnight && !have) ? 1 : 0;
+        if (have) {
+            for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) {
+                const int v = k / RH_SLOTS_PER_DAY, j = k % RH_SLOTS_PER_DAY;
+                const double x = D->series[v][i0 + j];
+                L.f[v][j] = x;
+                D->forc[v][j] = x;
+            }
+            S.itt_day = 0;
+            S.year[1] = D->calendar[0][i0];
+            S.month[1] = D->calendar[1][i0];
+            S.doy[1] = D->calendar[2][i0];
+            S.itt_forc = i0 + RH_SLOTS_PER_DAY;
+            if (lane == 0) D->per_cell = D->weights[0] ? 1 : 0;
+            fresh_day = true;
+        }
+        if (lane == 0) D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
+    }
+    if (!fresh_day)
+        for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) L.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
+    wave_sync();
+    // word 0: the columns' bits 0..3 and the predicates of the day's series (adaptive_time_stepping.py:38-81)
+    unsigned long long fb = 0;
+    int cnt_d = 0, cnt_h = 0;
+    const int64_t itd = S.itt_day;
+    for (int k = lane; k < RH_SLOTS_PER_DAY; k += 64) fb |= forcing_bits(L.f[0][k], L.f[1][k], Kf);
+    for (int k0 = 0; k0 < RH_SLOTS_PER_DAY; k0 += 64) {   // nanmean's divisors
+        const int k = k0 + lane;
+        const bool ok = k < RH_SLOTS_PER_DAY && !isnan(L.f[1][k < RH_SLOTS_PER_DAY ? k : 0]);
+        cnt_d += __popcll(__ballot(ok));
+        cnt_h += __popcll(__ballot(ok && (k >= itd) && (k < itd + 6)));
+    }
+    const unsigned long long w = (cells & 0xFull) | wave_or(fb);
+    // numpy's partial sums (agg_body): six sums x 16 (half, lane-of-eight) pairs
+    for (int item = lane; item < 96; item += 64) {
+        const int sum_id = item >> 4, l16 = item & 15, half = l16 >> 3, j = l16 & 7;
+        const int var = sum_id % 3;          // 0 prec, 1 ta, 2 pet
+        const bool hourly = sum_id >= 3;     // sums 0..2 daily, 3..5 hourly window
+        double r = 0.0;
+        for (int q = 0; q < 9; ++q) {
+            const int k = half * 72 + j + 8 * q;
+            double v = L.f[var][k];
+            const bool in = !hourly || ((k >= itd) && (k < itd + 6));
+            if (var == 1) v = (in && !isnan(v)) ? v : 0.0;  // nanmean: NaN (and masked) slots count as 0
+            else v = in ? v : 0.0;
+            r = (q == 0) ? v : r + v;
+        }
+        L.part[sum_id][l16] = r;
+    }
+    wave_sync();
+    {   // uniform from here on (every lane computes the same)
+        const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
+        const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
+        const bool any_pgt0_tale = bit(w, PB_PGT0_TALE), all_ple0_tale = !bit(w, PB_NOT_PLE0_TALE);
+        const bool all_swe_le0 = !bit(w, PB_SWE_NOT_LE0), all_swetop_le0 = !bit(w, PB_SWETOP_NOT_LE0);
+        const bool snow_any = (bit(w, PB_SWE_GT0) || bit(w, PB_SWETOP_GT0)) && any_ta_gt;
+        const bool cond0 = all_p_le0 && all_swe_le0 && all_swetop_le0 && all_ta_gt;
+        const bool cond00 = any_pgt0_tale || all_ple0_tale;
+        const bool cond1 = any_p_gthpi && any_p_gt0 && any_ta_gt;
+        const bool cond2 = all_p_lehpi && any_p_gt0 && any_ta_gt;
+        const bool cond3 = any_p_gthpi && any_p_gt0 && snow_any;
+        const bool cond4 = all_p_lehpi && any_p_gt0 && snow_any;
+        const bool cond5 = all_p_le0 && snow_any;
+        X.cond_time = (S.time % 86400 == 0);
+        X.sel_daily = cond0 || cond00;
+        X.sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
+        X.sel_10min = (cond1 || cond3) && !cond2 && !cond4 && !cond5;
+        int64_t dts = X.cond_time ? 86400 : 3600;   // :143-144 (the second assignment overwrites the first), :166, :190
+        if (X.sel_hourly) dts = 3600;
+        if (X.sel_10min) dts = 600;
+        X.dt_secs_prelim = dts;
+        X.itt_day = itd;
+        X.sel_p = X.sel_10min ? 2 : (X.sel_hourly ? 1 : (X.sel_daily ? 0 : -1));
+#define RH_SUM6(q) (0.0 + (np_tree8(&L.part[q][0]) + np_tree8(&L.part[q][8])))
+        X.agg[0] = RH_SUM6(0);
+        X.agg[1] = RH_SUM6(1) / (double)cnt_d;
+        X.agg[2] = RH_SUM6(2);
+        X.agg[3] = RH_SUM6(3);
+        X.agg[4] = RH_SUM6(4) / (double)cnt_h;
+        X.agg[5] = RH_SUM6(5);
+#undef RH_SUM6
+        int64_t k = itd < 0 ? itd + RH_SLOTS_PER_DAY : itd;
+        k = k > RH_SLOTS_PER_DAY - 1 ? RH_SLOTS_PER_DAY - 1 : k;
+        X.agg[6] = L.f[0][k];
+        X.agg[7] = L.f[1][k];
+        X.agg[8] = L.f[2][k];
+        if (X.sel_p >= 0) {
+            X.prec_sel = agg_pick(X, X.sel_p, 0);
+            X.ta_sel = agg_pick(X, X.sel_p, 1);
+        }
+    }
+    const int64_t dts = scalars_update(S, X, derive_word1(cells, X, Kf), 1, 1, false, end_event);
+    if (lane == 0) {
+        D->words[0] = 0;
+        D->words[1] = 0;
+        D->words[2] = 0;
+        log_dt(D, dts);
+    }
+}
+RH_DEV unsigned long long dev_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RH_DEV void dev_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The control kernel of a step that does not find S_next / X_next ready (first step, after the host touched planes or
+// scalars, multi-GPU after the exchange): one wavefront.  src: where the columns' summary word is (RH_SRC_*); src64 != null:
+// it arrives as 64 int32 (0 / 1) from the exchange between the ranks and is folded here.
+__global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src, const int *src64) {
+    __shared__ CtrlLds L;
+    const int lane = threadIdx.x & 63;
     unsigned long long cells;
     if (src64) {
-        if (threadIdx.x < 64) {
-            unsigned long long b = src64[threadIdx.x] ? (1ull << threadIdx.x) : 0ull;
-            for (int off = 32; off; off >>= 1) b |= __shfl_xor(b, off);
-            if (threadIdx.x == 0) D->words[3] = b;
-        }
-        __threadfence();
-        __syncthreads();
-    }
-    if (from_word3) {
-        if (threadIdx.x == 0) D->bflags[0][0] = D->words[3];
-        __threadfence();
-        __syncthreads();
-        cells = finish_word0(D, D->bflags[0], 1, 0xFull);
+        cells = wave_or(src64[lane] ? (1ull << lane) : 0ull);
+    } else if (src == RH_SRC_SUMW) {
+        cells = wave_or(dev_load(&D->sumw[lane]));
+        dev_store(&D->sumw[lane], 0ull);
     } else {
-        cells = finish_word0(D, D->sflags, D->sflag_blocks, 0xFull);
+        cells = D->words[3];
     }
-    if (threadIdx.x == 0) s_sum = cells;
-    __syncthreads();
-    agg_body(D);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) scalars_body(D, derive_word1(s_sum, D->X, D->K), 1, 1);
+    rh_scalars S = D->S;
+    StepCtx X = D->X;
+    ctrl_wave(D, L, S, X, cells, do_hooks);
+    if (lane == 0) {
+        D->words[3] = cells;
+        D->sanity_last = 0;
+        D->S = S;
+        D->X = X;
+        if (X.forc_exhausted) D->err_flags |= RH_DEVERR_FORCING;
+    }
 }
-// summary words straight from the arena (first step, or after the host changed planes); same workgroup -> column
-// mapping as the fused kernel
+// The tail of the fused kernel, run by the wavefront that finishes last: folds the summary words into words[3] (and, for the
+// exchange between ranks, spreads them over 64 int32), latches the sanity word, commits S_next / X_next if the step ran on them,
+// and forms the next step's S_next / X_next (the control part of the next step: no control kernel between two fused kernels).
+RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long cells = wave_or(dev_load(&D->sumw[lane]));
+    dev_store(&D->sumw[lane], 0ull);
+    const unsigned long long bad = dev_load(&D->words[2]);
+    rh_scalars S;
+    StepCtx X;
+    if (flags & RH_TAIL_USE_NEXT) {
+        S = D->S_next;
+        X = D->X_next;
+    } else {
+        S = D->S;
+        X = D->X;
+    }
+    if (lane == 0) {
+        D->words[3] = cells;
+        D->sanity_last = bad;
+        if (flags & RH_TAIL_USE_NEXT) {
+            D->S = S;
+            D->X = X;
+            if (X.forc_exhausted) D->err_flags |= RH_DEVERR_FORCING;
+        }
+    }
+    if (dst64) dst64[lane] = (int)((cells >> lane) & 1ull);
+    if (!(flags & RH_TAIL_CTRL)) return;
+    ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0);
+    if (lane == 0) {
+        D->S_next = S;
+        D->X_next = X;
+    }
+}
+// summary bits straight from the arena (first step, or after the host changed planes), OR-ed into sumw (zeroed by the host)
 __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     unsigned long long b = 0;
@@ -720,7 +913,8 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
         rh_ld(a, RH_P_ta, i, ta);
         b = summary_bits(swe, swe_top, prec, ta, D->K);
     }
-    wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], b);
+    b = wave_or(b);
+    if ((threadIdx.x & 63) == 0 && b) __hip_atomic_fetch_or(&D->sumw[blockIdx.x & 63], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Output accumulators: after a step that covered (t0, t1], day = t0 / 86400, slot = day mod diag_slots; the first
 // step of a day (t0 on midnight) overwrites.  Rate planes add this step's value (Rate.diagnose, roger/diagnostics/
@@ -749,11 +943,19 @@ __global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
 }
 // multi-GPU: OR of the summary words into words[3] for the exchange
 // dst64 != null: also spread over 64 int32 (0 / 1) for the MAX all-reduce (k_words_expand folded in)
-__global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks, int *dst64) {
+__global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do_hooks, int *dst64, int src) {
     if (do_hooks) hooks_set_forcing(D);
-    const unsigned long long w = reduce_bflags(D->sflags, D->sflag_blocks);
-    if (threadIdx.x == 0) D->words[3] = w;
-    if (dst64 && threadIdx.x < 64) dst64[threadIdx.x] = (int)((w >> threadIdx.x) & 1ull);
+    if (threadIdx.x < 64) {
+        unsigned long long w;
+        if (src == RH_SRC_SUMW) {
+            w = wave_or(dev_load(&D->sumw[threadIdx.x]));
+            dev_store(&D->sumw[threadIdx.x], 0ull);
+        } else {
+            w = D->words[3];
+        }
+        if (threadIdx.x == 0) D->words[3] = w;
+        if (dst64) dst64[threadIdx.x] = (int)((w >> threadIdx.x) & 1ull);
+    }
 }
 
 __global__ void k_advance(DevState *D) {  // roger.py:449-450
@@ -826,7 +1028,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)                                   \
     RH_LOADS(seq, rt_inf_events)                                                                         \
     rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
-    q = summary_bits_sw(q, c.swe, c.swe_top);                                                            \
+    q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
     RH_LOADS(seq, rt_inf_matrix)                                                                         \
     rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
     RH_LOADS(seq, rt_inf_macropores)                                                                     \
@@ -868,7 +1070,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     RH_STAGE(seq, rt_interception, rt_interception(c, K))                                                \
     RH_STAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                    \
     RH_STAGE(seq, rt_snow, rt_snow(c, K, X))                                                             \
-    RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top);)                                                \
+    RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);)                       \
     RH_STAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                 \
     RH_STAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                 \
     RH_STAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                         \
@@ -881,12 +1083,26 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     RH_STAGE(seq, at_rt, at_call)
 #endif
 
+// A wavefront's summary bits into the device-wide words, as soon as they are final (right after the snow stage: the latency of
+// the returning atomic hides behind the infiltration stages).  `dep` carries the returned value to the completion count at the end
+// of the kernel, so that the wave is counted as done only after its bits have arrived.
+RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
+    // (by ballots, not lane exchanges: the last wavefront of the grid may run with its upper lanes switched off)
+    unsigned long long qq = 0;
+#pragma unroll
+    for (int b = 0; b <= QB_P_NE0; ++b) qq |= __ballot((q >> b) & 1ull) ? (1ull << b) : 0ull;
+    if ((threadIdx.x & 63) == 0 && qq) {
+        const unsigned long long old = __hip_atomic_fetch_or(&D->sumw[blockIdx.x & 63], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dep |= (unsigned)(old >> 63);   // (bit 63 is never set: dep stays as it is, but depends on the atomic's return)
+    }
+}
+
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
 template <bool MONTHLY, bool LATERAL, bool LAZY>
-RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long long &q, bool &bad) {
+RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep) {
     {
     const Consts K = D->K;
-    const StepCtx X = D->X;
+    const StepCtx X = *Xp;
     Col c;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     if (D->per_cell && X.sel_w >= 0) {
@@ -914,8 +1130,10 @@ RH_DEV void step_column(const Arena &a, DevState *D, int64_t i, unsigned long lo
 
 // MODE: 0 = the plain step, 1 = with the monthly surface parameters (calc_parameters_surface_kernel first), 2 = decided
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
+// flags: RH_TAIL_*; grp_shift: 2^grp_shift workgroups per completion group; dst64: the summary word for the exchange between
+// ranks, written by the tail (or null)
 template <int MODE, bool LATERAL, bool LAZY>
-__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D) {
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int flags, int grp_shift, int *dst64) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
     // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
     // the arena instead of every XCD touching every page.  Never slower; on one box 6 - 11 % faster at 10^7 columns (21 GB
@@ -928,14 +1146,40 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #else
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
 #endif
+    __shared__ unsigned wg_done;      // wavefronts of this workgroup that are through
+    __shared__ CtrlLds tail_lds;      // scratch of the tail (one wavefront of the whole grid uses it)
+    if (threadIdx.x == 0) wg_done = 0;
+    __syncthreads();                  // (at the start, where all waves are in step; the kernel has no closing barrier)
     unsigned long long q = 0;
     bool bad = false;
+    unsigned dep = 1;
+    const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
     if (i < a.n) {
-        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY>(a, D, i, q, bad);
-        else step_column<false, LATERAL, LAZY>(a, D, i, q, bad);
+        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY>(a, D, Xp, i, q, bad, dep);
+        else step_column<false, LATERAL, LAZY>(a, D, Xp, i, q, bad, dep);
+    } else {
+        post_summary(D, 0ull, dep);
     }
-    if (bad) atomicOr(&D->words[2], 1ull);
-    wave_or_store(&D->sflags[(size_t)blockIdx.x * (RH_BLOCK / 64)], q);
+    const bool any_bad = __any(bad);
+    // Completion, without a barrier and without fences (a release fence at device scope writes the XCD's L2 back): everything the
+    // tail reads from other waves went through device-scope atomics that have RETURNED before the wave counts itself done.
+    bool last = false;
+    if ((threadIdx.x & 63) == 0) {
+        if (any_bad) dep |= (unsigned)(__hip_atomic_fetch_or(&D->words[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
+        const unsigned o = atomicAdd(&wg_done, dep);   // LDS; dep == 1
+        if (o == (RH_BLOCK / 64) - 1) {                // the last wave of the workgroup reports the workgroup
+            const unsigned nblk = gridDim.x, g = blockIdx.x >> grp_shift, ng = ((nblk - 1) >> grp_shift) + 1;
+            const unsigned cnt = (g == ng - 1) ? nblk - (g << grp_shift) : (1u << grp_shift);
+            if (__hip_atomic_fetch_add(&D->done_grp[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1) {
+                __hip_atomic_store(&D->done_grp[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {
+                    __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = true;
+                }
+            }
+        }
+    }
+    if (__shfl((int)last, 0)) step_tail(D, tail_lds, flags, dst64);
 }
 
 #define RH_CELL_KERNEL(kname, rt, call)                                       \
@@ -1119,6 +1363,7 @@ static void planes_touched(rh_ctx *ctx) {
     materialise_m1(ctx);
     ctx->rot_consistent = false;
     ctx->summary_valid = false;
+    ctx->pending_valid = false;
 }
 #define LAUNCH_CELLS(ctx, kern)                                                                                          \
     do {                                                                                                                 \
@@ -1160,7 +1405,7 @@ void rh_default_config(rh_config *cfg) {
     cfg->hpi = 5;
     cfg->dx = 1;
     cfg->enable_lateral_flow = 0;
-    cfg->placement_probes = 8;
+    cfg->placement_probes = 1;   // placement probing is opt-in (rh_config.placement_probes or RH_PLACEMENT_PROBES)
 }
 
 const char *rh_last_error(const rh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -1208,7 +1453,6 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->agg_cell_buf = nullptr;
     ctx->series_buf = nullptr;
     ctx->mlms_buf = nullptr;
-    ctx->sflags_buf = nullptr;
     ctx->diag_buf = nullptr;
     ctx->diag_steps_buf = nullptr;
     ctx->diag_interval = 86400;
@@ -1248,9 +1492,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (probes > 1 && (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)) probes = 1;
         for (int k = 0; k < probes; ++k) {
-            if (k > 0) {   // never take more than a third of what is still free
+            if (k > 0) {   // all candidates are held until the choice is made: never more than a quarter of the free memory in total
                 size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 3 < arena_bytes + ctx->arena_offset) break;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+                    (free_b + k * (arena_bytes + ctx->arena_offset)) / 4 < (k + 1) * (arena_bytes + ctx->arena_offset)) break;
             }
             char *p = nullptr;
             if ((e = hipMalloc((void **)&p, arena_bytes + ctx->arena_offset)) != hipSuccess) {
@@ -1321,14 +1566,11 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     if ((e = hipMemcpyAsync(&ctx->dev->S, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(scalars)");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // K, S are stack locals
-    {
-        const int nb = (int)grid_for(ctx->n) * (RH_BLOCK / 64);
-        if ((e = hipMalloc((void **)&ctx->sflags_buf, (size_t)nb * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(sflags)");
-        if ((e = hipMemsetAsync(ctx->sflags_buf, 0, (size_t)nb * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
-        if ((e = hipMemcpyAsync(&ctx->dev->sflags, &ctx->sflags_buf, sizeof(void *), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return bail(e, "hipMemcpy(sflags)");
-        if ((e = hipMemcpyAsync(&ctx->dev->sflag_blocks, &nb, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return bail(e, "hipMemcpy(sflag_blocks)");
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // nb is a stack local
-    }
+    ctx->pending_valid = false;
+    ctx->pending_hooks = 0;
+    ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
+    ctx->grp_shift = 6;
+    while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
     ctx->summary_valid = false;
     ctx->pred_blocks = (int)(grid_for(ctx->n) < RH_PRED_BLOCKS ? grid_for(ctx->n) : RH_PRED_BLOCKS);
     if ((e = hipMemcpyAsync(&ctx->dev->pred_blocks, &ctx->pred_blocks, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
@@ -1354,7 +1596,6 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->agg_cell_buf) (void)hipFree(ctx->agg_cell_buf);
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
     if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
-    if (ctx->sflags_buf) (void)hipFree(ctx->sflags_buf);
     if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
     if (ctx->diag_steps_buf) (void)hipFree(ctx->diag_steps_buf);
     if (ctx->arena_alloc) (void)hipFree(ctx->arena_alloc);
@@ -1373,10 +1614,19 @@ int rh_set_stream(rh_ctx *ctx, void *hip_stream) {
     return RH_OK;
 }
 
+static int device_error(rh_ctx *ctx, unsigned err) {
+    if (err & RH_DEVERR_FORCING)
+        return fail(ctx, RH_ERR_STATE, "a step began a day beyond the end of the resident forcing series (rh_set_forcing_series): it ran on the "
+                                       "previous day's forcing; hand over a longer series (the reference fails on the short slice, "
+                                       "benchmarks/SVAT_benchmark.py:151-171)");
+    return RH_OK;
+}
 int rh_sync(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
+    unsigned err = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&err, &ctx->dev->err_flags, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return RH_OK;
+    return device_error(ctx, err);
 }
 
 static int plane_bytes(rh_ctx *ctx, int plane, size_t bytes, size_t *elem) {
@@ -1433,6 +1683,8 @@ void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
 
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
     if (!ctx || !s) return RH_ERR_ARG;
+    ctx->pending_valid = false;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->S, s, sizeof(*s), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     LAUNCH_ONE(ctx, k_sync_ctx, ctx->dev);
@@ -1442,12 +1694,16 @@ int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
 
 int rh_get_scalars(rh_ctx *ctx, rh_scalars *s) {
     if (!ctx || !s) return RH_ERR_ARG;
-    unsigned long long bad = 0;
+    unsigned long long bad = 0, bad_last = 0;
+    unsigned err = 0;
     HIPCHK(ctx, hipMemcpyAsync(s, &ctx->dev->S, sizeof(*s), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&bad, &ctx->dev->words[2], sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&bad_last, &ctx->dev->sanity_last, sizeof(bad_last), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&err, &ctx->dev->err_flags, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    s->sanity_ok = bad ? 0 : 1;  // word 2 collects the sanity violations of the last step
-    return RH_OK;
+    // word 2 collects the sanity violations of the last step; the fused kernel's tail moves it to sanity_last
+    s->sanity_ok = (bad | bad_last) ? 0 : 1;
+    return device_error(ctx, err);
 }
 
 int rh_set_luts(rh_ctx *ctx, const double *ilu, const double *gc, const double *gcm, const double *rdlu) {
@@ -1503,6 +1759,7 @@ int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day
         }
     }
     ctx->per_cell = pc != 0;
+    ctx->pending_valid = false;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->per_cell, &pc, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
@@ -1549,6 +1806,7 @@ int rh_infiltration(rh_ctx *ctx) {
 int rh_num_error(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->sanity_last, 0, sizeof(unsigned long long), ctx->stream));
     if (ctx->cfg.enable_lateral_flow)
         LAUNCH_CELLS(ctx, k_num_error_lateral);
     else
@@ -1590,13 +1848,15 @@ int rh_after_timestep(rh_ctx *ctx) {
         hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
     } while (0)
 
-static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
+static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst64 = nullptr) {
     // Timing: the event pair rides on the kernel's own dispatch (hipExtLaunchKernelGGL: start / stop are taken from the
     // dispatch's completion signal) instead of two hipEventRecord packets around it, which cost 5 us per step at 10^6
     // columns.  -DRH_EVENT_RECORD: the hipEventRecord pair.
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
-        while (ctx->events.size() < ctx->ev_used + 2) {
+        if (ctx->ev_used + 2 > 2 * (size_t)RH_DT_LOG_CAP)
+            return fail(ctx, RH_ERR_STATE, "timing: more than 65536 timed steps since rh_enable_timing(1); read the timings and enable again");
+        while (ctx->events.size() < ctx->ev_used + 2) {   // the pool is reused by the next rh_enable_timing(1), never beyond the cap
             hipEvent_t ev;
             HIPCHK(ctx, hipEventCreate(&ev));
             ctx->events.push_back(ev);
@@ -1610,9 +1870,9 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
     const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
     const bool lat = ctx->cfg.enable_lateral_flow != 0;
 #ifdef RH_EVENT_RECORD
-#define RH_LAUNCH_K(K) hipLaunchKernelGGL(K, grid, block, 0, ctx->stream, ctx->arena, ctx->dev)
+#define RH_LAUNCH_K(K) hipLaunchKernelGGL(K, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, flags, ctx->grp_shift, dst64)
 #else
-#define RH_LAUNCH_K(K) hipExtLaunchKernelGGL(K, grid, block, 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev)
+#define RH_LAUNCH_K(K) hipExtLaunchKernelGGL(K, grid, block, 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev, flags, ctx->grp_shift, dst64)
 #endif
     // lazy rotation: the planes were last touched by a complete fused step (X_m1 == X) and nobody who reads X_m1 planes
     // follows inside this call (the accumulator kernel may, if it was given an X_m1 plane)
@@ -1635,14 +1895,20 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly) {
     ctx->m1_stale = lazy;
 #undef RH_LAUNCH_STEP
 #undef RH_LAUNCH_K
+    CHECK_LAUNCH(ctx);
     if (ctx->timing) {
 #ifdef RH_EVENT_RECORD
         HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
 #endif
         ctx->ev_used += 2;
     }
-    ctx->summary_valid = true;  // the fused kernel leaves the summary words of the state it wrote
-    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev);
+    ctx->summary_valid = true;  // the fused kernel's tail leaves the summary word of the state it wrote (words[3])
+    ctx->pending_valid = (flags & RH_TAIL_CTRL) != 0;
+    ctx->pending_hooks = (flags & RH_TAIL_HOOKS) != 0;
+    if (ctx->diag_n) {
+        hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev);
+        CHECK_LAUNCH(ctx);
+    }
     return RH_OK;
 }
 
@@ -1683,12 +1949,20 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
     if (!ctx->per_cell) {
         // summary path: the previous fused kernel left what the predicates need; one control kernel, one fused kernel
-        if (!ctx->summary_valid) LAUNCH_CELLS(ctx, k_summary);
-        LAUNCH_WG(ctx, k_ctrl, ctx->dev, hooks, 0, (const int *)nullptr);
-        int rc = launch_fused_kernel(ctx, monthly);
-        if (rc) return rc;
-        CHECK_LAUNCH(ctx);
-        return RH_OK;
+        // ... unless the previous fused kernel's tail has formed this step's control part already (S_next / X_next)
+        const bool use_next = ctx->pending_valid && ctx->pending_hooks == (hooks != 0);
+        if (!use_next) {
+            int src = RH_SRC_WORD3;
+            if (!ctx->summary_valid) {
+                HIPCHK(ctx, hipMemsetAsync(ctx->dev->sumw, 0, sizeof(ctx->dev->sumw), ctx->stream));
+                LAUNCH_CELLS(ctx, k_summary);
+                src = RH_SRC_SUMW;
+            }
+            LAUNCH_ONE(ctx, k_ctrl, ctx->dev, hooks, src, (const int *)nullptr);
+            CHECK_LAUNCH(ctx);
+        }
+        const int flags = (use_next ? RH_TAIL_USE_NEXT : 0) | (ctx->tail_ok ? RH_TAIL_CTRL | (hooks ? RH_TAIL_HOOKS : 0) : 0);
+        return launch_fused_kernel(ctx, monthly, flags);
     }
     if (hooks) {  // per-cell forcing from the resident series: the hooks must have formed it before k_pred1 reads it
         launch_hooks(ctx);
@@ -1713,18 +1987,22 @@ static int step_summary(rh_ctx *ctx, int32_t *dev_dst64) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
     if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_summary: the summary path needs forcing shared by all columns; use rh_step_phase1/2/3");
+    int src = RH_SRC_WORD3;
     if (!ctx->summary_valid) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->dev->sumw, 0, sizeof(ctx->dev->sumw), ctx->stream));
         LAUNCH_CELLS(ctx, k_summary);
         ctx->summary_valid = true;
+        src = RH_SRC_SUMW;
     }
-    LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0, (int *)dev_dst64);
+    ctx->pending_valid = false;   // the ranks decide together: the control kernel follows the exchange
+    LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0, (int *)dev_dst64, src);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
 static int step_finish(rh_ctx *ctx, int monthly, const int32_t *dev_src64) {
     if (!ctx) return RH_ERR_ARG;
     if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_step_finish: the summary path needs forcing shared by all columns");
-    LAUNCH_WG(ctx, k_ctrl, ctx->dev, 0, 1, (const int *)dev_src64);
+    LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 0, RH_SRC_WORD3, (const int *)dev_src64);
     int rc = launch_fused_kernel(ctx, monthly);
     if (rc) return rc;
     CHECK_LAUNCH(ctx);
@@ -1772,8 +2050,10 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->series, sp, sizeof(sp), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->calendar, cp, sizeof(cp), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->nitt_forc, &nitt_forc, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
+    ctx->pending_valid = false;
     ctx->per_cell = false;
     return RH_OK;
 }
@@ -1816,6 +2096,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->weights, dptr, sizeof(dptr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pending_valid = false;
     ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
     ctx->agg_daily_stale = true;
     ctx->pred_daily_stale = true;
@@ -1971,6 +2252,7 @@ int rh_enable_timing(rh_ctx *ctx, int on) {
     if (!ctx) return RH_ERR_ARG;
     ctx->timing = on != 0;
     ctx->ev_used = 0;
+    ctx->pending_valid = false;   // the step log restarts: the next step's entry must be written after this call
     if (on && !ctx->dt_log_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->dt_log_buf, sizeof(int) * RH_DT_LOG_CAP));
     int *log = on ? ctx->dt_log_buf : nullptr;
     const int cap = RH_DT_LOG_CAP, zero = 0;
@@ -1986,7 +2268,8 @@ int rh_timing_detail(rh_ctx *ctx, double *kernel_ms, int32_t *dt_secs, int64_t c
     int logged = 0;
     if (ctx->dt_log_buf) HIPCHK(ctx, hipMemcpy(&logged, &ctx->dev->dt_log_n, sizeof(int), hipMemcpyDeviceToHost));
     const int64_t n = (int64_t)(ctx->ev_used / 2);
-    if (logged != n || n > RH_DT_LOG_CAP)
+    // (the tail of the last timed kernel has logged the step after it already: one entry more than launches)
+    if ((logged != n && logged != n + 1) || n > RH_DT_LOG_CAP)
         return fail(ctx, RH_ERR_STATE, "rh_timing_detail: the step log does not match the timed launches (timing enabled mid-step, "
                                        "or more than 65536 steps)");
     *launches = n;

@@ -425,7 +425,10 @@ def test_placement_probing_keeps_the_fastest_candidate():
     from roger_amd.svat import create_svat
 
     forcing = combo_forcing(ndays=30)
-    ctx = create_svat(512, 512, device=0)
+    default = create_svat(512, 512, device=0)          # probing is opt-in
+    assert default.placement_report() == []
+    default.close()
+    ctx = create_svat(512, 512, device=0, placement_probes=8)
     rep = ctx.placement_report()
     assert 2 <= len(rep) <= 8 and rep[0] == min(rep) and min(rep) > 0
     ctx.set_forcing_series(forcing)
@@ -437,7 +440,7 @@ def test_placement_probing_keeps_the_fastest_candidate():
     small.close()
     os.environ["RH_PLACEMENT_PROBES"] = "1"
     try:
-        ctx = create_svat(512, 512, device=0)
+        ctx = create_svat(512, 512, device=0, placement_probes=8)   # the environment overrides the configuration
         assert ctx.placement_report() == []
         ctx.set_forcing_series(forcing)
         ctx.run_steps(40)
@@ -446,6 +449,77 @@ def test_placement_probing_keeps_the_fastest_candidate():
         ctx.close()
     finally:
         del os.environ["RH_PLACEMENT_PROBES"]
+
+
+def test_tail_control_equals_control_kernel(native):
+    """The control part of a step (hooks, predicates, forcing aggregates, dt and event bookkeeping) formed by the tail of the
+    previous fused kernel (last wavefront done; S_next / X_next) against the control kernel in front of every step
+    (RH_NO_TAIL_CTRL): the same scalars after every call and the same planes, with scalar reads, uploads, host-side scalar changes,
+    timing switches and host-driven steps in between."""
+    import os
+
+    import hip_util as H
+
+    g, names, forcing = load_case("svat_hetero_combo")
+
+    def run(tail):
+        if tail:
+            os.environ.pop("RH_NO_TAIL_CTRL", None)
+        else:
+            os.environ["RH_NO_TAIL_CTRL"] = "1"
+        try:
+            ctx = _ctx(native, g, names)
+        finally:
+            os.environ.pop("RH_NO_TAIL_CTRL", None)
+        ctx.set_forcing_series(forcing)
+        out = []
+        for n in (1, 1, 2, 35, 1, 60):
+            ctx.run_steps(n)
+            out.append(H.scalars_to_row(ctx.get_scalars()))
+        out.append(H.download_snapshot(ctx, names))
+        ctx.upload("S_dep", ctx.download("S_dep") * 0.5)           # planes touched: the pending control part is dropped
+        ctx.run_steps(20)
+        s = ctx.get_scalars()
+        ctx.set_scalars(s)                                         # scalars touched
+        ctx.run_steps(20)
+        ctx.enable_timing(True)
+        ctx.run_steps(7)
+        ms, dts = ctx.timing_detail()
+        ctx.enable_timing(False)
+        out.append(np.asarray(dts, dtype=np.float64))
+        drv = H.HipForcingDriver(ctx, forcing)                     # host-driven hooks after device-driven ones
+        for _ in range(30):
+            ctx.step(drv.before_step())
+        ctx.run_steps(25)
+        out.append(H.scalars_to_row(ctx.get_scalars()))
+        out.append(H.download_snapshot(ctx, names))
+        ctx.close()
+        return out
+
+    a, b = run(True), run(False)
+    for k, (x, y) in enumerate(zip(a, b)):
+        np.testing.assert_array_equal(x, y, err_msg=f"item {k}")
+
+
+def test_exhausted_forcing_series_is_reported(native):
+    """A step that begins a day beyond the end of the resident series would run on the previous day's forcing: reported as
+    RH_ERR_STATE by rh_get_scalars / rh_sync (the reference fails on the short slice); running exactly to the end is fine."""
+    import hip_util as H
+
+    g, names, forcing = load_case("svat_uniform_rain")
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_series(forcing)
+    ctx.run_steps(int(g["nsteps"]))
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][-1])   # no error: nothing ran beyond the series
+    ctx.sync()
+    ctx.run_steps(1)
+    with pytest.raises(native.NativeError, match="forcing series"):
+        ctx.get_scalars()
+    with pytest.raises(native.NativeError, match="forcing series"):
+        ctx.sync()
+    ctx.set_forcing_series(forcing)    # a new series clears the condition
+    ctx.sync()
+    ctx.close()
 
 
 def test_lazy_rotation_equals_eager(native):
