@@ -11,11 +11,24 @@ roger_amd.forcing.combo_forcing; the reference's forcing.nc is not shipped).  Al
 in HBM before the timed region.  For N > 1 every rank owns one nx*ny slab of a grid split along x
 (weak scaling); the only data-path communication is one 64-value predicate all-reduce per step.
 
-Prints one JSON line on rank 0 (see the bench contract).  The `roofline` entry prices the fused
-kernel `k_step` at 2779 algorithmic bytes per cell-step against the
-8 TB/s HBM peak, with the kernel duration measured by HIP events on the kernel's stream inside
-the timed region.  The `cpu_baseline` entry times the oracle (a scalar C port of the reference's
-NumPy step, 1 thread) on a bounded sample of the same workload.
+Prints one JSON line on rank 0 (see the bench contract).  The `roofline` entry prices the fused kernel `k_step`
+against the 8 TB/s HBM peak, with the kernel duration measured by HIP events on the kernel's stream inside the timed
+region:
+
+  * `achieved` / `frac`: the bytes one launch must move -- per column what the kernel variant that ran loads and stores
+    (every plane the step needs read once, every plane it assigns written once; counted from the kernel's gfx950 ISA by
+    tools/isa_census.py into roger_amd/csrc/rh_step_bytes.json) x the launch's columns -- over the average kernel
+    duration.  Physical: always <= 1.
+  * `traffic`: the HBM bytes per launch measured with the PMC counters FETCH_SIZE / WRITE_SIZE (separate passes,
+    calibrated on a copy of known size with the same access shape; tools/make_profiles.sh -> profiles/traffic.json) for
+    this kernel variant at this column count, or null if that combination was not profiled.
+  * `reference_equivalent`: the same kernel time against SURVEY.md section 8(d)'s 2 779 B per cell-step -- the distinct
+    variables the REFERENCE's step reads and assigns.  The fused kernel keeps the intermediates in registers and defers
+    the tau -> taum1 copies, so it moves fewer bytes than that; this figure can exceed the peak and is not a roofline
+    fraction.
+
+The `cpu_baseline` entry times the oracle (a C port of the reference's NumPy step, OpenMP over the columns) on a bounded
+sample of the same workload.
 """
 import argparse
 import json
@@ -26,8 +39,41 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-ALGO_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md section 8(d)
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+REFERENCE_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md section 8(d): the reference's read / write sets (SVAT)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def kernel_bytes_per_cell(model, lazy):
+    """(load, store) bytes one column moves per fused step: roger_amd/csrc/rh_step_bytes.json (tools/isa_census.py)."""
+    rec = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))
+    r = rec[f"{'oned' if model == 'oned' else 'svat'}_{'lazy' if lazy else 'eager'}"]
+    return r["load_bytes"], r["store_bytes"]
+
+
+def measured_traffic(key, n_cells):
+    """HBM bytes per launch from profiles/traffic.json (PMC passes of tools/make_profiles.sh) for this kernel variant, only if it
+    was profiled at this column count.  Returns (bytes per launch or None, the record or None)."""
+    tf = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(tf)).get(key, {}).get(str(n_cells))
+    except Exception:   # noqa: BLE001
+        rec = None
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], rec
+
+
+def device_clocks():
+    """Clock levels rocm-smi reports (a child process; nothing here touches the GPU): the fused kernel's speed follows the
+    memory-side clocks of the moment."""
+    import re
+    import subprocess
+
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=15).stdout
+        return {k: int(v) for k, v in re.findall(r"GPU\[0\]\s*:\s*(\w+) clock level: \d+: \((\d+)Mhz\)", out)}
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def host_threads():
@@ -142,15 +188,28 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = algo * n / k_avg_s / 1e9
         pows = 5 * args.substeps * (args.ages + 1)
-        traffic, traffic_note = None, ""
-        tf = os.path.join(REPO, "profiles", "traffic_sas.json")
-        if os.path.exists(tf) and args.ages == 1000:
-            try:
-                rec = json.load(open(tf))
-                traffic = rec["bytes_per_cell"] * n   # same kernel, one workgroup per column: linear in the column count
-                traffic_note = f"; traffic = PMC bytes per column measured at {rec['n_cells']} columns x this launch's columns"
-            except Exception:
-                traffic = None
+        traffic, trec = measured_traffic(f"k_sas_ages{args.ages}_sub{args.substeps}", n)
+        traffic_note = f"; traffic = PMC FETCH_SIZE / WRITE_SIZE of this kernel at this column count ({trec['source']})" if trec else ""
+        # compute side ("state the compute bound for SAS explicitly"): the kernel is bound by fp64 VALU ISSUE.  Per column-day it
+        # issues `valu_wave_insts` wave-instructions (PMC SQ_INSTS_VALU / columns, profiles/sas_valu.json); an fp64 wave64 instruction
+        # occupies its SIMD for 4 cycles (MI355X_MICROARCH.md: 64 lanes over 16-wide fp64 VALUs), the chip has 256 CUs x 4 SIMDs.
+        compute = None
+        try:
+            vrec = json.load(open(os.path.join(REPO, "profiles", "sas_valu.json")))[f"ages{args.ages}_sub{args.substeps}"]
+            cyc = vrec["valu_wave_insts_per_column"] * n * 4.0 / 1024.0
+            clock_hz = vrec.get("clock_mhz", 2400) * 1e6
+            compute = {
+                "bound": "fp64 VALU issue",
+                "valu_wave_insts_per_column_day": vrec["valu_wave_insts_per_column"],
+                "cycles_per_wave_inst": 4,
+                "simds": 1024,
+                "clock_mhz": vrec.get("clock_mhz", 2400),
+                "min_ms_at_full_issue": cyc / clock_hz * 1e3,
+                "frac": (cyc / clock_hz) / k_avg_s,
+                "source": vrec.get("source"),
+            }
+        except Exception:   # noqa: BLE001
+            compute = None
         out = {
             "metric": "cell-timesteps/sec on SVATOXYGEN18_benchmark grid",
             "value": world * n * args.steps / elapsed,
@@ -185,6 +244,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
                 "algorithmic_bytes_per_launch": algo * n,
                 "avg_kernel_ms": k_avg_s * 1e3,
                 "launches_timed": launches,
+                "compute": compute,
             },
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
@@ -277,8 +337,17 @@ def main():
         ctx.set_forcing_weights(rng.uniform(0.8, 1.2, n_local), rng.uniform(-1.5, 1.5, n_local), rng.uniform(0.9, 1.1, n_local))
     if args.station_weights and world > 1:
         raise SystemExit("--station-weights: the three-phase exchange of per-cell forcing is not wired into bench.py (single GPU only)")
-    if world > 1 or os.environ.get("RH_BENCH_FORCE_PHASED"):   # the env switch rehearses the multi-GPU orchestration on one GPU
+    stepping = "rh_run_steps"
+    if (world > 1 and not rehearsal) or os.environ.get("RH_BENCH_FORCE_DIST"):
+        # multi-GPU: per step ncclAllReduce (64 x int32) -> control kernel -> fused kernel, enqueued from C (rh_run_steps_dist);
+        # RH_BENCH_FORCE_DIST=1 rehearses it on one GPU with a one-rank communicator
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        ctx.comm_init_torch()
+        run = ctx.run_steps_dist
+        stepping = "rh_run_steps_dist (RCCL from C)"
+    elif world > 1 or os.environ.get("RH_BENCH_FORCE_PHASED"):   # rehearsals: the Python orchestration (gloo between CPU-side ranks)
         run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run   # one summary all-reduce per step
+        stepping = "PhasedStepper (torch.distributed)"
     else:
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
         run = ctx.run_steps                               # single GPU: no exchange, fewer launches
@@ -291,6 +360,7 @@ def main():
 
     run(args.warmup)
     s0 = ctx.get_scalars()
+    clocks0 = device_clocks() if rank == 0 else None
     ctx.enable_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -311,16 +381,13 @@ def main():
     if rank == 0:
         value = world * n_local * args.steps / elapsed
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = ALGO_BYTES_PER_CELL_STEP * n_local / k_avg_s / 1e9
-        traffic = None
-        tf = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                rec = json.load(open(tf))
-                if args.model == "svat":   # measured on the SVAT kernel; one thread per column: linear in the column count
-                    traffic = rec["bytes_per_cell"] * n_local
-            except Exception:
-                traffic = None
+        lazy, tail = ctx.step_mode()
+        ld_b, st_b = kernel_bytes_per_cell(args.model, lazy)
+        algo = (ld_b + st_b) * n_local
+        achieved = algo / k_avg_s / 1e9
+        variant = f"k_step_{'oned' if args.model == 'oned' else 'svat'}_{'lazy' if lazy else 'eager'}"
+        traffic, trec = measured_traffic(variant, n_local)
+        ref_achieved = REFERENCE_BYTES_PER_CELL_STEP * n_local / k_avg_s / 1e9
         out = {
             "metric": "cell-timesteps/sec on SVAT_benchmark grid",
             "value": value,
@@ -340,6 +407,7 @@ def main():
                 "cells_per_gpu": n_local,
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, " + ("one 256-byte predicate all-reduce per step" if world > 1 else "single GPU: no exchange"),
+                "stepping": stepping,
                 # per time-step class (kernel time only, rank 0); `value` is the aggregate over the run
                 "dt_classes": {
                     name: {"steps": int((per_dt == secs).sum()),
@@ -350,24 +418,29 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_step",
-                "note": "2779 B/cell-step is SURVEY 8(d)'s SVAT figure; the oneD step adds the lateral-flow fields"
-                        if args.model == "oned" else "algorithmic bytes per SURVEY 8(d) (the reference's read + write sets); traffic = PMC "
-                        "bytes per column (profiles/traffic.json, measured at 10^6 columns) x this launch's columns: the fused kernel "
-                        "keeps intermediates in registers and skips the tau->taum1 copies while it alone touches the state, so it "
-                        "moves less than the algorithmic bytes and frac can exceed 1; traffic_frac is the HBM peak really in use",
+                "kernel": variant + (", control part of the next step in its tail" if tail else ""),
+                "note": "achieved = bytes the launch must move (per column the planes this kernel variant loads + stores once: "
+                        f"{ld_b} + {st_b} B, roger_amd/csrc/rh_step_bytes.json from the ISA) / average kernel duration by HIP events; "
+                        "traffic = HBM bytes per launch by PMC (profiles/traffic.json) if this variant was profiled at this size; "
+                        "reference_equivalent = the same time against the 2779 B per cell-step of the reference's read + write sets "
+                        "(SURVEY 8d; for oneD the reference moves more) -- not a fraction of the peak, the kernel moves fewer bytes",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                # the same kernel time against the bytes the kernel really moves (PMC): the fraction of the HBM peak in use
                 "traffic_achieved": (traffic / k_avg_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / k_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_STEP * n_local,
+                "traffic_source": trec["source"] if trec else None,
+                "algorithmic_bytes_per_launch": algo,
+                "algorithmic_bytes_per_cell": {"load": ld_b, "store": st_b},
+                "reference_equivalent": {"bytes_per_cell_step": REFERENCE_BYTES_PER_CELL_STEP, "achieved": ref_achieved,
+                                         "ratio_to_peak": ref_achieved / HBM_PEAK_GBS},
                 "avg_kernel_ms": k_avg_s * 1e3,
                 "launches_timed": launches,
+                "outside_kernel_us_per_step": (elapsed / args.steps - k_avg_s) * 1e6,
             },
+            "clocks_mhz": {"before": clocks0, "after": device_clocks()},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cpu_steps = min(args.steps + args.warmup, 60)

@@ -111,6 +111,13 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes);
  *     ptr + (i / 64) * (rh_num_planes() * 512) + (i % 64) * sizeof(element). */
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane);
 
+/* How the last fused step ran (measurement, tests): RH_STEP_MODE_LAZY = it deferred the tau -> taum1 copies of after_timestep
+ * (models/svat/svat.py:187-384; materialised on demand), RH_STEP_MODE_TAIL = its last wavefront formed the control part of the next
+ * step (adaptive_time_stepping.py:22-381 for the step to come), so that no control kernel runs in between. */
+#define RH_STEP_MODE_LAZY 1
+#define RH_STEP_MODE_TAIL 2
+int rh_step_mode(const rh_ctx *ctx);
+
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s);
 int rh_get_scalars(rh_ctx *ctx, rh_scalars *s); /* synchronises */
 
@@ -216,6 +223,22 @@ void *rh_predicate_words(rh_ctx *ctx);
  * Stream-ordered, no synchronisation. */
 int rh_predicates_expand(rh_ctx *ctx, int word, int32_t *dev_dst64);
 int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64);
+
+/* ---- multi-GPU stepping without the host in the loop (SURVEY section 8b "rh_set_comm", 8e) -----------------------------------
+ * One process per GPU, the grid split along x (roger/distributed.py:121-187); the only exchange of the SVAT / oneD step is the
+ * OR of the ranks' summary words -- what the reference does per step by gathering 18 fields to rank 0, deciding dt there and
+ * scattering them back (roger/core/adaptive_time_stepping_dist_safe.py:6-26).  rh_run_steps_dist enqueues, per step, on the
+ * context's stream: ncclAllReduce(MAX, 64 x int32: the summary word the previous fused kernel's tail spread out) -> control kernel
+ * (device-side hooks, dt, selection, event bookkeeping from the reduced word) -> fused kernel.  No host synchronisation and no
+ * Python between the steps.  The communicator is RCCL's (librccl is loaded on first use, the library does not link against it):
+ *   rh_comm_unique_id   rank 0 creates the 128-byte id (ncclGetUniqueId); the caller hands it to the other ranks
+ *   rh_comm_init        every rank: ncclCommInitRank on the context's device (collective); owned by the context
+ *   rh_set_comm         or: borrow a communicator the caller owns (an ncclComm_t); NULL detaches
+ * With one rank the all-reduce is a copy: rh_run_steps_dist then equals rh_run_steps bit for bit (tests/test_hip_comm.py). */
+int rh_comm_unique_id(void *id128);
+int rh_comm_init(rh_ctx *ctx, const void *id128, int nranks, int rank);
+int rh_set_comm(rh_ctx *ctx, void *nccl_comm);
+int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps);
 
 /* ---- device-side output accumulators --------------------------------
  * The reference's "rate" diagnostic adds every registered variable after each step (`rate += var[..., tau]`,

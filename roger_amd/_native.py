@@ -91,6 +91,11 @@ def load():
     lib.rh_step_phase3.argtypes = [vp, i32]
     lib.rh_step_finish.argtypes = [vp, i32]
     lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
+    lib.rh_step_mode.argtypes = [vp]
+    lib.rh_comm_unique_id.argtypes = [vp]
+    lib.rh_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.rh_set_comm.argtypes = [vp, vp]
+    lib.rh_run_steps_dist.argtypes = [vp, i64]
     lib.rh_diag_set_interval.argtypes = [vp, i64]
     lib.rh_diag_slot_times.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.rh_step_summary_expand.argtypes = [vp, vp]
@@ -335,8 +340,17 @@ DECLARED_SYMBOLS = (
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
-    "rh_set_forcing_weights",
+    "rh_set_forcing_weights", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
 )
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (ncclGetUniqueId): created on rank 0, handed to every rank's `comm_init`."""
+    lib = load()
+    buf = C.create_string_buffer(128)
+    if lib.rh_comm_unique_id(buf) != 0:
+        raise NativeError(f"rh_comm_unique_id failed: {lib.rh_last_error(None).decode()}")
+    return buf.raw
 
 
 def plane_table():
@@ -500,6 +514,30 @@ class Context:
 
     def diag_device_ptr(self, name, slot):
         return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))
+
+    def step_mode(self):
+        """(lazy, tail) of the last fused step: it deferred the tau -> taum1 copies / its last wavefront formed the next step's control part."""
+        m = self._lib.rh_step_mode(self._h)
+        return bool(m & 1), bool(m & 2)
+
+    # -- multi-GPU stepping without the host in the loop (RCCL from C) -------------------------------------------------
+    def comm_init(self, unique_id, nranks, rank):
+        """Every rank, collectively: an RCCL communicator on this context's device from rank 0's `comm_unique_id()` bytes."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.rh_comm_init(self._h, buf, int(nranks), int(rank)), "rh_comm_init")
+
+    def comm_init_torch(self, group=None):
+        """The same through an initialised torch.distributed process group: rank 0 creates the id, broadcast to the others."""
+        import torch.distributed as dist
+
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        box = [comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self.comm_init(box[0], world, rank)
+
+    def run_steps_dist(self, nsteps):
+        self._check(self._lib.rh_run_steps_dist(self._h, int(nsteps)), "rh_run_steps_dist")
 
     def placement_report(self):
         """Streaming-kernel time (ms) on every candidate arena rh_create probed, the chosen one first ([]: probing off)."""

@@ -57,10 +57,27 @@ RH_DEV T *rh_cell(const Arena &a, int plane, int64_t i) {
     return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
 #endif
 }
-RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, double &dst) { dst = *rh_cell<const double>(a, plane, i); }
-RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, int &dst) { dst = *rh_cell<const int>(a, plane, i); }
-RH_DEV void rh_st(const Arena &a, int plane, int64_t i, double v) { *rh_cell<double>(a, plane, i) = v; }
-RH_DEV void rh_st(const Arena &a, int plane, int64_t i, int v) { *rh_cell<int>(a, plane, i) = v; }
+// RH_NT: plane accesses as non-temporal (streaming) loads / stores -- every plane is touched once per kernel, nothing is worth
+// keeping in the caches.  bit 0: loads, bit 1: stores.  Measured on the fused step at 10^6 columns, alternating in one call
+// (tools/ab_variants.sh): 0.3158 ms plain, 0.3136 loads only, 0.3108 stores only, 0.3016 both (- 4.5 %); a plain copy with the
+// same access shape gains 3 - 5 % (tools/experiments/bw_probe.hip).
+#ifndef RH_NT
+#define RH_NT 3
+#endif
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, double &dst) {
+    dst = (RH_NT & 1) ? __builtin_nontemporal_load(rh_cell<const double>(a, plane, i)) : *rh_cell<const double>(a, plane, i);
+}
+RH_DEV void rh_ld(const Arena &a, int plane, int64_t i, int &dst) {
+    dst = (RH_NT & 1) ? __builtin_nontemporal_load(rh_cell<const int>(a, plane, i)) : *rh_cell<const int>(a, plane, i);
+}
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, double v) {
+    if (RH_NT & 2) __builtin_nontemporal_store(v, rh_cell<double>(a, plane, i));
+    else *rh_cell<double>(a, plane, i) = v;
+}
+RH_DEV void rh_st(const Arena &a, int plane, int64_t i, int v) {
+    if (RH_NT & 2) __builtin_nontemporal_store(v, rh_cell<int>(a, plane, i));
+    else *rh_cell<int>(a, plane, i) = v;
+}
 
 // Settings that the kernels read (subset of rh_config, device copy).
 struct Consts {

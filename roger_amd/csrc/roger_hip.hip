@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the entry points are resolved with dlsym on first use (rccl_api)
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -133,6 +136,11 @@ struct rh_ctx {
     char *arena_alloc;    // what hipMalloc returned for the arena (arena.base = arena_alloc + arena_offset)
     size_t arena_offset;
     void *stage_buf;      // one contiguous plane (n * 8 bytes): uploads and downloads pass through it
+    // multi-GPU: RCCL communicator and the exchange buffers of the summary word (64 int32 sent, 64 received)
+    ncclComm_t comm;
+    bool own_comm;
+    int *exch_buf;
+    bool exch_valid;      // exch_buf[0..63] holds the summary word of the columns as they are now (written by the last fused kernel's tail)
     std::string err;
 };
 #define RH_DT_LOG_CAP 65536
@@ -1179,7 +1187,9 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
             }
         }
     }
+#ifndef RH_CENSUS   // tools/isa_census.py counts the per-column memory instructions of the kernel without its tail
     if (__shfl((int)last, 0)) step_tail(D, tail_lds, flags, dst64);
+#endif
 }
 
 #define RH_CELL_KERNEL(kname, rt, call)                                       \
@@ -1364,6 +1374,7 @@ static void planes_touched(rh_ctx *ctx) {
     ctx->rot_consistent = false;
     ctx->summary_valid = false;
     ctx->pending_valid = false;
+    ctx->exch_valid = false;
 }
 #define LAUNCH_CELLS(ctx, kern)                                                                                          \
     do {                                                                                                                 \
@@ -1373,6 +1384,51 @@ static void planes_touched(rh_ctx *ctx) {
 #define LAUNCH_ONE(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, (ctx)->stream, __VA_ARGS__)
 #define LAUNCH_WG(ctx, kern, ...) hipLaunchKernelGGL(kern, dim3(1), dim3(RH_BLOCK), 0, (ctx)->stream, __VA_ARGS__)
 #define CHECK_LAUNCH(ctx) HIPCHK(ctx, hipGetLastError())
+
+// RCCL, resolved at run time: a single-GPU user needs no librccl, and a process that already holds one (PyTorch ships its own
+// copy under the same soname) keeps using that one.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+    bool ok;
+    std::string why;
+};
+static RcclApi *rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a{};
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            a.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            return a;
+        }
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        if (!a.ok) a.why = "librccl lacks an expected entry point";
+        return a;
+    }();
+    return &api;
+}
+static void release_comm(rh_ctx *ctx) {
+    if (ctx->comm && ctx->own_comm && rccl_api()->ok) (void)rccl_api()->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->own_comm = false;
+}
+#define NCCLCHK(ctx, call)                                                                                                   \
+    do {                                                                                                                     \
+        ncclResult_t r_ = (call);                                                                                            \
+        if (r_ != ncclSuccess) return fail(ctx, RH_ERR_HIP, std::string(#call) + ": " + rccl_api()->GetErrorString(r_));     \
+    } while (0)
 
 extern "C" {
 
@@ -1468,6 +1524,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->arena.stride = stride;
     ctx->arena.n = ctx->n;
     ctx->stage_buf = nullptr;
+    ctx->comm = nullptr;
+    ctx->own_comm = false;
+    ctx->exch_buf = nullptr;
+    ctx->exch_valid = false;
     auto bail = [&](hipError_t e, const char *what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         rh_destroy(ctx);
@@ -1600,6 +1660,8 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->diag_steps_buf) (void)hipFree(ctx->diag_steps_buf);
     if (ctx->arena_alloc) (void)hipFree(ctx->arena_alloc);
     if (ctx->stage_buf) (void)hipFree(ctx->stage_buf);
+    if (ctx->exch_buf) (void)hipFree(ctx->exch_buf);
+    release_comm(ctx);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1905,6 +1967,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     ctx->summary_valid = true;  // the fused kernel's tail leaves the summary word of the state it wrote (words[3])
     ctx->pending_valid = (flags & RH_TAIL_CTRL) != 0;
     ctx->pending_hooks = (flags & RH_TAIL_HOOKS) != 0;
+    ctx->exch_valid = dst64 != nullptr;
     if (ctx->diag_n) {
         hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev);
         CHECK_LAUNCH(ctx);
@@ -2113,6 +2176,63 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     return RH_OK;
 }
 
+int rh_comm_unique_id(void *id128) {
+    if (!id128) return fail(nullptr, RH_ERR_ARG, "rh_comm_unique_id: null pointer");
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(nullptr, RH_ERR_STATE, "rh_comm_unique_id: " + api->why);
+    ncclUniqueId id;
+    NCCLCHK(nullptr, api->GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return RH_OK;
+}
+int rh_comm_init(rh_ctx *ctx, const void *id128, int nranks, int rank) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return ctx ? fail(ctx, RH_ERR_ARG, "rh_comm_init: bad arguments") : RH_ERR_ARG;
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_comm_init: " + api->why);
+    release_comm(ctx);
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    NCCLCHK(ctx, api->CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->own_comm = true;
+    return RH_OK;
+}
+int rh_set_comm(rh_ctx *ctx, void *nccl_comm) {
+    if (!ctx) return RH_ERR_ARG;
+    release_comm(ctx);
+    ctx->comm = (ncclComm_t)nccl_comm;
+    return RH_OK;
+}
+int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
+    if (!ctx || nsteps < 0) return RH_ERR_ARG;
+    if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
+    if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
+    if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: the one-exchange step needs forcing shared by all columns (rh_step_phase1/2/3 otherwise)");
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: " + api->why);
+    if (!ctx->exch_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->exch_buf, 128 * sizeof(int)));
+    int *send = ctx->exch_buf, *recv = ctx->exch_buf + 64;
+    for (int64_t k = 0; k < nsteps; ++k) {
+        if (!ctx->exch_valid) {   // first step, or the host touched the planes: the summary word from words[3] or from the arena
+            int src = RH_SRC_WORD3;
+            if (!ctx->summary_valid) {
+                HIPCHK(ctx, hipMemsetAsync(ctx->dev->sumw, 0, sizeof(ctx->dev->sumw), ctx->stream));
+                LAUNCH_CELLS(ctx, k_summary);
+                ctx->summary_valid = true;
+                src = RH_SRC_SUMW;
+            }
+            LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, 0, send, src);
+            CHECK_LAUNCH(ctx);
+        }
+        NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+        LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv);
+        CHECK_LAUNCH(ctx);
+        int rc = launch_fused_kernel(ctx, -1, 0, send);   // the tail spreads the next step's summary word into `send`
+        if (rc) return rc;
+    }
+    return RH_OK;
+}
+
 int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int *collect_planes, int n_collect, int n_slots) {
     if (!ctx) return RH_ERR_ARG;
     if (n_rate < 0 || n_collect < 0 || n_rate + n_collect > 32 || n_slots < 1 || (n_rate && !rate_planes) || (n_collect && !collect_planes))
@@ -2244,6 +2364,11 @@ int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
     const int n = (int)ctx->probe_ms.size();
     for (int k = 0; k < n && k < cap && ms; ++k) ms[k] = ctx->probe_ms[k];
     return n;
+}
+
+int rh_step_mode(const rh_ctx *ctx) {
+    if (!ctx) return 0;
+    return (ctx->m1_stale ? RH_STEP_MODE_LAZY : 0) | (ctx->pending_valid ? RH_STEP_MODE_TAIL : 0);
 }
 
 void *rh_predicate_words(rh_ctx *ctx) { return ctx ? (void *)ctx->dev->words : nullptr; }

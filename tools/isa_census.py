@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Memory-instruction census of the fused kernel from its gfx950 ISA: what ONE column (one lane) loads and stores per launch.
+
+    python tools/isa_census.py            # prints the table and rewrites roger_amd/csrc/rh_step_bytes.json
+
+The kernel is compiled with -DRH_CENSUS (the tail, which one wavefront of the whole grid runs, is left out), so every
+global_load / global_store of the kernel is per-column traffic: the kernel loads no plane twice and the sub-step loops of the
+infiltration stages touch registers only.  The compiler drops the loads of planes the step assigns before reading them, so these
+counts -- not the plane sets of tools/gen_sets.py, which list every plane a stage mentions -- are the bytes the kernel requests:
+its algorithmic (compulsory) traffic, priced by bench.py's roofline.  It is a static count: an instruction that the compiler
+duplicated into two mutually exclusive paths counts twice, so the figure is an upper bound a few per cent above the measured HBM
+traffic (PMC: 1 714 B against 1 768 B for the lazy SVAT step)."""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from roger_amd.build import CSRC, FLAGS, HIPCC  # noqa: E402
+
+OUT = os.path.join(CSRC, "rh_step_bytes.json")
+WIDTH = {"ubyte": 1, "sbyte": 1, "ushort": 2, "sshort": 2, "short": 2, "byte": 1, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}
+
+
+def census():
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([HIPCC] + FLAGS + ["-DRH_CENSUS", "-S", "--cuda-device-only", os.path.join(CSRC, "roger_hip.hip"), "-o", os.path.join(tmp, "k.s")],
+                       check=True, stderr=subprocess.DEVNULL)
+        txt = open(os.path.join(tmp, "k.s")).read()
+    out = {}
+    for fn in re.split(r"\n(?=_Z\w+:)", txt):
+        m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])EEv", fn)
+        if not m:
+            continue
+        body = fn[: fn.find("s_endpgm")]
+        ld = st = 0
+        for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M):
+            if op == "load":
+                ld += WIDTH[w]
+            else:
+                st += WIDTH[w]
+        in_loop = 0
+        mode, lateral, lazy = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
+        out[f"mode{mode}_{'oned' if lateral else 'svat'}_{'lazy' if lazy else 'eager'}"] = {"load_bytes": ld, "store_bytes": st, "in_loops": in_loop}
+    return out
+
+
+if __name__ == "__main__":
+    rec = census()
+    for k in sorted(rec):
+        print(f"{k:28s} loads {rec[k]['load_bytes']:5d} B  stores {rec[k]['store_bytes']:5d} B  total {rec[k]['load_bytes'] + rec[k]['store_bytes']:5d} B per column and launch"
+              )
+    # the non-monthly pipeline (mode 0) is what a step executes unless the month changes; mode 2 holds both pipelines
+    keep = {k[6:]: {"load_bytes": v["load_bytes"], "store_bytes": v["store_bytes"]} for k, v in rec.items() if k.startswith("mode0_")}
+    keep["_note"] = "bytes one column loads / stores per fused step (k_step, non-monthly pipeline), counted from the gfx950 ISA by tools/isa_census.py"
+    txt = json.dumps(keep, indent=1, sort_keys=True) + "\n"
+    if not os.path.exists(OUT) or open(OUT).read() != txt:
+        open(OUT, "w").write(txt)

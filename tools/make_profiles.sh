@@ -1,0 +1,83 @@
+#!/bin/bash
+# Rebuilds every number under profiles/ from ONE call on the GPU box, so that they cannot drift apart:
+#     gpurun --timeout 1200 -- tools/make_profiles.sh r02      (then, in the build container:  cp gpurun_out/profiles/* profiles/)
+# Bench lines (default, dt classes, 10^7, oneD, 80 x 53, SAS), rocprofv3 --kernel-trace --stats of the default bench command and of the
+# SAS bench, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated) of every benched kernel variant and size, and the VALU
+# instruction counters of the SAS kernel.  rocprofv3 is always given the program itself (python3 ...), never a wrapper.
+set -o pipefail
+tag=${1:-r02}
+export RH_TAG=$tag
+what=${2:-all}
+out=gpurun_out/profiles
+scratch=gpurun_out/prof_scratch
+mkdir -p $out $scratch
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+export PYTHONUNBUFFERED=1
+last() { tail -n 1 "$1"; }
+
+bench() {   # name, args...
+  local name=$1; shift
+  python3 bench.py "$@" > $scratch/$name.out 2> $scratch/$name.err && last $scratch/$name.out > $out/${tag}_bench_$name.json && echo "bench $name: $(python3 -c "import json,sys; d=json.load(open('$out/${tag}_bench_$name.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_kernel_ms'], d['roofline']['frac'])")"
+}
+pmc_pair() {   # key, kernel substring, n_cells, calib_cells, program args... (environment already exported)
+  local key=$1 kern=$2 n=$3 calib=$4; shift 4
+  rm -rf $scratch/pmc_f $scratch/pmc_w
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $scratch/pmc_f -- "$@" > $scratch/pmc_f.log 2>&1 || { echo "pmc fetch pass failed: $key"; tail -3 $scratch/pmc_f.log; return 1; }
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $scratch/pmc_w -- "$@" > $scratch/pmc_w.log 2>&1 || { echo "pmc write pass failed: $key"; tail -3 $scratch/pmc_w.log; return 1; }
+  python3 tools/pmc_summarise.py $scratch/pmc_f $scratch/pmc_w $n "$key" "$kern" $calib --out $out/traffic.json --source "tools/make_profiles.sh $tag: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), calibrated on k_calib_copy"
+}
+
+if [ "$what" = all ] || [ "$what" = svat ]; then
+  bench svat_1e6 --steps 200 --warmup 10
+  bench svat_1e6_default
+  bench svat_1e6_dt_classes --steps 600 --warmup 10 --no-cpu-baseline
+  bench svat_1e6_hetero --params hetero --steps 200 --warmup 10 --no-cpu-baseline
+  bench svat_1e7 --size 3200 3125 --steps 60 --warmup 5 --no-cpu-baseline
+  bench oned_1e6 --model oned --steps 200 --warmup 10 --no-cpu-baseline
+  bench oned_1e7 --model oned --size 3200 3125 --steps 60 --warmup 5 --no-cpu-baseline
+  bench svat_80x53 --size 80 53 --params hetero --steps 2000 --warmup 50 --no-cpu-baseline
+  bench svat_80x53_station_weights --size 80 53 --params hetero --station-weights --steps 2000 --warmup 50 --no-cpu-baseline
+  RH_BENCH_FORCE_DIST=1 bench svat_1e6_rccl_one_rank --steps 200 --warmup 10 --no-cpu-baseline
+  # the default bench command under rocprofv3 --kernel-trace --stats: the kernel's average duration there must agree with the HIP events
+  rm -rf $scratch/stats_svat
+  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_svat -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_svat.out 2> $scratch/stats_svat.err \
+    && last $scratch/stats_svat.out > $out/${tag}_bench_svat_1e6_under_rocprof.json \
+    && cp "$(find $scratch/stats_svat -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_svat_1e6.csv && echo "kernel stats svat ok"
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 1000000 1000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=oned RH_PMC_SIZE=1000x1000
+  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 1000000 1000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=3200x3125
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 10000000 10000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=oned RH_PMC_SIZE=3200x3125
+  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 10000000 10000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=80x53
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 4240 4240 python3 tools/pmc_workload.py
+  unset RH_PMC_MODEL RH_PMC_SIZE
+fi
+if [ "$what" = all ] || [ "$what" = sas ]; then
+  bench sas_1e6 --model sas --steps 8 --warmup 2
+  rm -rf $scratch/stats_sas
+  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_sas -- python3 bench.py --model sas --size 316 316 --steps 8 --warmup 2 --no-cpu-baseline > $scratch/stats_sas.out 2> $scratch/stats_sas.err \
+    && last $scratch/stats_sas.out > $out/${tag}_bench_sas_1e5_under_rocprof.json \
+    && cp "$(find $scratch/stats_sas -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_sas_1e5.csv && echo "kernel stats sas ok"
+  export RH_PMC_CALIB=1
+  pmc_pair k_sas_ages1000_sub6 "k_sas<" 100000 1000000 python3 tools/sas_workload.py 100000 4
+  unset RH_PMC_CALIB
+  # VALU issue: wave-instructions of the SAS kernel per launch (SQ block, one pass), and the busy cycles beside them
+  rm -rf $scratch/pmc_valu
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $scratch/pmc_valu -- python3 tools/sas_workload.py 100000 4 > $scratch/pmc_valu.log 2>&1 \
+    && python3 tools/sas_valu_summarise.py $scratch/pmc_valu 100000 $out/sas_valu.json "tools/make_profiles.sh $tag: rocprofv3 --pmc SQ_INSTS_VALU ... on tools/sas_workload.py 100000 4" \
+    && cp "$(find $scratch/pmc_valu -name '*counter_collection.csv' | head -1)" $scratch/sas_counters.csv && python3 - <<'PY'
+import csv, collections
+rows = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open("gpurun_out/prof_scratch/sas_counters.csv")):
+    rows[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("gpurun_out/profiles/TAG_pmc_sas_valu_by_kernel.csv".replace("TAG", __import__("os").environ.get("RH_TAG", "r02")), "w") as f:
+    f.write("kernel,counter,launches,average\n")
+    for k, c in rows.items():
+        for name, v in sorted(c.items()):
+            f.write(f"\"{k}\",{name},{len(v)},{sum(v) / len(v):.1f}\n")
+PY
+fi
+ls -la $out
