@@ -30,8 +30,8 @@ def main(pmc_dir, n_cells, out, source):
     rec["min_cycles_at_full_issue"] = insts * 4 / 1024
     if "GRBM_GUI_ACTIVE" in avg:
         rec["gui_active_cycles"] = avg["GRBM_GUI_ACTIVE"]
-        rec["issue_fraction_by_counters"] = insts * 4 / 1024 / avg["GRBM_GUI_ACTIVE"]
-        rec["clock_mhz"] = avg["GRBM_GUI_ACTIVE"] / (sum(dur) / len(dur)) * 1e3   # cycles per ns -> MHz
+        rec["issue_fraction_by_counters"] = insts * 4 / 1024 / (avg["GRBM_GUI_ACTIVE"] / 8)   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        rec["clock_mhz"] = avg["GRBM_GUI_ACTIVE"] / 8 / (sum(dur) / len(dur)) * 1e3   # cycles per ns -> MHz
     table = json.load(open(out)) if os.path.exists(out) else {}
     table["ages1000_sub6"] = rec
     json.dump(table, open(out, "w"), indent=1, sort_keys=True)
