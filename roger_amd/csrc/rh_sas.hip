@@ -62,6 +62,20 @@ SAS_DEV double udiv(double a, const UDiv &u) {
     return __builtin_fma(__builtin_fma(-u.d, q0, a), u.r, q0);
 }
 
+// Square root of r in [2^-700, 1] -- the quotient SA / S of the power law with exponent 0.5 / 1.5.  The compiler's sqrt wraps this very
+// sequence (v_rsq_f64, Goldschmidt step, two residual corrections: correctly rounded) in a rescaling for arguments below 2^-767 and a
+// class test for 0 / inf / NaN, twenty instructions in all; inside the range neither can trigger, ten remain.  r == 0 never reaches the
+// result (the caller selects 0 for SA <= 0).  Checked against the host's sqrt through rh_sas_selftest_pow (tests/test_hip_sas.py).
+SAS_DEV double sqrt_unit(double r) {
+    const double y = __builtin_amdgcn_rsq(r);
+    double g = r * y, h = y * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    g = __builtin_fma(__builtin_fma(-g, g, r), h, g);
+    return __builtin_fma(__builtin_fma(-g, g, r), h, g);
+}
+
 // Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
 // operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
 #include "rh_sas_tables.inc"
@@ -482,19 +496,25 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
                 if (code == 62) k = p3 + (S_rel * p4);
             }
             // Exponents with a closed form -- the benchmark's own: 0.5 for transpiration, 1.5 for percolation
-            // (benchmarks/SVATOXYGEN18_benchmark.py:129-138) -- go through a correctly rounded square root instead of
-            // exp2(k * log2 .): 15 instead of 42 instructions per evaluation.  Uniform over the column.
+            // (benchmarks/SVATOXYGEN18_benchmark.py:129-138) -- go through a correctly rounded square root of the true quotient
+            // SA / S (exactly 1 at the top edge, as in the reference's (SA / S) ** k) instead of exp2(k * log2 .).  The exponent
+            // and S are uniform over the column, so the variants are branches of the whole workgroup, not selects per class.
             const int kmode = (k == 0.5) ? 1 : ((k == 1.5) ? 2 : ((k == 1.0) ? 3 : 0));
-            if (kmode != 0) {
-                const double rS = 1.0 / S;
+            if (S <= 0) {   // Omega = where(S <= 0, 0, .): nothing to evaluate
+#pragma unroll
+                for (int j = 0; j < E; ++j) Om[j] = 0.0 * mk;
+            } else if (kmode != 0) {
+                const UDiv by_S = udiv_prepare(S);
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     const double x = SA_hi[j];
-                    const double r = (x == S) ? 1.0 : x * rS;   // exactly 1 at the top edge, as (S / S) ** k is
-                    const double sq = sqrt(r);
-                    const double v = (kmode == 1) ? sq : ((kmode == 2) ? r * sq : r);
-                    const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
-                    Om[j] = (S <= 0 ? 0 : o) * mk;
+                    const double r = udiv(x, by_S);
+                    double v;
+                    if (kmode == 1) v = sqrt_unit(r);
+                    else if (kmode == 2) v = r * sqrt_unit(r);
+                    else v = r;
+                    const double o = (x > 0 ? fmin(v, 1.) : 0.) * 1.0 * mk;   // x <= S ? v : 1, and v > 1 exactly where x > S
+                    Om[j] = o * mk;
                 }
             } else {
             const double log2S = sas_log2(C, S);
@@ -505,7 +525,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
                 // evaluations interleave (a NaN from x <= 0 is discarded by the select)
                 const double v = sas_pow_ratio(C, x, S, log2S, k);
                 const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
-                Om[j] = (S <= 0 ? 0 : o) * mk;
+                Om[j] = o * mk;
             }
             }
         } else if (dirac) {  // piston flow, sas.py:43-64: the edge index (vs.nages) against the age threshold p1
@@ -564,8 +584,8 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const double d = Om[j] - (j == 0 ? Om_lo : Om[j - 1]);
-            double t = (d >= 0 ? d : 0);                                       // :430-433
-            const double q = (flux * t * h > san[j] ? san[j] : flux * t * h);   // :435-438
+            double t = fmax(d, 0.0);                                            // :430-433  where(d >= 0, d, 0)
+            const double q = fmin(flux * t * h, san[j]);                        // :435-438  where(flux t h > san, san, flux t h)
             t = udiv(q, by_fh);                                                 // :440-443: q / (flux * h), fh > 0 here
             san[j] = san[j] + -t * flux * h;                                    // :445-448
             tti[j] = t;
@@ -577,12 +597,12 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
 #pragma unroll
         for (int j = 0; j < E; ++j) ttn[j] += tti[j];
     }
-    const double N = (double)P.substeps;
+    const UDiv by_N = udiv_prepare((double)P.substeps), by_flux = udiv_prepare(flux);   // (flux > 0 here: fh > 0)
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const double t = ttn[j] / N;                                              // :482-490
+        const double t = udiv(ttn[j], by_N);                                      // :482-490
         const double q = (flux * t > sa[j] ? sa[j] : flux * t);                   // :493-496
-        tt[j] = (flux > 0 ? q / flux : 0);                                        // :497-499
+        tt[j] = udiv(q, by_flux);                                                 // :497-499  where(flux > 0, q / flux, 0)
     }
 }
 template <int W, int E>
@@ -606,6 +626,14 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
     }
 }
 
+template <int W, int E>
+SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&cdf_hi)[E], double cdf_lo,
+                       const double (&dens)[E], int first_arr, bool skip10_90);
+// The age statistics of a flux's travel time distribution are formed as soon as the distribution exists when the whole day runs
+// in one launch (they depend on nothing later); keeping tt / TT alive until the storage stage cost 36 registers across four fluxes,
+// which the compiler spilled.  With the stages in launches of their own they come back from the diagnostics arrays (load_dist).
+SAS_DEV bool stats_now(const SasArgs &P) { return P.stats && (P.stages & RH_SAS_STORAGE); }
+
 // One outgoing flux: SA, tt, TT, mtt, C, C_iso, the sink's isotope mixing, update_sa.
 // calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
 // calc_percolation_rz/ss_transport_iso_kernel (core/subsurface_runoff.py:1531-1626, 1753-1820),
@@ -626,17 +654,10 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
         s[0] += mtt[j] * tt[j];
         s[1] += tt[j];
     }
-    if (P.diag || (KEEP && P.stats)) {  // TT[1:] = cumsum(tt)
+    if (P.diag || (KEEP && stats_now(P))) {  // TT[1:] = cumsum(tt)
         double TT_hi[E], TT_lo;
         blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-        if (KEEP) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                keep.tt[j] = tt[j];
-                keep.TT_hi[j] = TT_hi[j];
-            }
-            keep.TT_lo = TT_lo;
-        }
+        if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
         if (P.diag) {
             double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
             double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
@@ -663,8 +684,9 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
     for (int j = 0; j < E; ++j) {
         if (SINK) {
             const double add = tt[j] * flux;
+            const UDiv by_tot = udiv_prepare(add + sa_sink[j]);   // two quotients by one divisor (udiv: the bits of `/`)
             msa_sink[j] = (add + sa_sink[j] > 0
-                               ? msa_sink[j] * (sa_sink[j] / (add + sa_sink[j])) + mtt[j] * (add / (add + sa_sink[j]))
+                               ? msa_sink[j] * udiv(sa_sink[j], by_tot) + mtt[j] * udiv(add, by_tot)
                                : msa_sink[j]) * mk;
         }
         double v = sa[j] + -flux * tt[j];  // update_sa :599-619
@@ -686,14 +708,19 @@ SAS_DEV void inflow(Blk<W> &B, const SasArgs &P, int64_t cell, int which, double
         ((double *)P.a[SA_C_inf_mat_rz + which])[cell] = C;
         ((double *)P.a[SA_C_iso_inf_mat_rz + which])[cell] = conc_to_delta(P, C) * mk;
     }
+    // tt is 1 in age class 0 and 0 elsewhere.  For the other classes the mixing formula reduces to msa * (sa / sa) + 0 = msa (sa > 0)
+    // or msa (sa <= 0): the identity, bit for bit (a NaN marker stays a NaN) -- only the thread that owns class 0 computes
+    if (base == 0) {
+        const double ttk = (inf > 0 ? 1 : 0) * mk;
+        const double mttk = (inf > 0 ? C_in : 0) * mk;
+        msa[0] = (inf * ttk + sa[0] > 0 ? msa[0] * (sa[0] / (ttk * inf + sa[0])) + mttk * ((ttk * inf) / (inf * ttk + sa[0]))
+                                        : msa[0]) * mk;
+        sa[0] += inf * mk;
+    }
+    if (mk != 1.0) {   // (the reference multiplies every class by maskCatch)
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const bool first = (base + j == 0);
-        const double ttk = first ? (inf > 0 ? 1 : 0) * mk : 0.0;
-        const double mttk = first ? (inf > 0 ? C_in : 0) * mk : 0.0;
-        msa[j] = (inf * ttk + sa[j] > 0 ? msa[j] * (sa[j] / (ttk * inf + sa[j])) + mttk * ((ttk * inf) / (inf * ttk + sa[j]))
-                                       : msa[j]) * mk;
-        if (first) sa[j] += inf * mk;
+        for (int j = 0; j < E; ++j)
+            if (base + j != 0) msa[j] = msa[j] * mk;
     }
 }
 
@@ -705,24 +732,43 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
                        const double (&dens)[E], int first_arr, bool skip10_90) {
     const int A = P.ages;
     const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    // number of classes with cdf <= q, per percentile: counted with ballots (a compare per class and percentile, the population
+    // counts on the scalar unit) and summed over the waves through LDS, instead of five floating-point block sums
+    int cnt5[5] = {0, 0, 0, 0, 0};
+    double v[2] = {0, 0};
     double mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < E; ++j)
-        if (base + j < A) {
+    for (int j = 0; j < E; ++j) {
+        const bool in = base + j < A;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) v[q] += (cdf_hi[j] <= Q[q]) ? 1.0 : 0.0;
-            v[5] += dens[j];
-            v[6] += (double)(base + j + 1) * dens[j];
+        for (int q = 0; q < 5; ++q) cnt5[q] += __popcll(__ballot(in && (cdf_hi[j] <= Q[q])));
+        if (in) {
+            v[0] += dens[j];
+            v[1] += (double)(base + j + 1) * dens[j];
             mx = fmax(mx, cdf_hi[j]);
         }
-    blk_sum<W, 7>(B, v);
+    }
+    if (W > 1) {
+        const int buf = B.phase++ & 1;
+        if (B.lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) B.red[buf][B.wave][q] = (double)cnt5[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double c = B.red[buf][0][q];
+            for (int w = 1; w < W; ++w) c += B.red[buf][w][q];
+            cnt5[q] = (int)c;
+        }
+    }
+    blk_sum<W, 2>(B, v);
     mx = blk_max<W>(B, mx);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         if (skip10_90 && (q == 0 || q == 4)) continue;
         double *dst = (double *)P.a[first_arr + q] + cell;
-        const int cnt = (int)v[q];  // number of classes with cdf <= q; the crossing is in class `cnt`
+        const int cnt = cnt5[q];  // number of classes with cdf <= q; the crossing is in class `cnt`
         if (!(mx > 0)) {
             if (B.tid == 0) *dst = NAN;
         } else if (cnt <= 0) {
@@ -740,7 +786,7 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
                 }
         }
     }
-    if (B.tid == 0) ((double *)P.a[first_arr + 5])[cell] = (v[5] > 0 ? v[6] : NAN);
+    if (B.tid == 0) ((double *)P.a[first_arr + 5])[cell] = (v[0] > 0 ? v[1] : NAN);
 }
 
 template <int W, int E>
@@ -751,10 +797,11 @@ SAS_DEV void residence_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base
     blk_cumsum<W, E, false>(B, sa, SA_hi, SA_lo, &mx, base, P.ages - 1);
     mx *= mk;
     double RT_hi[E], rt[E];
-    const double RT_lo = (mx > 0 ? (SA_lo * mk) / mx : 0);
+    const UDiv by_mx = udiv_prepare(mx);
+    const double RT_lo = (mx > 0 ? udiv(SA_lo * mk, by_mx) : 0);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        RT_hi[j] = (mx > 0 ? (SA_hi[j] * mk) / mx : 0);
+        RT_hi[j] = (mx > 0 ? udiv(SA_hi[j] * mk, by_mx) : 0);
         rt[j] = RT_hi[j] - (j == 0 ? RT_lo : RT_hi[j > 0 ? j - 1 : 0]);
     }
     age_stats<W, E>(B, P, cell, base, RT_hi, RT_lo, rt, first_arr, skip10_90);
@@ -801,18 +848,11 @@ SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E
 template <int W, int E, bool KEEP>
 SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, int base, const double (&tt)[E], const double *mtt,
                          Dist<E> &keep) {
-    if (!(P.diag || (KEEP && P.stats))) return;
+    if (!(P.diag || (KEEP && stats_now(P)))) return;
     const int A = P.ages;
     double TT_hi[E], TT_lo;
     blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-    if (KEEP) {
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            keep.tt[j] = tt[j];
-            keep.TT_hi[j] = TT_hi[j];
-        }
-        keep.TT_lo = TT_lo;
-    }
+    if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
     if (P.diag) {
         double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
         double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
@@ -1071,7 +1111,8 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
                 s[4] += (msa_s[j] != msa_s[j]) ? 0 : msa_s[j];
             } else {
                 const double tot = sa_rz[j] + sa_ss[j];
-                const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
+                const UDiv by_tot = udiv_prepare(tot);
+                const double v = (tot > 0 ? msa_rz[j] * udiv(sa_rz[j], by_tot) + msa_ss[j] * udiv(sa_ss[j], by_tot) : 0);
                 msa_s[j] = (v != v) ? 0 : v;
                 s[0] += msa_rz[j] * sa_rz[j];
                 s[2] += msa_ss[j] * sa_ss[j];
@@ -1106,10 +1147,16 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
         }
         if (stats) {  // calculate_age_statistics_* :59-312
             // stages run one launch at a time: the distributions come back from the diagnostics arrays
-            if (!have_transp) load_dist<E>(P, cell, base, 1, d_transp);
-            if (!have_q_ss) load_dist<E>(P, cell, base, 3, d_q_ss);
-            age_stats<W, E>(B, P, cell, base, d_transp.TT_hi, d_transp.TT_lo, d_transp.tt, SA_tt10_transp, false);
-            age_stats<W, E>(B, P, cell, base, d_q_ss.TT_hi, d_q_ss.TT_lo, d_q_ss.tt, SA_tt10_q_ss, false);
+            if (!have_transp) {
+                Dist<E> d;
+                load_dist<E>(P, cell, base, 1, d);
+                age_stats<W, E>(B, P, cell, base, d.TT_hi, d.TT_lo, d.tt, SA_tt10_transp, false);
+            }
+            if (!have_q_ss) {
+                Dist<E> d;
+                load_dist<E>(P, cell, base, 3, d);
+                age_stats<W, E>(B, P, cell, base, d.TT_hi, d.TT_lo, d.tt, SA_tt10_q_ss, false);
+            }
             // the reference never assigns rt10 / rt90 of root zone and subsoil (:181-196, :232-247)
             residence_stats<W, E>(B, P, cell, base, sa_rz, mk, SA_rt10_rz, true);
             residence_stats<W, E>(B, P, cell, base, sa_ss, mk, SA_rt10_ss, true);
@@ -1220,7 +1267,12 @@ __global__ void k_selftest_div(const double *a, const double *d, double *out, in
 __global__ void k_selftest_pow(const double *x, const double *k, double *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const PowConsts C = load_pow_consts(SAS_LOG_T);
-    if (i < n) out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
+    if (i >= n) return;
+    // the same dispatch as the power-law branch of calc_tt_family: exponents 0.5 / 1.5 / 1 through the square root
+    if (k[i] == 0.5) out[i] = sqrt_unit(x[i]);
+    else if (k[i] == 1.5) out[i] = x[i] * sqrt_unit(x[i]);
+    else if (k[i] == 1.0) out[i] = x[i];
+    else out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -55,6 +55,23 @@ def compare(got, ref, names, rtol=RTOL, atol=ATOL, what=""):
         raise AssertionError(f"{what}: {len(bad)} mismatching values\n" + "\n".join(lines))
 
 
+def deviating_columns(got, ref, rtol=RTOL, atol=ATOL):
+    """Columns in which any plane misses the tolerance (NaN == NaN, inf == inf)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        ok = (got == ref) | (np.isnan(got) & np.isnan(ref)) | (np.abs(got - ref) <= atol + rtol * np.abs(ref))
+    return set(np.unique(np.argwhere(~ok)[:, 1]).tolist())
+
+
+# oneD model: emptied lateral stores are not snapped to zero (models/oneD/oneD.py vs svat.py:326-345) and the sign of a rounding
+# residue (+-1e-18) decides a branch, so a column's trajectory parts from the reference's at such a tie when `pow` rounds
+# differently (numpy's AVX-512 pow, glibc's, ROCm's).  Columns are independent: every OTHER column is compared over the whole
+# trajectory, a column that tied stays off.  Measured: the oracle loses columns {2, 3, 13} of oned_hetero_combo (first at step 49),
+# the device the same three (first at step 2); one more is allowed.
+ONED_TIE_COLUMNS = {"oned_hetero_combo": 3}
+
+
 def compare_bulk(got, ref, names, what="", rtol_bulk=RTOL, atol_bulk=ATOL, frac_bulk=0.999, rtol_max=1e-3, atol_max=1e-6):
     """Stress-set comparison: at least `frac_bulk` of all values within the golden tolerance and
     every value within (rtol_max, atol_max).  A handful of ill-conditioned columns (subsoil of a

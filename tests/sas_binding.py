@@ -218,6 +218,21 @@ FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6, "sas_gamma_a40": 3, "sa
 MIN_TIGHT = {"sas_gamma_a40": 0.97}
 
 
+# Residue ties of the DEVICE against the reference, measured on MI355X / ROCm 7.2 with the round-2 kernel (tools/sas_tie_rate.py prints
+# them; every GPU test prints its own counts too): (day, column) pairs of a golden case that miss 1e-10 when each day restarts from
+# the reference's state.  The tests allow ONE more than measured: a kernel change that shifts the last bit of Omega moves single ties
+# (re-measure then), a regression that doubles the rate fails.
+DEVICE_TIES = {"sas_power_a40": 2, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_families_a50": 6, "sas_warmup_a30": 0, "sas_gamma_a40": 4,
+               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0}
+# ... and of the ORACLE (glibc's pow against numpy's AVX-512 pow), same criterion, measured in the build container
+ORACLE_TIES = {"sas_power_a40": 0, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_families_a50": 1, "sas_warmup_a30": 0, "sas_gamma_a40": 4,
+               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0}
+# Random columns against the oracle (tests/test_hip_sas.py::test_random_columns_against_oracle), per configuration (n, ages,
+# substeps): columns that newly miss 1e-10 on day 0, 1, 2 (a column that tied stays off afterwards: its state carries on).
+DEVICE_NEW_TIES = {(96, 1000, 6): (0, 5, 1), (200, 300, 3): (2, 5, 3), (64, 1500, 2): (0, 3, 1), (64, 2500, 2): (0, 1, 0),
+                   (300, 17, 4): (0, 1, 0), (150, 100, 5): (0, 0, 4)}
+
+
 def check_day_loose(g, st, d, tag, atol_mm=2e-2, atol_permil=2e-3):
     for k in ("sa_rz", "sa_ss"):
         err = np.abs(st.state[k] - g.day(d, k)).max()

@@ -3,7 +3,8 @@ against the oracle.  Needs a real MI355X: `pytest -m gpu`."""
 import numpy as np
 import pytest
 
-from golden_util import ATOL, CASES, ONED_CASES, RTOL, WEIGHTED_CASES, compare, compare_bulk, is_lateral, load_case, load_weights
+from golden_util import (ATOL, CASES, ONED_CASES, ONED_TIE_COLUMNS, RTOL, WEIGHTED_CASES, compare, compare_bulk, deviating_columns, is_lateral,
+                         load_case, load_weights)
 
 pytestmark = pytest.mark.gpu
 
@@ -29,17 +30,11 @@ def _ctx(native, g, names, key="state0", scal_key="scal0"):
     return ctx
 
 
-# oneD model: step after which an emptied store's rounding residue (+-1e-18) decides a branch (with
-# ocml's `pow` roundings that is step 2 for column 13 of this case; with glibc's it is step 44); see
-# tests/test_oracle_golden.py::test_single_steps_from_reference_states and DESIGN.md.  The 240-step
-# oneD heavy-rain trajectory has no such tie and is compared in full.
-FIRST_TIE = {"oned_hetero_combo": 2}
-
-
 @pytest.mark.parametrize("case", CASES)
 def test_trajectory_golden(native, case):
-    """Fused rh_svat_step reproduces the reference trajectory (all planes at the stored steps,
-    the integer scalars exactly at every step)."""
+    """Fused rh_svat_step reproduces the reference trajectory (all planes at the stored steps, the integer scalars exactly at
+    every step).  oneD combo case: every column but the few that part from the reference at a residue tie
+    (golden_util.ONED_TIE_COLUMNS) over the WHOLE trajectory; a column that tied stays off."""
     import hip_util as H
 
     g, names, forcing = load_case(case)
@@ -47,6 +42,7 @@ def test_trajectory_golden(native, case):
     drv = H.HipForcingDriver(ctx, forcing)
     nsteps = int(g["nsteps"])
     checked = 0
+    off = set()
     for step in range(1, nsteps + 1):
         monthly = drv.before_step()
         ctx.step(monthly)
@@ -55,11 +51,15 @@ def test_trajectory_golden(native, case):
         assert s.sanity_ok == 1
         key = f"s{step:05d}"
         if key in g.files:
-            compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}")
+            if case in ONED_TIE_COLUMNS:
+                off |= deviating_columns(H.download_snapshot(ctx, names), g[key])
+                assert len(off) <= ONED_TIE_COLUMNS[case] + 1, f"{case} step {step}: columns {sorted(off)} deviate"
+            else:
+                compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}")
             checked += 1
-        if step >= FIRST_TIE.get(case, 10 ** 9):
-            break
-    assert checked >= (2 if case in FIRST_TIE else 3)
+    if case in ONED_TIE_COLUMNS:
+        print(f"TIES {case}: columns {sorted(off)} parted from the reference")
+    assert checked >= 3
     ctx.close()
 
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from sas_binding import FLUXES, GOLDEN, SAS_CASES, TIE_WIPED, SasGolden, SasState, column_deviation, compare_sas
+from sas_binding import DEVICE_NEW_TIES, DEVICE_TIES, FLUXES, GOLDEN, SAS_CASES, TIE_WIPED, SasGolden, SasState, column_deviation, compare_sas
 from test_oracle_sas import compare_msa
 
 pytestmark = pytest.mark.gpu
@@ -50,8 +50,8 @@ def pull(ctx, st):
 def test_single_days_from_reference_states(case):
     """Each day of the golden run restarted on the device from the reference's own state.  A (day, column) pair
     may hit a residue tie inside the day (sas_binding.FIRST_TIE: the last bit of `pow` decides whether an emptied
-    age class keeps 1e-16 mm, which the next flux of the same day sees through the power law): at most 7 % of the
-    pairs may miss 1e-10 (3 % measured with the discontinuous families), none may miss the loose bound."""
+    age class keeps 1e-16 mm, which the next flux of the same day sees through the power law): at most ONE more pair than
+    measured for the case (sas_binding.DEVICE_TIES) may miss 1e-10, none may miss the loose bound."""
     g = SasGolden(case)
     st = g.new_state()
     ctx = make_ctx(st)
@@ -64,9 +64,9 @@ def test_single_days_from_reference_states(case):
         pull(ctx, st)
         tight.append(column_deviation(st, lambda k: g.day(d, k), g.n, bool(g.stats)))
     tight = np.array(tight)
-    # measured on MI355X / ROCm 7.2 (tools/sas_tie_rate.py): power 0.986 (2/144), mixed 1.0, stats 1.0,
-    # families 0.964 (6/168), warm-up 1.0
-    assert tight.mean() >= 0.93, f"{case}: {np.count_nonzero(~tight)} of {tight.size} (day, column) pairs deviate: {np.argwhere(~tight)[:8]}"
+    ties = int(np.count_nonzero(~tight))
+    print(f"TIES {case}: {ties} of {tight.size} (day, column) pairs; allowed {DEVICE_TIES[case] + 1}")
+    assert ties <= DEVICE_TIES[case] + 1, f"{case}: {ties} of {tight.size} (day, column) pairs deviate (measured {DEVICE_TIES[case]}): {np.argwhere(~tight)[:8]}"
     ctx.close()
 
 
@@ -154,11 +154,15 @@ def clone(st):
 def test_random_columns_against_oracle(n, ages, substeps, stats):
     """Every workgroup shape (1..16 waves, 1..4 classes per thread) on random columns, three days in a row;
     the oracle runs the same days on the host.  Columns that hit a residue tie (sas_binding.FIRST_TIE; measured
-    1-4 % of random columns per day, deviations 1e-11 .. 1e-4) stay off afterwards because the state carries on:
-    at least 90 % of the columns must agree to 1e-10 in every output on every day, all of them to 5e-3."""
+    1-4 % of random columns per day, deviations 1e-11 .. 1e-4) stay off afterwards because the state carries on.  Every
+    column that has not tied before must agree to 1e-10 in every output or count as a NEW tie of that day -- bounded then by
+    the loose tolerance on every water quantity and isotope signal -- and the number of new ties per day may exceed the
+    measured one (sas_binding.DEVICE_NEW_TIES) by one column at most."""
     st = random_problem(n, ages, substeps, seed=ages + n, stats=stats)
     ref = clone(st)
     ctx = make_ctx(st)
+    tied = np.zeros(n, bool)      # columns that hit a residue tie on an earlier day: their state carries on, they stay off
+    new_ties = []
     for day in range(3):
         if day == 0:
             push(ctx, st)       # later days continue from the device's own state with the same inputs
@@ -182,14 +186,20 @@ def test_random_columns_against_oracle(n, ages, substeps, stats):
                 loose |= np.isnan(a) ^ np.isnan(b)      # a tie can flip a signal between NaN and a number (column_deviation)
             if k in TIE_WIPED:
                 loose[:] = True                         # ... and wipe the oldest class of the soil's signal (sas_binding.TIE_WIPED)
-            if day > 0 and (k.startswith("C_") or k.startswith("msa") or k.startswith("mtt")):
-                # a NaN marker that survived yesterday poisons what is mixed into its class today (NaN * 0 in the
-                # mixing formulas, then isnan -> 0): the isotope signals of a tie column are unbounded from the second
-                # day on; such columns only count against the 10 %
-                loose[:] = True
-            assert loose.all(), f"day {day} {k}: max dev {np.nanmax(np.abs(a - b))}"
+            if k.startswith("C_") or k.startswith("msa") or k.startswith("mtt"):
+                # a NaN marker that survived an earlier day poisons what is mixed into its class (NaN * 0 in the mixing formulas,
+                # then isnan -> 0): the isotope signals of a column that tied BEFORE today are unbounded; every other column --
+                # also one that ties today -- is held to the loose bound, and to 1e-10 through `bad` below
+                loose[tied] = True
+            assert loose.all(), f"day {day} {k}: max dev {np.nanmax(np.abs(a - b))} in columns {np.argwhere(~loose.reshape(n, -1).all(axis=1)).ravel()[:6]}"
             bad |= ~(ok.reshape(n, -1).all(axis=1))
-        assert bad.mean() <= 0.10, f"day {day}: {bad.sum()} of {n} columns deviate"
+        new = bad & ~tied
+        new_ties.append(int(new.sum()))
+        tied |= bad
+    allowed = DEVICE_NEW_TIES[(n, ages, substeps)]
+    print(f"TIES random columns {(n, ages, substeps)}: new per day {new_ties}, allowed {[a + 1 for a in allowed]}")
+    for day in range(3):
+        assert new_ties[day] <= allowed[day] + 1, f"day {day}: {new_ties[day]} columns newly deviate (measured {allowed[day]}); all days {new_ties}"
     ctx.close()
 
 
@@ -270,6 +280,21 @@ def test_power_function_accuracy():
     assert rel[-2:].max() < 1e-12          # 1e-300 and the smallest denormal
     assert got[-4] == 1.0 and (_native.sas_selftest_pow(np.ones(8), np.linspace(0.1, 5, 8)) == 1.0).all()
     assert (_native.sas_selftest_pow(np.array([1e-300, 1e-10]), np.array([50.0, 0.0])) == np.array([0.0, 1.0])).all()
+
+
+def test_square_root_path_is_correctly_rounded():
+    """Exponents 0.5 and 1.5 (the benchmark's transpiration and percolation, SVATOXYGEN18_benchmark.py:129-138) go through
+    sqrt_unit, the compiler's own sqrt sequence without its rescaling and class test: bit-identical to the correctly rounded
+    square root over the quotient's range (2^-700, 1]."""
+    from roger_amd import _native
+
+    rng = np.random.default_rng(1)
+    x = np.concatenate([10.0 ** rng.uniform(-200, 0, 200_000), rng.uniform(0.0, 1.0, 200_000), [1.0, 0.25, 0.5, 2.0 ** -600]])
+    got = _native.sas_selftest_pow(x, np.full(x.size, 0.5))
+    np.testing.assert_array_equal(got, np.sqrt(x))
+    got15 = _native.sas_selftest_pow(x, np.full(x.size, 1.5))
+    np.testing.assert_array_equal(got15, x * np.sqrt(x))
+    assert got[-4] == 1.0 and got15[-4] == 1.0
 
 
 def test_full_size_properties():

