@@ -162,6 +162,9 @@ int rh_initial_conditions(rh_ctx *ctx); /* surface/soil.calculate_initial_condit
 
 /* ---- one entry point per routine of RogerSetup.step (roger/roger.py:396-457,485) ---------- */
 int rh_adaptive_dt(rh_ctx *ctx);        /* adaptive_time_stepping, core/adaptive_time_stepping.py:22-437 */
+/* ... in three parts for several ranks: rh_step_phase1 -> exchange word 0 -> rh_step_phase2 -> exchange word 1 -> this call (dt, event
+ * bookkeeping, pet / ta selection).  Replaces adaptive_time_stepping_dist_safe.py:6-380 (gather to rank 0, decide, scatter). */
+int rh_adaptive_dt_finish(rh_ctx *ctx);
 int rh_interception(rh_ctx *ctx);       /* calculate_interception, core/interception.py:347-356 */
 int rh_evapotranspiration(rh_ctx *ctx); /* calculate_evapotranspiration, core/evapotranspiration.py:603-616 */
 int rh_snow(rh_ctx *ctx);               /* calculate_snow, core/snow.py:294-304 */
@@ -258,6 +261,11 @@ int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes); 
 void *rh_diag_device_ptr(rh_ctx *ctx, int j, int slot);
 /* Number of steps accumulated in a day slot: the divisor of the "average" diagnostic (roger/diagnostics/average.py:
  * `avg += var; n += 1`, output avg / n) for a variable registered as a rate plane.  Synchronises. */
+/* Restart (roger/restart.py:140-174 writes the diagnostics' accumulators next to the core state): put an accumulator slot back --
+ * the values of variable j, and the slot's bookkeeping (steps accumulated, start time of the interval's first step, end time of its
+ * last step: what rh_diag_steps / rh_diag_slot_times report). */
+int rh_diag_upload(rh_ctx *ctx, int j, int slot, const double *host, size_t bytes);
+int rh_diag_set_slot_state(rh_ctx *ctx, int slot, int64_t steps, int64_t t_start, int64_t t_end);
 int rh_diag_steps(rh_ctx *ctx, int slot, int64_t *steps);
 /* Output intervals other than a day: 3600 or 600 seconds (the step classes; a step never straddles a boundary it does not
  * start on).  Slots are then indexed by the interval of the step's start; an interval that a longer step covers is never

@@ -40,7 +40,7 @@ _ENTRY_POINTS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
     "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core", "rh_params_lateral",
-    "rh_step_summary",
+    "rh_step_summary", "rh_adaptive_dt_finish",
 )
 
 
@@ -92,6 +92,8 @@ def load():
     lib.rh_step_finish.argtypes = [vp, i32]
     lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.rh_step_mode.argtypes = [vp]
+    lib.rh_diag_upload.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    lib.rh_diag_set_slot_state.argtypes = [vp, i32, i64, i64, i64]
     lib.rh_comm_unique_id.argtypes = [vp]
     lib.rh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.rh_set_comm.argtypes = [vp, vp]
@@ -340,7 +342,7 @@ DECLARED_SYMBOLS = (
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
-    "rh_set_forcing_weights", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
+    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
 )
 
 
@@ -511,6 +513,14 @@ class Context:
         t0, t1 = C.c_int64(), C.c_int64()
         self._check(self._lib.rh_diag_slot_times(self._h, int(slot), C.byref(t0), C.byref(t1)), "rh_diag_slot_times")
         return t0.value, t1.value
+
+    def diag_upload(self, name, slot, values):
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        self._check(self._lib.rh_diag_upload(self._h, self._diag_names.index(name), int(slot), a.ctypes.data_as(C.c_void_p), a.nbytes),
+                    "rh_diag_upload")
+
+    def diag_set_slot_state(self, slot, steps, t_start, t_end):
+        self._check(self._lib.rh_diag_set_slot_state(self._h, int(slot), int(steps), int(t_start), int(t_end)), "rh_diag_set_slot_state")
 
     def diag_device_ptr(self, name, slot):
         return self._lib.rh_diag_device_ptr(self._h, self._diag_names.index(name), int(slot))

@@ -2098,6 +2098,16 @@ int rh_adaptive_dt(rh_ctx *ctx) {
     return RH_OK;
 }
 
+// the last part of rh_adaptive_dt on its own: with several ranks the two predicate words are exchanged between rh_step_phase1 /
+// rh_step_phase2 and this call (adaptive_time_stepping_dist_safe.py:6-26 gathers 18 fields to rank 0 for the same decision)
+int rh_adaptive_dt_finish(rh_ctx *ctx) {
+    if (!ctx) return RH_ERR_ARG;
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 0, 0);
+    LAUNCH_CELLS(ctx, k_select_pet);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
 int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, const double *pet, const int64_t *year,
                           const int64_t *month, const int64_t *doy, int64_t nitt_forc) {
     if (!ctx || !prec || !ta || !pet || !year || !month || !doy || nitt_forc <= 0) return RH_ERR_ARG;
@@ -2293,6 +2303,22 @@ int rh_diag_download(rh_ctx *ctx, int j, int slot, double *host, size_t bytes) {
     if (rc) return rc;
     if (!host || bytes != (size_t)ctx->n * sizeof(double)) return fail(ctx, RH_ERR_ARG, "rh_diag_download: size mismatch");
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->diag_buf + ((size_t)slot * ctx->diag_n + j) * ctx->n, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_diag_upload(rh_ctx *ctx, int j, int slot, const double *host, size_t bytes) {
+    const int rc = diag_check(ctx, j, slot);
+    if (rc) return rc;
+    if (!host || bytes != (size_t)ctx->n * sizeof(double)) return fail(ctx, RH_ERR_ARG, "rh_diag_upload: size mismatch");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->diag_buf + ((size_t)slot * ctx->diag_n + j) * ctx->n, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_diag_set_slot_state(rh_ctx *ctx, int slot, int64_t steps, int64_t t_start, int64_t t_end) {
+    const int rc = diag_check(ctx, 0, slot);
+    if (rc) return rc;
+    const long long v[3] = {(long long)steps, (long long)t_start, (long long)t_end};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->diag_steps_buf + 3 * slot, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RH_OK;
 }

@@ -196,6 +196,29 @@ class PhasedStepper:
         for _ in range(nsteps):
             self.step()
 
+    def adaptive_dt(self):
+        """The stand-alone adaptive time stepping (rh_adaptive_dt) of the hook-preserving `RogerSetup.step()` with several ranks: the
+        two predicate words are all-reduced between its parts, so that every rank derives the same dt, event ids and forcing window
+        (the reference gathers 18 fields to rank 0 for it, adaptive_time_stepping_dist_safe.py:6-26)."""
+        b = self.backend
+        b.phase1()
+        self._exchange(0)
+        b.phase2()
+        self._exchange(1)
+        b.adaptive_dt_finish()
+
+
+def phases_for(ctx, one_exchange=True):
+    """The PhasedStepper backend of a context: HipPhases on the context's device for `_native.Context`; a context that brings its
+    own (the tests' device double) says so through `make_phases`."""
+    if hasattr(ctx, "make_phases"):
+        return ctx.make_phases(one_exchange=one_exchange)
+    import os
+
+    import torch
+
+    return HipPhases(ctx, torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))), one_exchange=one_exchange)
+
 
 class HipPhases:
     """Adapter of a `_native.Context` to PhasedStepper; the exchange buffers are torch tensors on
@@ -237,6 +260,9 @@ class HipPhases:
 
     def phase3(self):
         self.ctx.step_phase3(-1)
+
+    def adaptive_dt_finish(self):
+        self.ctx.call("rh_adaptive_dt_finish")
 
     def predicate_buffer(self, word):
         self.ctx.predicates_expand(word, self.buf[word].data_ptr())

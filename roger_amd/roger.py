@@ -17,7 +17,7 @@ it uploads vs.PREC/TA/PET/YEAR/MONTH/DOY once and advances with rh_run_steps, no
 """
 import abc
 
-from . import diagnostics, distributed, logger, runtime_settings as rs
+from . import diagnostics, distributed, logger, restart, runtime_settings as rs, runtime_state as rst
 from . import settings as settings_mod
 from .routines import is_roger_routine, roger_routine, run_native
 from .state import RogerState
@@ -116,8 +116,11 @@ class RogerSetup(metaclass=abc.ABCMeta):
                 for setting, value in self.override_settings.items():
                     setattr(state.settings, setting, value)
             settings_mod.check_setting_conflicts(state.settings)
-            distributed.validate_decomposition(state.settings.nx, state.settings.ny, rs.num_proc,
-                                               rs.num_proc[0] * rs.num_proc[1])
+            # against the REAL size of the process group (roger/roger.py:292, distributed.py:121-138): a run started on N ranks
+            # without num_proc=(N, 1) must fail here instead of stepping N uncoupled copies
+            distributed.validate_decomposition(state.settings.nx, state.settings.ny, rs.num_proc, rst.proc_num)
+            if rst.proc_num > 1 and rs.num_proc[1] != 1:
+                raise NotImplementedError("the hip backend splits the grid along x only: num_proc = (N, 1) (BASELINE.json north_star)")
             state.initialize_variables()
             offline = state.settings.enable_offline_transport
             self.set_grid(state)
@@ -140,6 +143,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
             self.set_boundary_conditions_setup(state)
             self.set_boundary_conditions(state)
             self.set_forcing_setup(state)
+            restart.read_restart(state)   # roger/roger.py:324-326
         self._setup_done = True
         if not state.settings.enable_offline_transport:   # roger/roger.py:324-327
             with state.settings.unlock():
@@ -174,6 +178,9 @@ class RogerSetup(metaclass=abc.ABCMeta):
         self._ensure_setup_done()
         if state.settings.enable_offline_transport:
             return self._step_offline_transport(state)
+        if state.settings.restart_frequency > 0:
+            with state.timers["diagnostics"]:
+                restart.write_restart(state)   # roger/roger.py:385-386
         with state.timers["main"]:
             with state.timers["read data"]:
                 self.read_data(state)
@@ -182,7 +189,14 @@ class RogerSetup(metaclass=abc.ABCMeta):
             with state.timers["forcing"]:
                 self.set_forcing(state)
             with state.timers["adaptive time-stepping"]:
-                run_native(state, "rh_adaptive_dt", ("prec", "ta", "pet", "pet_res"))
+                if rst.proc_num > 1:
+                    # dt is ONE scalar for the whole domain: the ranks agree on the predicates before it is derived
+                    # (adaptive_time_stepping_dist_safe.py:6-26 does it through rank 0)
+                    state.variables.flush_to_device()
+                    self._stepper(one_exchange=False).adaptive_dt()
+                    state.variables.mark_device_newer(("prec", "ta", "pet", "pet_res"))
+                else:
+                    run_native(state, "rh_adaptive_dt", ("prec", "ta", "pet", "pet_res"))
             with state.timers["time-variant parameters"]:
                 self.set_parameters(state)
             with state.timers["processes"]:
@@ -228,8 +242,12 @@ class RogerSetup(metaclass=abc.ABCMeta):
         settings = self.state.settings
         runlen = settings.runlen if settings.warmup_done else settings.runlen_warmup   # roger/roger.py:541-546
         start_time = vs.time
-        while vs.time - start_time < runlen:
-            self.step(self.state)
+        try:
+            while vs.time - start_time < runlen:
+                self.step(self.state)
+        finally:
+            if settings.write_restart and not settings.enable_offline_transport:   # roger/roger.py:577-579
+                restart.write_restart(self.state, force=True)
         (self.state.sas_context or self.state.backend_context).sync()
         diagnostics.close(self.state)
 
@@ -245,12 +263,30 @@ class RogerSetup(metaclass=abc.ABCMeta):
             dict(PREC=vs.PREC, TA=vs.TA, PET=vs.PET, YEAR=vs.YEAR, MONTH=vs.MONTH, DOY=vs.DOY))
         self._device_hooks = True
 
+    def _stepper(self, one_exchange):
+        key = "_stepper_one" if one_exchange else "_stepper_three"
+        if getattr(self, key, None) is None:
+            setattr(self, key, distributed.PhasedStepper(distributed.phases_for(self.state.backend_context, one_exchange=one_exchange)))
+        return getattr(self, key)
+
     def run_device(self, nsteps):
         if not getattr(self, "_device_hooks", False):
             self.enable_device_hooks()
         vs = self.state.variables
         vs.flush_to_device()
-        self.state.backend_context.run_steps(nsteps)
+        ctx = self.state.backend_context
+        if rst.proc_num > 1:
+            # several ranks: one exchange of the summary word per step -- from C over RCCL where the context offers it
+            # (rh_comm_init + rh_run_steps_dist), through torch.distributed otherwise
+            if hasattr(ctx, "run_steps_dist"):
+                if not getattr(self, "_comm_ready", False):
+                    ctx.comm_init_torch()
+                    self._comm_ready = True
+                ctx.run_steps_dist(nsteps)
+            else:
+                self._stepper(one_exchange=True).run(nsteps)
+        else:
+            ctx.run_steps(nsteps)
         vs.mark_device_newer()
         if getattr(self.state, "_diag_active", None):
             diagnostics.output(self.state, final=True)

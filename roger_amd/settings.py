@@ -43,7 +43,10 @@ _GROUPS = {
         "enable_offline_transport": (False, bool), "enable_groundwater_boundary": (False, bool),
         "enable_groundwater": (False, bool), "enable_routing_1D": (False, bool), "enable_routing_2D": (False, bool),
         "enable_macropore_lower_boundary_condition": (False, bool), "enable_adaptive_time_stepping": (False, bool),
-        "warmup_done": (False, bool), "restart_input_filename": (None, optional(str)),
+        "warmup_done": (False, bool),
+        # roger/settings.py:117-133
+        "write_restart": (False, bool), "restart_input_filename": (None, optional(str)),
+        "restart_output_filename": ("{identifier}_{itt:0>4d}.restart.h5", optional(str)), "restart_frequency": (0, float),
     },
 }
 SETTINGS = {name: Setting(default, type_, group) for group, table in _GROUPS.items() for name, (default, type_) in table.items()}

@@ -164,6 +164,12 @@ class OracleContext:
     def diag_steps(self, slot):
         return int(self._diag["steps"][int(slot)])
 
+    def diag_upload(self, name, slot, values):
+        self._diag["data"][name][int(slot)] = np.asarray(values, dtype=np.float64).reshape(-1)
+
+    def diag_set_slot_state(self, slot, steps, t_start, t_end):
+        self._diag["steps"][int(slot)], self._diag["t0"][int(slot)], self._diag["t1"][int(slot)] = int(steps), int(t_start), int(t_end)
+
     def _hooks(self):
         s, F = self.st.scal, self.series
         if s.time % 86400 == 0 and s.itt_forc + 144 <= len(F["PREC"]):
@@ -249,6 +255,13 @@ class OracleContext:
             self._hooks()
             self.step(-1)
 
+    def make_phases(self, one_exchange=True):
+        return OraclePhases(self, one_exchange=one_exchange)
+
+    def adaptive_dt_finish(self):
+        ob.lib().oc_adt_finish(self.st._ptrs, C.c_int64(self.n), *self._forc(), C.byref(self.st.scal),
+                               C.byref(self.st.settings), C.c_uint64(self.words[0]), C.c_uint64(self.words[1]))
+
 
 class OraclePhases:
     """PhasedStepper backend over an OracleContext, exchanging the predicate words as 64 int32
@@ -276,6 +289,9 @@ class OraclePhases:
 
     def phase3(self):
         self.ctx.step_phase3(-1)
+
+    def adaptive_dt_finish(self):
+        self.ctx.adaptive_dt_finish()
 
     def predicate_buffer(self, word):
         import torch

@@ -9,10 +9,11 @@ from roger_amd.core.operators import at, numpy as npx, update
 from roger_amd.models.svat import SVATSetup
 
 
-def make_model(params, forcing, ndays, lateral=False):
+def make_model(params, forcing, ndays, lateral=False, global_shape=None):
+    """global_shape: (nx, ny) of the whole domain when `params` holds this rank's slab only (num_proc = (N, 1))."""
     from roger_amd.models.oned import ONEDSetup
 
-    nx, ny = params["lu_id"].shape
+    nx, ny = global_shape or params["lu_id"].shape
     F = forcing
     Base = ONEDSetup if lateral else SVATSetup
 

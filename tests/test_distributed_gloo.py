@@ -148,3 +148,95 @@ def test_two_ranks_reproduce_single_domain(tmp_path, oracle, case, nsteps, one_e
         gs = g["scal"][nsteps - 1]
         np.testing.assert_array_equal(d["scal"], [gs[0], gs[1], gs[2], gs[3], gs[9], gs[6], gs[7]])
     compare(got, ref, names, what=f"{case}: 2 ranks vs single-domain reference, step {nsteps}")
+
+
+def _setup_worker(rank, world, port, case, ndays, out_dir, device_hooks):
+    """RogerSetup on two ranks (num_proc = (2, 1)): the hook-preserving run() and run_device(), the device replaced by the double."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from roger_amd import runtime_settings
+
+    runtime_settings.update(num_proc=(world, 1))     # before the core is imported (locked afterwards, as in the reference)
+    import oracle_binding as ob
+    import oracle_context
+    import svat_scripts as S
+    from golden_util import load_case
+    from roger_amd import _native
+    from roger_amd.distributed import get_chunk_slices
+
+    _native.Context = oracle_context.OracleContext
+    _native.plane_table = lambda: list(zip(ob.plane_names(), ob.plane_is_int()))
+    g, names, forcing = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    (gx, gy), _ = get_chunk_slices(nx, ny, (world, 1), rank)
+    p = {k: v[gx, gy] for k, v in S.params_from_golden(g, names).items()}
+    model = S.make_model(p, forcing, ndays, global_shape=(nx, ny))
+    model.setup()
+    vs = model.state.variables
+    assert np.asarray(vs.lu_id).shape == (nx // world + 4, ny + 4)
+    if device_hooks:
+        steps = int(np.sum(g["scal"][:, 1] <= ndays * 86400))
+        model.run_device(steps)
+    else:
+        model.run()
+    snap = S.snapshot_from_vs(vs, names)
+    sel = np.arange(nx * ny).reshape(nx, ny)[gx, gy].ravel()
+    np.savez(os.path.join(out_dir, f"setup{rank}.npz"), snap=snap, sel=sel,
+             scal=np.array([int(vs.itt), int(vs.time), int(vs.dt_secs), int(vs.itt_day), int(vs.event_id_counter)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_hooks", [False, True])
+def test_roger_setup_on_two_ranks(tmp_path, oracle, device_hooks):
+    """`RogerSetup.run()` (user hooks on the host, rh_adaptive_dt in three parts with the predicate words all-reduced in between) and
+    `run_device()` (one exchange of the summary word per step) with num_proc = (2, 1) reproduce the single-domain reference run:
+    every rank derives the same dt, event ids and forcing window.  (The reference decides dt through rank 0,
+    adaptive_time_stepping_dist_safe.py:6-26.)  A world size that does not match num_proc is refused (roger/distributed.py:128-131)."""
+    from golden_util import compare, load_case
+
+    case, ndays = "svat_hetero_combo", 24    # the whole golden run: its last step carries a snapshot
+    port = 29500 + (os.getpid() % 2000) + 11 + int(device_hooks)
+    mp.spawn(_setup_worker, args=(2, port, case, ndays, str(tmp_path), device_hooks), nprocs=2, join=True)
+    g, names, _ = load_case(case)
+    nsteps = int(np.sum(g["scal"][:, 1] <= ndays * 86400))
+    key = f"s{nsteps:05d}"
+    gs = g["scal"][nsteps - 1]
+    got = None
+    for r in range(2):
+        d = np.load(tmp_path / f"setup{r}.npz")
+        np.testing.assert_array_equal(d["scal"], [gs[0], gs[1], gs[2], gs[3], gs[6]], err_msg=f"rank {r}")
+        if key in g.files:
+            got = np.full_like(g[key], np.nan) if got is None else got
+            got[:, d["sel"]] = d["snap"]
+    if got is not None:
+        compare(got, g[key], names, what=f"RogerSetup on 2 ranks, step {nsteps}")
+
+
+def _mismatch_worker(rank, world, port):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_binding as ob
+    import oracle_context
+    import svat_scripts as S
+    from golden_util import load_case
+    from roger_amd import _native
+
+    _native.Context = oracle_context.OracleContext
+    _native.plane_table = lambda: list(zip(ob.plane_names(), ob.plane_is_int()))
+    g, names, forcing = load_case("svat_uniform_rain")
+    model = S.make_model(S.params_from_golden(g, names), forcing, 1)     # num_proc left at (1, 1) on two ranks
+    try:
+        model.setup()
+    except RuntimeError as e:
+        assert "does not match size of communicator" in str(e)
+    else:
+        raise AssertionError("setup() accepted num_proc = (1, 1) on two ranks")
+    dist.destroy_process_group()
+
+
+def test_world_size_must_match_num_proc():
+    mp.spawn(_mismatch_worker, args=(2, 29500 + (os.getpid() % 2000) + 17), nprocs=2, join=True)

@@ -137,29 +137,54 @@ def test_scope_errors(oracle_backend):
 
 
 def test_restart_round_trip(tmp_path, monkeypatch):
-    """write_restart after n steps, read_restart into a fresh model, continue: identical to the uninterrupted run
-    (roger/restart.py counterpart with an .npz container)."""
+    """roger/restart.py on the hip backend: the file the model writes through its settings (restart_output_filename with format
+    syntax, restart_frequency; write_restart at the end of run()) is an HDF5 file with the group "core" in the reference's layout;
+    a fresh model that names it in restart_input_filename reads it at the end of setup() and continues identically to the
+    uninterrupted run."""
     import oracle_context as OC
     from golden_util import load_case
-    from roger_amd import _native, restart
+    from roger_amd import _native, h5lite, restart
     from svat_scripts import make_model, params_from_golden
 
     monkeypatch.setattr(_native, "Context", OC.OracleContext)
+    monkeypatch.chdir(tmp_path)
     g, names, forcing = load_case("svat_hetero_combo")
     p = params_from_golden(g, names)
-    a, b = make_model(p, forcing, 2), make_model(p, forcing, 2)
+    a = make_model(p, forcing, 2)
+    a.override_settings = dict(write_restart=True, restart_output_filename="{identifier}_{itt:0>4d}.restart.h5")
     a.setup()
+    a.run()                                   # two days; the restart file is written in run()'s finally clause
+    n = int(a.state.variables.itt)
+    fname = tmp_path / f"GoldenSVAT_{n:0>4d}.restart.h5"
+    assert fname.is_file()
+    groups = h5lite.read(fname)
+    core = groups["core"]
+    nx, ny = (int(v) for v in g["nx_ny"])
+    assert core["S_rz"].shape == (nx + 4, ny + 4, 2) and core["lu_id"].shape == (nx + 4, ny + 4) and core["itt"].shape == ()
+    assert int(core["itt"]) == n and int(core["time"]) == 2 * 86400
+    have = [k for k in restart.REFERENCE_RESTART_VARIABLES if k in a.state.var_meta]
+    assert len(have) > 120 and all(k in core for k in have)
+    np.testing.assert_array_equal(core["S_rz"], np.asarray(a.state.variables.S_rz))
+    # a fresh model restarts from the file at the end of its setup() ...
+    b = make_model(p, forcing, 4)
+    b.override_settings = dict(restart_input_filename=str(fname))
     b.setup()
-    for _ in range(40):
-        a.step(a.state)
-    f = restart.write_restart(a.state, tmp_path / "ckpt")
-    restart.read_restart(b.state, f)
-    assert b.state.variables.itt == a.state.variables.itt and b.state.variables.time == a.state.variables.time
-    for _ in range(25):
-        a.step(a.state)
-        b.step(b.state)
-    for nm in ("S", "theta_rz", "z_wf", "q_ss", "swe", "event_id", "time_event0", "itt_forc"):
-        np.testing.assert_array_equal(np.asarray(getattr(a.state.variables, nm)), np.asarray(getattr(b.state.variables, nm)), err_msg=nm)
+    assert b.state.variables.itt == n and b.state.variables.time == 2 * 86400
+    # ... and continues like the uninterrupted run
+    c = make_model(p, forcing, 4)
+    c.setup()
+    c.run()
+    with b.state.settings.unlock():
+        b.state.settings.runlen = 2 * 86400   # two more days
+    b.run()
+    assert b.state.variables.itt == c.state.variables.itt
+    for nm in ("S", "theta_rz", "z_wf", "q_ss", "swe", "event_id", "time_event0", "itt_forc", "prec", "ta", "z0", "S_dep"):
+        np.testing.assert_array_equal(np.asarray(getattr(b.state.variables, nm)), np.asarray(getattr(c.state.variables, nm)), err_msg=nm)
+    # a missing file is an error, as in the reference (restart.py:84-85), not a silent cold start
+    d = make_model(p, forcing, 1)
+    d.override_settings = dict(restart_input_filename=str(tmp_path / "nothing.h5"))
+    with pytest.raises(IOError, match="not found"):
+        d.setup()
 
 
 def test_forcing_from_text_inputs():
