@@ -214,6 +214,14 @@ int rh_step_finish(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-sid
  * per step on the multi-GPU path. */
 int rh_step_summary_expand(rh_ctx *ctx, int32_t *dev_dst64);
 int rh_step_finish_compress(rh_ctx *ctx, int monthly, const int32_t *dev_src64);
+/* Several meteorological stations (settings.enable_distributed_input: vs.PREC_DIST / TA_DIST / PET_DIST (n_stations, t_forc) and the
+ * per-cell vs.station_id, roger/variables.py:882-916, 3522, 4138, 6383-6402; the distributed models' set_forcing picks, per cell, the
+ * series of its station before applying the weights, roger/bmimodels/svat_dist/svat_dist.py:274-310).  prec / ta / pet: (n_stations,
+ * nitt_forc) row-major; station_index: per cell the ROW of its station (0-based; < 0: no station, the cell sees zeros, like a cell whose
+ * vs.station_id matches no entry of vs.station_ids).  The device-side hooks stage every station's day at midnight; each column forms its
+ * own day from its station's rows and its weights (rh_set_forcing_weights; neutral if none were set).  Replaces rh_set_forcing_series. */
+int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, const double *pet, const int64_t *year, const int64_t *month,
+                            const int64_t *doy, int64_t nitt_forc, int n_stations, const int32_t *station_index);
 /* Device-side `set_forcing` + `set_parameters` hooks (needs rh_set_forcing_series); runs before
  * phase 1. */
 int rh_hooks_phase(rh_ctx *ctx);

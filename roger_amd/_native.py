@@ -92,6 +92,7 @@ def load():
     lib.rh_step_finish.argtypes = [vp, i32]
     lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.rh_step_mode.argtypes = [vp]
+    lib.rh_set_forcing_stations.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.rh_diag_upload.argtypes = [vp, i32, i32, vp, C.c_size_t]
     lib.rh_diag_set_slot_state.argtypes = [vp, i32, i64, i64, i64]
     lib.rh_comm_unique_id.argtypes = [vp]
@@ -342,7 +343,7 @@ DECLARED_SYMBOLS = (
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
-    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
+    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
 )
 
 
@@ -459,6 +460,20 @@ class Context:
             raise ValueError("forcing vectors differ in length")
         self._check(self._lib.rh_set_forcing_series(self._h, *[a.ctypes.data_as(C.c_void_p) for a in f + c], n),
                     "rh_set_forcing_series")
+
+    def set_forcing_stations(self, F, station_index):
+        """F: PREC, TA, PET as (n_stations, nitt_forc) float64 and YEAR, MONTH, DOY (nitt_forc,) int64; station_index: per cell the row
+        of its station (< 0: none).  settings.enable_distributed_input (roger/bmimodels/svat_dist/svat_dist.py:274-310)."""
+        f = [np.ascontiguousarray(F[k], dtype=np.float64) for k in ("PREC", "TA", "PET")]
+        c = [np.ascontiguousarray(F[k], dtype=np.int64) for k in ("YEAR", "MONTH", "DOY")]
+        ns, nitt = f[0].shape
+        if any(a.shape != (ns, nitt) for a in f) or any(a.shape != (nitt,) for a in c):
+            raise ValueError("station forcing: PREC / TA / PET must be (n_stations, nitt_forc), the calendar (nitt_forc,)")
+        idx = np.ascontiguousarray(station_index, dtype=np.int32).reshape(-1)
+        if idx.size != self.n or idx.max() >= ns:
+            raise ValueError("station_index: one row index per cell, below the number of stations")
+        self._check(self._lib.rh_set_forcing_stations(self._h, *[a.ctypes.data_as(C.c_void_p) for a in f + c], nitt, ns,
+                                                      idx.ctypes.data_as(C.c_void_p)), "rh_set_forcing_stations")
 
     def run_steps(self, nsteps):
         self._check(self._lib.rh_run_steps(self._h, int(nsteps)), "rh_run_steps")

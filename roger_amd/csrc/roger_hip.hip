@@ -82,7 +82,8 @@ struct DevState {
     int *dt_log;
     int dt_log_cap, dt_log_n;
     double forc[3][RH_SLOTS_PER_DAY];  // shared forcing of the day: prec, ta, pet
-    const double *forc_cell[3];        // per-cell forcing (n, 144) or null
+    const double *forc_cell[3];        // per-cell forcing, TRANSPOSED on upload to (144, n): slot s of column i at [s * n + i], unit stride over
+                                       // the columns (a wave reads 512 contiguous bytes per slot instead of 64 values 1152 bytes apart); or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
     int per_cell;
     // whole forcing series resident on the device (rh_set_forcing_series): 10-minute PREC/TA/PET
@@ -92,6 +93,12 @@ struct DevState {
     int64_t nitt_forc;
     int monthly;                       // set_parameters' month-change test, evaluated on the device
     const double *weights[3];          // per-cell prec_weight, ta_offset, pet_weight (rh_set_forcing_weights) or null
+    // several meteorological stations (settings.enable_distributed_input, roger/variables.py:6383-6402): the resident series are
+    // (n_stations, nitt_forc) each, a column takes the series of station station_idx[column] (< 0: none, all zeros); the day of
+    // every station is staged in forc_multi (3, n_stations, 144) at midnight
+    int n_stations;
+    const int *station_idx;
+    double *forc_multi;
 
     const double *mlms;                // lut_mlms rows (oneD model), device copy
     int64_t mlms_rows;
@@ -108,6 +115,9 @@ struct rh_ctx {
     bool own_stream;
     double *forc_cell_buf[3];
     double *weight_buf[3];
+    int *station_buf;
+    double *forc_multi_buf;
+    double *transpose_buf;   // staging of one (n, 144) per-cell forcing array before its transposition
     double *agg_cell_buf;
     void *series_buf;
     double *mlms_buf;
@@ -319,6 +329,13 @@ RH_DEV void hooks_set_forcing(DevState *D) {
     __syncthreads();  // everybody has read S before thread 0 changes it
     if (have && threadIdx.x < RH_SLOTS_PER_DAY)
         for (int k = 0; k < 3; ++k) D->forc[k][threadIdx.x] = D->series[k][i0 + threadIdx.x];
+    if (have && D->n_stations > 0) {   // the series are (n_stations, nitt_forc): the day of every station
+        const int S = D->n_stations;
+        for (int q = threadIdx.x; q < 3 * S * RH_SLOTS_PER_DAY; q += RH_BLOCK) {
+            const int v = q / (S * RH_SLOTS_PER_DAY), r = q % (S * RH_SLOTS_PER_DAY), st = r / RH_SLOTS_PER_DAY, j = r % RH_SLOTS_PER_DAY;
+            D->forc_multi[q] = D->series[v][(size_t)st * D->nitt_forc + i0 + j];
+        }
+    }
     if (threadIdx.x == 0) {
         if (have) {
             S.itt_day = 0;
@@ -345,6 +362,25 @@ RH_DEV void stage_day(const DevState *D, DaySeries &s) {
     for (int k = threadIdx.x; k < 3 * RH_SLOTS_PER_DAY; k += RH_BLOCK) s.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
     __syncthreads();
 }
+// The day's series as a column sees it: the one shared series staged in LDS, or -- with several stations -- its station's rows of
+// forc_multi (a table of 3 x n_stations x 144 values: cache-resident); a column without a station reads zeros.
+struct DayView {
+    const DaySeries *lds;
+    const double *multi;
+    int S, st;
+    RH_DEV double operator()(int v, int k) const {
+        if (!multi) return lds->f[v][k];
+        return st < 0 ? 0.0 : multi[((size_t)v * S + st) * RH_SLOTS_PER_DAY + k];
+    }
+};
+RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i) {
+    DayView d;
+    d.lds = &lds;
+    d.multi = D->n_stations > 0 ? D->forc_multi : nullptr;
+    d.S = D->n_stations;
+    d.st = D->n_stations > 0 ? D->station_idx[i] : 0;
+    return d;
+}
 // start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
 __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D, int force_daily) {
     const Consts K = D->K;
@@ -366,11 +402,12 @@ __global__ __launch_bounds__(RH_BLOCK) void k_pred1(Arena a, DevState *D, int fo
         if (per_cell && weighted) {
             if (daily) {
                 const double pw = D->weights[0][i], toff = D->weights[1][i];
-                for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(day.f[0][k] * pw, day.f[1][k] + toff, K);
+                const DayView F = day_view(D, day, i);
+                for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(F(0, k) * pw, F(1, k) + toff, K);
             }
         } else if (per_cell) {
-            const double *p = D->forc_cell[0] + i * RH_SLOTS_PER_DAY, *t = D->forc_cell[1] + i * RH_SLOTS_PER_DAY;
-            for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p[k], t[k], K);
+            const double *p = D->forc_cell[0] + i, *t = D->forc_cell[1] + i;   // (144, n): stride n between the slots
+            for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p[(size_t)k * a.n], t[(size_t)k * a.n], K);
         }
     }
     if (per_cell && weighted) {   // keep / reuse the day's forcing bits of this workgroup
@@ -522,11 +559,15 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int
     const bool daily = !weighted || force_daily || D->S.itt_day == 0;
     if (weighted) {
         const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
-        forcing_aggregates_of([&](int k) { return day.f[0][k] * pw; }, [&](int k) { return day.f[1][k] + toff; },
-                              [&](int k) { return day.f[2][k] * ew; }, D->S.itt_day, agg, daily);
-    } else
-        forcing_aggregates(D->forc_cell[0] + i * RH_SLOTS_PER_DAY, D->forc_cell[1] + i * RH_SLOTS_PER_DAY,
-                           D->forc_cell[2] + i * RH_SLOTS_PER_DAY, D->S.itt_day, agg);
+        const DayView F = day_view(D, day, i);
+        forcing_aggregates_of([&](int k) { return F(0, k) * pw; }, [&](int k) { return F(1, k) + toff; },
+                              [&](int k) { return F(2, k) * ew; }, D->S.itt_day, agg, daily);
+    } else {
+        const double *p = D->forc_cell[0] + i, *t = D->forc_cell[1] + i, *e = D->forc_cell[2] + i;
+        const size_t n = (size_t)a.n;
+        forcing_aggregates_of([&](int k) { return p[k * n]; }, [&](int k) { return t[k * n]; }, [&](int k) { return e[k * n]; },
+                              D->S.itt_day, agg);
+    }
     for (int k = daily ? 0 : 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
@@ -1300,6 +1341,26 @@ __global__ __launch_bounds__(RH_BLOCK) void k_plane_scatter(Arena a, int plane, 
     if (i < a.n) *rh_cell<T>(a, plane, i) = src[i];
 }
 
+// (n, 144) -> (144, n): a per-cell forcing array as the host hands it over (the reference's vs.prec_day[x, y, :]) into the layout the
+// kernels read with unit stride over the columns.  One 64 x 64 tile per workgroup through LDS, both sides coalesced.
+__global__ __launch_bounds__(RH_BLOCK) void k_transpose_forcing(const double *src, double *dst, int64_t n) {
+    __shared__ double tile[64][65];
+    const int64_t c0 = (int64_t)blockIdx.x * 64;   // first column of the tile
+    const int s0 = blockIdx.y * 64;                // first slot
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += RH_BLOCK / 64) {   // rows = columns of the grid, contiguous slots
+        const int64_t c = c0 + r;
+        const int sl = s0 + tx;
+        tile[r][tx] = (c < n && sl < RH_SLOTS_PER_DAY) ? src[c * RH_SLOTS_PER_DAY + sl] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += RH_BLOCK / 64) {   // rows = slots, contiguous columns
+        const int sl = s0 + r;
+        const int64_t c = c0 + tx;
+        if (c < n && sl < RH_SLOTS_PER_DAY) dst[(size_t)sl * n + c] = tile[tx][r];
+    }
+}
+
 // X_m1 = X for every rotation pair of after_timestep: what the lazy steps left undone (materialise_m1)
 __global__ __launch_bounds__(RH_BLOCK) void k_rotate_all(Arena a) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -1506,6 +1567,9 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
     for (auto &b : ctx->weight_buf) b = nullptr;
+    ctx->station_buf = nullptr;
+    ctx->forc_multi_buf = nullptr;
+    ctx->transpose_buf = nullptr;
     ctx->agg_cell_buf = nullptr;
     ctx->series_buf = nullptr;
     ctx->mlms_buf = nullptr;
@@ -1654,6 +1718,9 @@ void rh_destroy(rh_ctx *ctx) {
     for (auto &b : ctx->weight_buf)
         if (b) (void)hipFree(b);
     if (ctx->agg_cell_buf) (void)hipFree(ctx->agg_cell_buf);
+    if (ctx->station_buf) (void)hipFree(ctx->station_buf);
+    if (ctx->forc_multi_buf) (void)hipFree(ctx->forc_multi_buf);
+    if (ctx->transpose_buf) (void)hipFree(ctx->transpose_buf);
     if (ctx->series_buf) (void)hipFree(ctx->series_buf);
     if (ctx->mlms_buf) (void)hipFree(ctx->mlms_buf);
     if (ctx->diag_buf) (void)hipFree(ctx->diag_buf);
@@ -1810,9 +1877,13 @@ int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day
             HIPCHK(ctx, hipMemcpyAsync(ctx->dev->forc[k], src[k], sizeof(double) * RH_SLOTS_PER_DAY, hipMemcpyHostToDevice, ctx->stream));
     } else {
         const size_t bytes = sizeof(double) * RH_SLOTS_PER_DAY * (size_t)ctx->n;
-        for (int k = 0; k < 3; ++k) {
+        if (!ctx->transpose_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->transpose_buf, bytes));
+        for (int k = 0; k < 3; ++k) {   // (n, 144) from the host -> (144, n) on the device
             if (!ctx->forc_cell_buf[k]) HIPCHK(ctx, hipMalloc((void **)&ctx->forc_cell_buf[k], bytes));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->forc_cell_buf[k], src[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->transpose_buf, src[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_transpose_forcing, dim3((unsigned)((ctx->n + 63) / 64), (RH_SLOTS_PER_DAY + 63) / 64), dim3(RH_BLOCK), 0, ctx->stream,
+                               (const double *)ctx->transpose_buf, ctx->forc_cell_buf[k], ctx->n);
+            CHECK_LAUNCH(ctx);
         }
         HIPCHK(ctx, hipMemcpyAsync(ctx->dev->forc_cell, ctx->forc_cell_buf, sizeof(double *) * 3, hipMemcpyHostToDevice, ctx->stream));
         if (!ctx->agg_cell_buf) {
@@ -2124,10 +2195,55 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->calendar, cp, sizeof(cp), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->nitt_forc, &nitt_forc, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->n_stations, 0, sizeof(int), ctx->stream));   // one series for all columns
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
     ctx->pending_valid = false;
     ctx->per_cell = false;
+    return RH_OK;
+}
+
+int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, const double *pet, const int64_t *year, const int64_t *month,
+                            const int64_t *doy, int64_t nitt_forc, int n_stations, const int32_t *station_index) {
+    if (!ctx || !prec || !ta || !pet || !year || !month || !doy || !station_index || nitt_forc <= 0 || n_stations < 1)
+        return ctx ? fail(ctx, RH_ERR_ARG, "rh_set_forcing_stations: bad arguments") : RH_ERR_ARG;
+    if (n_stations > 4096) return fail(ctx, RH_ERR_ARG, "rh_set_forcing_stations: at most 4096 stations");
+    // the series: (n_stations, nitt_forc) per variable, then the calendar
+    const size_t nb1 = sizeof(double) * (size_t)nitt_forc, nbS = nb1 * (size_t)n_stations;
+    if (ctx->series_buf) HIPCHK(ctx, hipFree(ctx->series_buf));
+    ctx->series_buf = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->series_buf, 3 * nbS + 3 * nb1));
+    char *base = (char *)ctx->series_buf;
+    const void *fsrc[3] = {prec, ta, pet}, *csrc[3] = {year, month, doy};
+    for (int k = 0; k < 3; ++k) HIPCHK(ctx, hipMemcpyAsync(base + k * nbS, fsrc[k], nbS, hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < 3; ++k) HIPCHK(ctx, hipMemcpyAsync(base + 3 * nbS + k * nb1, csrc[k], nb1, hipMemcpyHostToDevice, ctx->stream));
+    const double *sp[3] = {(double *)base, (double *)(base + nbS), (double *)(base + 2 * nbS)};
+    const int64_t *cp[3] = {(int64_t *)(base + 3 * nbS), (int64_t *)(base + 3 * nbS + nb1), (int64_t *)(base + 3 * nbS + 2 * nb1)};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dev->series, sp, sizeof(sp), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dev->calendar, cp, sizeof(cp), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->nitt_forc, &nitt_forc, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    // the station of every column, the staging table of a day
+    if (!ctx->station_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->station_buf, sizeof(int) * (size_t)ctx->n));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->station_buf, station_index, sizeof(int) * (size_t)ctx->n, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->forc_multi_buf) HIPCHK(ctx, hipFree(ctx->forc_multi_buf));
+    ctx->forc_multi_buf = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->forc_multi_buf, sizeof(double) * 3 * (size_t)n_stations * RH_SLOTS_PER_DAY));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->station_idx, &ctx->station_buf, sizeof(int *), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->forc_multi, &ctx->forc_multi_buf, sizeof(double *), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->n_stations, &n_stations, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->forcing_set = true;
+    ctx->pending_valid = false;
+    // the station series reach the columns through the per-cell (weighted) path: neutral weights unless the caller sets some
+    if (!ctx->weight_buf[0]) {
+        std::vector<double> one((size_t)ctx->n, 1.0), zero((size_t)ctx->n, 0.0);
+        const int rc = rh_set_forcing_weights(ctx, one.data(), zero.data(), one.data());
+        if (rc) return rc;
+    }
+    ctx->per_cell = true;
+    ctx->agg_daily_stale = true;
+    ctx->pred_daily_stale = true;
     return RH_OK;
 }
 

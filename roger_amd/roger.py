@@ -257,10 +257,25 @@ class RogerSetup(metaclass=abc.ABCMeta):
         vs.DOY) to the device; `run_device` then performs the benchmark's set_forcing /
         set_parameters hooks there."""
         self._ensure_setup_done()
+        import numpy as np
+
         vs = self.state.variables
+        ctx = self.state.backend_context
         vs.flush_to_device()
-        self.state.backend_context.set_forcing_series(
-            dict(PREC=vs.PREC, TA=vs.TA, PET=vs.PET, YEAR=vs.YEAR, MONTH=vs.MONTH, DOY=vs.DOY))
+        weights = [np.asarray(getattr(vs, k))[2:-2, 2:-2].reshape(-1) for k in ("prec_weight", "ta_offset", "pet_weight")]
+        neutral = (weights[0] == 1).all() and (weights[1] == 0).all() and (weights[2] == 1).all()
+        if self.state.settings.enable_distributed_input:
+            # several stations: vs.PREC_DIST / TA_DIST / PET_DIST (n_stations, t_forc), vs.station_id per cell, vs.station_ids
+            # (roger/bmimodels/svat_dist/svat_dist.py:200-211, 261-263, 280-293)
+            ids = np.asarray(vs.station_ids)
+            cell = np.asarray(vs.station_id)[2:-2, 2:-2].reshape(-1)
+            index = np.array([int(np.where(ids == c)[0][0]) if c in ids else -1 for c in cell], dtype=np.int32)
+            ctx.set_forcing_stations(dict(PREC=vs.PREC_DIST, TA=vs.TA_DIST, PET=vs.PET_DIST, YEAR=vs.YEAR, MONTH=vs.MONTH, DOY=vs.DOY), index)
+            ctx.set_forcing_weights(*weights)
+        else:
+            ctx.set_forcing_series(dict(PREC=vs.PREC, TA=vs.TA, PET=vs.PET, YEAR=vs.YEAR, MONTH=vs.MONTH, DOY=vs.DOY))
+            if not neutral:   # eberbaechle/svat_distributed/svat.py:169-186, 276-296
+                ctx.set_forcing_weights(*weights)
         self._device_hooks = True
 
     def _stepper(self, one_exchange):

@@ -17,7 +17,7 @@ _GROUPS = {
     "run": {   # grid, run length, clock
         "identifier": ("UNNAMED", str), "nx": (1, int), "ny": (1, int), "nz": (1, int), "dx": (1, int),
         "dy": (1, int), "dz": (1, int), "nitt": (1, int), "nitt_forc": (1, int), "ages": (1, int), "nages": (2, int),
-        "nsas": (8, int), "runlen": (0.0, float), "runlen_warmup": (0.0, float), "x_origin": (0, float),
+        "nsas": (8, int), "nstations": (2, int), "runlen": (0.0, float), "runlen_warmup": (0.0, float), "x_origin": (0, float),
         "y_origin": (0, float), "time_origin": ("1900-01-01 00:00:00", str), "output_frequency": (0.0, float),
     },
     "const": {   # constants the kernels use (device copy: rh_config)
@@ -52,7 +52,7 @@ _GROUPS = {
 SETTINGS = {name: Setting(default, type_, group) for group, table in _GROUPS.items() for name, (default, type_) in table.items()}
 
 _UNSUPPORTED_SWITCHES = (
-    "enable_distributed_input", "enable_film_flow", "enable_crop_phenology",
+    "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
     "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
     "enable_nitrate",

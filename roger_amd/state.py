@@ -349,7 +349,7 @@ class RogerState:
             self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)
             return
         if self._var_meta is None:
-            self._var_meta = var_mod.build_variables()
+            self._var_meta = var_mod.build_variables(s)
         consts = {k: getattr(s, k) for k in (
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min", "clay_max",
             "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max", "a_bc", "b_bc",

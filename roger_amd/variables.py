@@ -21,7 +21,7 @@ GHOST_DIMENSIONS = ("x", "y")
 # roger/variables.py:101-131
 DIM_TO_SHAPE_VAR = {
     "x": "nx", "y": "ny", "t_forc": "nitt_forc", "timesteps": 2, "timesteps_day": 6 * 24,
-    "t": "nitt", "ages": "ages", "nages": "nages", "n_sas_params": "nsas",
+    "t": "nitt", "ages": "ages", "nages": "nages", "n_sas_params": "nsas", "n_stations": "nstations",
     "n_lu": 25, "n_sealing": 101, "n_slope": 10000, "n_params2": 2, "n_params7": 7, "n_params9": 9, "n_params13": 13,
 }
 
@@ -81,7 +81,7 @@ def _arena_variables():
     return out
 
 
-def build_variables():
+def build_variables(settings=None):
     V = {}
     i64 = np.int64
     # scalars (roger/variables.py:189-330); the time-stepping ones live in the device's rh_scalars
@@ -106,6 +106,17 @@ def build_variables():
         V[name] = Variable(name, ("t_forc",), dtype=i64)
     for name in ("prec_day", "ta_day", "pet_day"):
         V[name] = Variable(name, CATCH_GRID + ("timesteps_day",))
+    # per-cell weights of the station forcing (roger/variables.py:938, 3543, 4153) and, with settings.enable_distributed_input, the
+    # stations themselves (:882-916, 3522, 4138, 6383-6402); host-side: the user's set_forcing hook reads them, and
+    # RogerSetup.enable_device_hooks hands them to the device (rh_set_forcing_weights, rh_set_forcing_stations)
+    V["prec_weight"] = Variable("prec_weight", CATCH_GRID, initial=1.0)
+    V["ta_offset"] = Variable("ta_offset", CATCH_GRID, initial=0.0)
+    V["pet_weight"] = Variable("pet_weight", CATCH_GRID, initial=1.0)
+    if settings is not None and settings.enable_distributed_input:
+        V["station_ids"] = Variable("station_ids", ("n_stations",), dtype=i64)
+        V["station_id"] = Variable("station_id", CATCH_GRID, dtype=i64)
+        for name in ("PREC_DIST", "TA_DIST", "PET_DIST"):
+            V[name] = Variable(name, ("n_stations", "t_forc"))
     V.update(_arena_variables())
     return V
 

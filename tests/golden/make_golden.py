@@ -119,7 +119,7 @@ def tutorial_params():
     )
 
 
-def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
+def make_model(roger, params, forcing, ndays, lateral=False, weights=None, stations=None):
     from roger import roger_routine
     from roger.models.svat import SVATSetup
     from roger.models.oneD import ONEDSetup
@@ -147,6 +147,9 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
             s.enable_macropore_lower_boundary_condition = False
             s.enable_lateral_flow = bool(lateral)
             s.enable_adaptive_time_stepping = True
+            if stations is not None:   # several meteorological stations (roger/bmimodels/svat_dist/svat_dist.py:85, 67-70)
+                s.enable_distributed_input = True
+                s.nstations = len(stations["station_ids"])
 
         @roger_routine
         def set_grid(self, state):
@@ -164,6 +167,9 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
                 vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
                 vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)
                 vs.dmph = update(vs.dmph, at[2:-2, 2:-2], params["dmph"])
+            if stations is not None:   # svat_dist.py:200-211
+                vs.station_id = update(vs.station_id, at[2:-2, 2:-2], stations["station_id"])
+                vs.station_ids = update(vs.station_ids, at[:], stations["station_ids"])
             if weights is not None:   # examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186
                 vs.prec_weight = update(vs.prec_weight, at[2:-2, 2:-2], weights["prec_weight"])
                 vs.ta_offset = update(vs.ta_offset, at[2:-2, 2:-2], weights["ta_offset"])
@@ -178,6 +184,10 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
         @roger_routine
         def set_forcing_setup(self, state):
             vs = state.variables
+            if stations is not None:   # svat_dist.py:261-263: (n_stations, t_forc) series
+                for k in ("PREC", "TA", "PET"):
+                    setattr(vs, k + "_DIST", update(getattr(vs, k + "_DIST"), at[:, :], stations[k]))
+                return
             for k in ("PREC", "TA", "PET"):
                 setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
 
@@ -191,7 +201,20 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None):
                 vs.month = update(vs.month, at[1], F["MONTH"][vs.itt_forc])
                 vs.doy = update(vs.doy, at[1], F["DOY"][vs.itt_forc])
                 sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
-                if weights is not None:   # station series x per-cell weight (eberbaechle/svat_distributed/svat.py:276-296)
+                if stations is not None:
+                    # every cell takes the series of ITS station (svat_dist.py:280-293: one masked assignment per station; a cell
+                    # whose station_id matches none keeps zeros), then the weights (:305-322)
+                    day = {}
+                    for k in ("PREC", "TA", "PET"):
+                        a = npx.zeros(vs.prec_day.shape)
+                        for i, ii in enumerate(vs.station_ids):
+                            mask = vs.station_id == ii
+                            a = npx.where(mask[:, :, npx.newaxis], getattr(vs, k + "_DIST")[i, :][npx.newaxis, npx.newaxis, sl], a)
+                        day[k] = a
+                    vs.prec_day = update(vs.prec_day, at[2:-2, 2:-2, :], day["PREC"][2:-2, 2:-2, :] * vs.prec_weight[2:-2, 2:-2, npx.newaxis])
+                    vs.ta_day = update(vs.ta_day, at[2:-2, 2:-2, :], day["TA"][2:-2, 2:-2, :] + vs.ta_offset[2:-2, 2:-2, npx.newaxis])
+                    vs.pet_day = update(vs.pet_day, at[2:-2, 2:-2, :], day["PET"][2:-2, 2:-2, :] * vs.pet_weight[2:-2, 2:-2, npx.newaxis])
+                elif weights is not None:   # station series x per-cell weight (eberbaechle/svat_distributed/svat.py:276-296)
                     vs.prec_day = update(vs.prec_day, at[2:-2, 2:-2, :],
                                          vs.PREC[npx.newaxis, npx.newaxis, sl] * vs.prec_weight[2:-2, 2:-2, npx.newaxis])
                     vs.ta_day = update(vs.ta_day, at[2:-2, 2:-2, :],
@@ -268,10 +291,10 @@ ROUTINES = (
 
 
 def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine_steps, outdir, lateral=False,
-             pair_every=0, weights=None):
+             pair_every=0, weights=None, stations=None):
     import importlib
 
-    model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights)
+    model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights, stations=stations)
     planes = plane_names()
     rec = {}
     routine_log = {}
@@ -343,6 +366,9 @@ def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine
         if weights is not None:
             for k, v in weights.items():
                 rec[f"weight_{k}"] = np.asarray(v, dtype=np.float64).ravel()
+        if stations is not None:
+            for k, v in stations.items():
+                rec[f"station_{k}"] = np.asarray(v)
         scal_rows = []
         snaps = {}
         step = 0
@@ -418,6 +444,20 @@ def main():
 
         run_case(roger, "svat_eberbaechle_weights", hetero_params(nx, ny, seed=2019), forcing_from_txt(EBERBAECHLE_INPUT, ndays=nd),
                  nd, 100000, 100, {1, 2, 3, 300, 301}, args.out, weights=weights)
+    if not args.only or args.only == "svat_stations":
+        # settings.enable_distributed_input: three meteorological stations, every cell mapped to one of them by vs.station_id (one
+        # cell to none: it sees zeros), per-cell weights on top (roger/bmimodels/svat_dist/svat_dist.py:274-322)
+        nd, nx, ny = 14, 4, 3
+        rng = np.random.default_rng(77)
+        series = [combo_forcing(ndays=nd, seed=sd) for sd in (5, 6, 9)]
+        ids = np.array([11, 22, 33])
+        cell_ids = rng.choice(ids, (nx, ny))
+        cell_ids[1, 1] = 99
+        stations = dict(station_ids=ids, station_id=cell_ids, **{k: np.stack([f[k] for f in series]) for k in ("PREC", "TA", "PET")})
+        weights = dict(prec_weight=rng.uniform(0.8, 1.3, (nx, ny)), ta_offset=rng.uniform(-1.5, 1.5, (nx, ny)),
+                       pet_weight=rng.uniform(0.85, 1.15, (nx, ny)))
+        run_case(roger, "svat_stations", hetero_params(nx, ny, seed=77), series[0], nd, 100000, 60, {1, 2, 3}, args.out,
+                 weights=weights, stations=stations)
     # oneD model (lateral subsurface flow, benchmarks/oneD_benchmark.py): wet start so that a perched
     # water table forms and the lateral branches are taken
     def oned_params(nx, ny, seed):

@@ -11,6 +11,8 @@ ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo", "oned_uniform_benchm
 CASES = SVAT_CASES + ONED_CASES
 # BASELINE configs[4] (Eberbaechle, svat_distributed): the station's measured series x per-cell prec_weight / ta_offset / pet_weight
 WEIGHTED_CASES = ("svat_eberbaechle_weights",)
+# settings.enable_distributed_input: several stations, vs.station_id maps every cell to one (svat_dist.py:274-322), weights on top
+STATION_CASES = ("svat_stations",)
 
 # Tolerance of the oracle against the reference NumPy backend, and of the HIP path against the
 # oracle.  fp64 throughout; differences come only from libm `pow/log/exp` implementations
@@ -33,6 +35,15 @@ def load_weights(g):
     if "weight_prec_weight" not in g.files:
         return None
     return {k: np.asarray(g[f"weight_{k}"], dtype=np.float64) for k in ("prec_weight", "ta_offset", "pet_weight")}
+
+
+def load_stations(g):
+    """dict(PREC, TA, PET: (n_stations, t), station_index: per cell the row of its station or -1) of a station-mapped golden case."""
+    if "station_station_ids" not in g.files:
+        return None
+    ids, cell = np.asarray(g["station_station_ids"]), np.asarray(g["station_station_id"]).ravel()
+    index = np.array([int(np.where(ids == c)[0][0]) if c in ids else -1 for c in cell], dtype=np.int32)
+    return dict(PREC=g["station_PREC"], TA=g["station_TA"], PET=g["station_PET"], station_index=index)
 
 
 def is_lateral(g):

@@ -191,13 +191,19 @@ class ForcingDriver:
     """Host-side `set_forcing` / `set_parameters` hooks of the benchmark setup
     (benchmarks/SVAT_benchmark.py:105-110,151-171) for the oracle."""
 
-    def __init__(self, forcing, weights=None):
+    def __init__(self, forcing, weights=None, stations=None):
         self.F = forcing
         self.day = None
         self.weights = weights   # dict(prec_weight, ta_offset, pet_weight) per column: the distributed catchment setups' set_forcing
+        self.stations = stations   # golden_util.load_stations: several series, a row index per column (svat_dist.py:274-310)
 
     def day_slice(self, i):
         day = tuple(self.F[k][i:i + 144].copy() for k in ("PREC", "TA", "PET"))
+        if self.stations is not None:
+            st, idx = self.stations, self.stations["station_index"]
+            rows = [np.where(idx[:, None] >= 0, st[k][np.maximum(idx, 0), i:i + 144], 0.0) for k in ("PREC", "TA", "PET")]
+            w = self.weights or dict(prec_weight=np.ones(idx.size), ta_offset=np.zeros(idx.size), pet_weight=np.ones(idx.size))
+            return (rows[0] * w["prec_weight"][:, None], rows[1] + w["ta_offset"][:, None], rows[2] * w["pet_weight"][:, None])
         if self.weights is not None:   # examples/catchment_scale/eberbaechle/svat_distributed/svat.py:276-296
             w = self.weights
             day = (day[0][None, :] * w["prec_weight"][:, None], day[1][None, :] + w["ta_offset"][:, None],

@@ -84,6 +84,27 @@ class OracleContext:
 
     def set_forcing_series(self, F):
         self.series = {k: np.asarray(v) for k, v in F.items()}
+        self.stations = self.weights = None
+
+    def set_forcing_stations(self, F, station_index):
+        self.series = {k: np.asarray(v) for k, v in F.items()}
+        self.stations = np.asarray(station_index, dtype=np.int64).reshape(-1)
+        self.weights = getattr(self, "weights", None)
+
+    def set_forcing_weights(self, prec_weight=None, ta_offset=None, pet_weight=None):
+        self.weights = None if prec_weight is None else tuple(np.asarray(a, dtype=np.float64).reshape(-1) for a in (prec_weight, ta_offset, pet_weight))
+
+    def _day_from_series(self, i):
+        F = self.series
+        st, w = getattr(self, "stations", None), getattr(self, "weights", None)
+        if st is not None:
+            rows = [np.where(st[:, None] >= 0, np.asarray(F[k])[np.maximum(st, 0), i:i + 144], 0.0) for k in ("PREC", "TA", "PET")]
+        elif w is not None:
+            rows = [np.broadcast_to(np.asarray(F[k])[i:i + 144], (self.n, 144)) for k in ("PREC", "TA", "PET")]
+        else:
+            return [F[k][i:i + 144] for k in ("PREC", "TA", "PET")]
+        w = w or (np.ones(self.n), np.zeros(self.n), np.ones(self.n))
+        return [rows[0] * w[0][:, None], rows[1] + w[1][:, None], rows[2] * w[2][:, None]]
 
     # routines
     def call(self, entry):
@@ -172,11 +193,11 @@ class OracleContext:
 
     def _hooks(self):
         s, F = self.st.scal, self.series
-        if s.time % 86400 == 0 and s.itt_forc + 144 <= len(F["PREC"]):
+        if s.time % 86400 == 0 and s.itt_forc + 144 <= len(F["YEAR"]):
             i = s.itt_forc
             s.itt_day = 0
             s.year[1], s.month[1], s.doy[1] = int(F["YEAR"][i]), int(F["MONTH"][i]), int(F["DOY"][i])
-            self.set_forcing_day(F["PREC"][i:i + 144], F["TA"][i:i + 144], F["PET"][i:i + 144])
+            self.set_forcing_day(*self._day_from_series(i))
             s.itt_forc = i + 144
         self.monthly = (s.month[1] != s.month[0]) and (s.itt > 1)
 

@@ -9,7 +9,7 @@ from roger_amd.core.operators import at, numpy as npx, update
 from roger_amd.models.svat import SVATSetup
 
 
-def make_model(params, forcing, ndays, lateral=False, global_shape=None):
+def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights=None, stations=None):
     """global_shape: (nx, ny) of the whole domain when `params` holds this rank's slab only (num_proc = (N, 1))."""
     from roger_amd.models.oned import ONEDSetup
 
@@ -34,6 +34,9 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None):
             s.enable_macropore_lower_boundary_condition = False
             s.enable_lateral_flow = bool(lateral)
             s.enable_adaptive_time_stepping = True
+            if stations is not None:   # several meteorological stations (roger/bmimodels/svat_dist/svat_dist.py:85, 67-70)
+                s.enable_distributed_input = True
+                s.nstations = len(stations["station_ids"])
 
         @roger_routine
         def set_parameters_setup(self, state):
@@ -45,6 +48,13 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None):
                 vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
                 vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)
                 vs.dmph = update(vs.dmph, at[2:-2, 2:-2], params["dmph"])
+            if stations is not None:   # svat_dist.py:200-211
+                vs.station_id = update(vs.station_id, at[2:-2, 2:-2], stations["station_id"])
+                vs.station_ids = update(vs.station_ids, at[:], stations["station_ids"])
+            if weights is not None:   # examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186
+                vs.prec_weight = update(vs.prec_weight, at[2:-2, 2:-2], weights["prec_weight"])
+                vs.ta_offset = update(vs.ta_offset, at[2:-2, 2:-2], weights["ta_offset"])
+                vs.pet_weight = update(vs.pet_weight, at[2:-2, 2:-2], weights["pet_weight"])
 
         @roger_routine
         def set_initial_conditions(self, state):
@@ -55,8 +65,12 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None):
         @roger_routine
         def set_forcing_setup(self, state):
             vs = state.variables
-            for k in ("PREC", "TA", "PET"):
-                setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
+            if stations is not None:   # svat_dist.py:261-263: (n_stations, t_forc) series
+                for k in ("PREC", "TA", "PET"):
+                    setattr(vs, k + "_DIST", update(getattr(vs, k + "_DIST"), at[:, :], stations[k]))
+            else:
+                for k in ("PREC", "TA", "PET"):
+                    setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
             for k in ("YEAR", "MONTH", "DOY"):   # kept in vs so that run_device can hand them over
                 setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
 
@@ -69,9 +83,25 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None):
                 vs.month = update(vs.month, at[1], F["MONTH"][vs.itt_forc])
                 vs.doy = update(vs.doy, at[1], F["DOY"][vs.itt_forc])
                 sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
-                vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
-                vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
-                vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
+                if stations is not None:   # every cell takes the series of ITS station, then the weights (svat_dist.py:280-322)
+                    day = {}
+                    for k in ("PREC", "TA", "PET"):
+                        a = npx.zeros(vs.prec_day.shape)
+                        for i, ii in enumerate(vs.station_ids):
+                            mask = vs.station_id == ii
+                            a = npx.where(mask[:, :, npx.newaxis], getattr(vs, k + "_DIST")[i, :][npx.newaxis, npx.newaxis, sl], a)
+                        day[k] = a
+                    vs.prec_day = update(vs.prec_day, at[2:-2, 2:-2, :], day["PREC"][2:-2, 2:-2, :] * vs.prec_weight[2:-2, 2:-2, npx.newaxis])
+                    vs.ta_day = update(vs.ta_day, at[2:-2, 2:-2, :], day["TA"][2:-2, 2:-2, :] + vs.ta_offset[2:-2, 2:-2, npx.newaxis])
+                    vs.pet_day = update(vs.pet_day, at[2:-2, 2:-2, :], day["PET"][2:-2, 2:-2, :] * vs.pet_weight[2:-2, 2:-2, npx.newaxis])
+                elif weights is not None:   # eberbaechle/svat_distributed/svat.py:276-296
+                    vs.prec_day = update(vs.prec_day, at[2:-2, 2:-2, :], vs.PREC[npx.newaxis, npx.newaxis, sl] * vs.prec_weight[2:-2, 2:-2, npx.newaxis])
+                    vs.ta_day = update(vs.ta_day, at[2:-2, 2:-2, :], vs.TA[npx.newaxis, npx.newaxis, sl] + vs.ta_offset[2:-2, 2:-2, npx.newaxis])
+                    vs.pet_day = update(vs.pet_day, at[2:-2, 2:-2, :], vs.PET[npx.newaxis, npx.newaxis, sl] * vs.pet_weight[2:-2, 2:-2, npx.newaxis])
+                else:
+                    vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
+                    vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
+                    vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
                 vs.itt_forc = vs.itt_forc + 6 * 24
 
     return GoldenSVAT(forcing=F, nx=nx, ny=ny, ndays=ndays)

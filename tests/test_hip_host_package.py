@@ -29,6 +29,38 @@ def test_setup_step_reproduce_reference(case):
             compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case} step {step}")
 
 
+@pytest.mark.parametrize("case", ["svat_stations", "svat_eberbaechle_weights"])
+@pytest.mark.parametrize("device_hooks", [False, True])
+def test_distributed_input_setups_on_device(case, device_hooks):
+    """settings.enable_distributed_input (several stations, vs.station_id) and the per-cell weights of the distributed catchment
+    setups through RogerSetup on the device: hooks on the host (per-cell prec_day / ta_day / pet_day handed over every midnight,
+    transposed on upload) and hooks on the device (rh_set_forcing_stations / rh_set_forcing_weights) against the reference's runs of
+    the same setup scripts.  (tests/test_host_package.py::test_distributed_input_setups is the same on the CPU double.)"""
+    import svat_scripts as S
+    from golden_util import load_stations, load_weights
+
+    g, names, forcing = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    w = load_weights(g)
+    weights = {k: v.reshape(nx, ny) for k, v in w.items()} if w else None
+    stations = None
+    if load_stations(g) is not None:
+        stations = dict(station_ids=g["station_station_ids"], station_id=g["station_station_id"], PREC=g["station_PREC"],
+                        TA=g["station_TA"], PET=g["station_PET"])
+    nsteps = int(g["nsteps"])
+    model = S.make_model(S.params_from_golden(g, names), forcing, len(forcing["PREC"]) // 144, weights=weights, stations=stations)
+    model.setup()
+    if device_hooks:
+        model.run_device(nsteps)
+    else:
+        for _ in range(nsteps):
+            model.step(model.state)
+    vs = model.state.variables
+    gs = g["scal"][nsteps - 1]
+    assert (int(vs.itt), int(vs.time), int(vs.dt_secs), int(vs.itt_day)) == (gs[0], gs[1], gs[2], gs[3])
+    compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what=f"{case} step {nsteps}")
+
+
 def test_tutorial_year_on_device():
     """BASELINE configs[0]: examples/plot_scale/svat_tutorial (one cell, config.yml parameters, a year of measured forcing
     read by forcing_from_txt in the golden generator): setup() and the whole year through RogerSetup.step with the hooks on

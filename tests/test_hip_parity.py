@@ -3,8 +3,8 @@ against the oracle.  Needs a real MI355X: `pytest -m gpu`."""
 import numpy as np
 import pytest
 
-from golden_util import (ATOL, CASES, ONED_CASES, ONED_TIE_COLUMNS, RTOL, WEIGHTED_CASES, compare, compare_bulk, deviating_columns, is_lateral,
-                         load_case, load_weights)
+from golden_util import (ATOL, CASES, ONED_CASES, ONED_TIE_COLUMNS, RTOL, STATION_CASES, WEIGHTED_CASES, compare, compare_bulk,
+                         deviating_columns, is_lateral, load_case, load_stations, load_weights)
 
 pytestmark = pytest.mark.gpu
 
@@ -392,6 +392,47 @@ def test_weighted_station_forcing_golden(native, case):
         if f"s{step:05d}" in g.files:
             compare(H.download_snapshot(ctx2, names), g[f"s{step:05d}"], names, what=f"{case} host hook, step {step}")
     ctx.close()
+    ctx2.close()
+
+
+@pytest.mark.parametrize("case", STATION_CASES)
+def test_station_mapped_forcing_golden(native, case):
+    """settings.enable_distributed_input: three stations' series resident on the device, every column mapped
+    to one of them (one column to none: zeros), per-cell weights on top -- the reference's own run of such a setup
+    (roger/bmimodels/svat_dist/svat_dist.py:274-322) reproduced by rh_set_forcing_stations + rh_set_forcing_weights + rh_run_steps, no
+    host in the loop; and with the per-cell day handed over by the host every midnight (the transposed (144, n) layout)."""
+    import hip_util as H
+    import oracle_binding as ob
+
+    g, names, forcing = load_case(case)
+    st, w = load_stations(g), load_weights(g)
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_stations(dict(PREC=st["PREC"], TA=st["TA"], PET=st["PET"], YEAR=forcing["YEAR"], MONTH=forcing["MONTH"], DOY=forcing["DOY"]),
+                             st["station_index"])
+    ctx.set_forcing_weights(w["prec_weight"], w["ta_offset"], w["pet_weight"])
+    done = 0
+    for step in sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit()):
+        ctx.run_steps(step - done)
+        done = step
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][step - 1], err_msg=f"step {step}")
+        compare(H.download_snapshot(ctx, names), g[f"s{step:05d}"], names, what=f"{case} step {step}")
+    assert done == int(g["nsteps"])
+    ctx.close()
+    ctx2 = _ctx(native, g, names)
+    drv = ob.ForcingDriver(forcing, weights=w, stations=st)
+    for step in range(1, int(g["nsteps"]) + 1):
+        s = ctx2.get_scalars()
+        if s.time % 86400 == 0:
+            i = s.itt_forc
+            s.itt_day = 0
+            s.year[1], s.month[1], s.doy[1] = int(forcing["YEAR"][i]), int(forcing["MONTH"][i]), int(forcing["DOY"][i])
+            s.itt_forc = i + 144
+            ctx2.set_scalars(s)
+            ctx2.set_forcing_day(*drv.day_slice(i))
+        ctx2.step((s.month[1] != s.month[0]) and (s.itt > 1))
+        np.testing.assert_array_equal(H.scalars_to_row(ctx2.get_scalars()), g["scal"][step - 1], err_msg=f"host hook, step {step}")
+        if f"s{step:05d}" in g.files:
+            compare(H.download_snapshot(ctx2, names), g[f"s{step:05d}"], names, what=f"{case} host hook, step {step}")
     ctx2.close()
 
 

@@ -187,6 +187,39 @@ def test_restart_round_trip(tmp_path, monkeypatch):
         d.setup()
 
 
+@pytest.mark.parametrize("case", ["svat_stations", "svat_eberbaechle_weights"])
+@pytest.mark.parametrize("device_hooks", [False, True])
+def test_distributed_input_setups(oracle_backend, case, device_hooks):
+    """The distributed catchment setups on the host package: per-cell weights on one station's series
+    (eberbaechle/svat_distributed/svat.py:169-186, 276-296) and settings.enable_distributed_input with several stations
+    (roger/bmimodels/svat_dist/svat_dist.py:200-211, 261-322) -- the same hooks the golden generator drove through the reference, with
+    the hooks on the host (run) and handed to the device (run_device: rh_set_forcing_stations / rh_set_forcing_weights)."""
+    import svat_scripts as S
+    from golden_util import load_stations, load_weights
+
+    g, names, forcing = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    w = load_weights(g)
+    weights = {k: v.reshape(nx, ny) for k, v in w.items()} if w else None
+    stations = None
+    if load_stations(g) is not None:
+        stations = dict(station_ids=g["station_station_ids"], station_id=g["station_station_id"], PREC=g["station_PREC"],
+                        TA=g["station_TA"], PET=g["station_PET"])
+    nsteps = 120 if case == "svat_stations" else 100    # steps that carry a snapshot
+    model = S.make_model(S.params_from_golden(g, names), forcing, len(forcing["PREC"]) // 144, weights=weights, stations=stations)
+    model.setup()
+    compare(S.snapshot_from_vs(model.state.variables, names), g["state0"], names, what=f"{case} after setup")
+    if device_hooks:
+        model.run_device(nsteps)
+    else:
+        for _ in range(nsteps):
+            model.step(model.state)
+    vs = model.state.variables
+    gs = g["scal"][nsteps - 1]
+    assert (int(vs.itt), int(vs.time), int(vs.dt_secs), int(vs.itt_day)) == (gs[0], gs[1], gs[2], gs[3])
+    compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what=f"{case} step {nsteps}")
+
+
 def test_forcing_from_text_inputs():
     """roger_amd.forcing.forcing_from_txt (read_meteo + write_forcing's recipe, roger/io_tools/csv.py:10-104,
     roger/tools/setup.py:469-620) on the first 30 days of the tutorial's measured inputs (tests/golden/tutorial_input:

@@ -3,7 +3,8 @@ backend (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import CASES, ONED_CASES, ONED_TIE_COLUMNS, WEIGHTED_CASES, compare, deviating_columns, is_lateral, load_case, load_weights
+from golden_util import (CASES, ONED_CASES, ONED_TIE_COLUMNS, STATION_CASES, WEIGHTED_CASES, compare, deviating_columns, is_lateral, load_case,
+                         load_stations, load_weights)
 
 
 def _start(ob, g, names, key="state0"):
@@ -55,13 +56,13 @@ def test_single_steps_from_reference_states(oracle, case):
         compare(st.snapshot(), g[f"s{k:05d}"], st.names, what=f"{case} single step {k}")
 
 
-@pytest.mark.parametrize("case", CASES + WEIGHTED_CASES)
+@pytest.mark.parametrize("case", CASES + WEIGHTED_CASES + STATION_CASES)
 def test_trajectory(oracle, case):
     """Full steps (all routines fused per cell) reproduce the reference trajectory.  The weighted case pins the oracle's per-cell
     forcing path (a (n, 144) day per variable, `fstride = 144`) against the reference's own per-cell prec_day / ta_day / pet_day."""
     g, names, forcing = load_case(case)
     st = _start(oracle, g, names)
-    drv = oracle.ForcingDriver(forcing, weights=load_weights(g))
+    drv = oracle.ForcingDriver(forcing, weights=load_weights(g), stations=load_stations(g))
     nsteps = int(g["nsteps"])
     checked = 0
     off = set()   # oneD: columns that parted from the reference at a residue tie (golden_util.ONED_TIE_COLUMNS)
