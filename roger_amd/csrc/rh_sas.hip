@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1003,8 +1004,21 @@ SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> 
 #else
 #define SAS_OCCUPANCY
 #endif
+// Eight age classes per thread (the <2, 8> shape for ages <= 1024, RH_SAS_E8): the scans and lane exchanges of a sub-step are paid
+// once per thread, so twice the classes per thread halve their share; the state then needs the register budget of 2 waves per SIMD.
+#define SAS_OCCUPANCY_E8 __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int W, int E, bool ANION>
+__device__ __forceinline__ void sas_body(const SasArgs &P);
 template <int W, int E, bool ANION>
 __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
+    sas_body<W, E, ANION>(P);
+}
+template <int W, bool ANION>
+__global__ __launch_bounds__(W * 64) SAS_OCCUPANCY_E8 void k_sas8(const SasArgs P) {
+    sas_body<W, 8, ANION>(P);
+}
+template <int W, int E, bool ANION>
+__device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     __shared__ double2 s_logt[64];
@@ -1329,6 +1343,14 @@ static void launch_sas(rh_sas_ctx *ctx, const SasArgs &args) {
         hipLaunchKernelGGL((k_sas<W, E, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
 }
 
+template <int W>
+static void launch_sas8(rh_sas_ctx *ctx, const SasArgs &args) {
+    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18)
+        hipLaunchKernelGGL((k_sas8<W, true>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
+    else
+        hipLaunchKernelGGL((k_sas8<W, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
+}
+
 extern "C" {
 
 void rh_sas_default_config(rh_sas_config *cfg) {
@@ -1551,6 +1573,15 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     }
     // smallest workgroup whose blocked layout covers the ages + 1 edges: waves x classes per thread
     const int nages = c.ages + 1;
+    // eight classes per thread from 257 age classes on (9.63 against 10.17 ms per day at 10^5 columns x 1000 ages); RH_SAS_E4=1: the
+    // four-class shapes for comparison
+    static const bool e4 = std::getenv("RH_SAS_E4") != nullptr;
+    if (!e4 && nages > 256 && nages <= 4096) {
+        if (nages <= 512) launch_sas8<1>(ctx, args);
+        else if (nages <= 1024) launch_sas8<2>(ctx, args);
+        else if (nages <= 2048) launch_sas8<4>(ctx, args);
+        else launch_sas8<8>(ctx, args);
+    } else
     if (nages <= 64) launch_sas<1, 1>(ctx, args);
     else if (nages <= 128) launch_sas<1, 2>(ctx, args);
     else if (nages <= 256) launch_sas<1, 4>(ctx, args);
