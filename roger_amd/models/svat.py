@@ -12,30 +12,49 @@ from ..core.surface import calc_parameters_surface_kernel
 from ..variables import allocate
 
 
-class SVATSetup(RogerSetup):
-    """A SVAT model."""
+# default parameter table of the ready-made model (the values of roger/models/svat/svat.py:93-117; a dict instead of one assignment per
+# parameter: subclasses and callers override entries, see `parameters=`)
+DEFAULT_PARAMETERS = dict(lu_id=8, sealing=0, S_dep_tot=0, z_soil=2000, dmpv=50, lmpv=500, theta_ac=0.1, theta_ufc=0.1, theta_pwp=0.2,
+                          ks=5, kf=2500)
+DEFAULT_INITIAL_THETA = dict(theta_rz=0.3, theta_ss=0.3)
+LOOK_UP_TABLES = dict(lut_ilu="ARR_ILU", lut_gc="ARR_GC", lut_gcm="ARR_GCM", lut_rdlu="ARR_RDLU")
+FORCING_SERIES = ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY")
+DAY = 24 * 60 * 60
+SLOTS = 6 * 24
 
-    def __init__(self, forcing=None, nx=1, ny=1, ndays=None, override=None):
+
+def _fill_interior(vs, table, levels=False):
+    """vs.<name>[2:-2, 2:-2(, :taup1)] = value for every entry of a parameter table (scalars or (nx, ny) arrays)."""
+    for name, value in table.items():
+        where = at[2:-2, 2:-2, : vs.taup1] if levels else at[2:-2, 2:-2]
+        setattr(vs, name, update(getattr(vs, name), where, value))
+
+
+class SVATSetup(RogerSetup):
+    """A SVAT model: uniform default parameters (`DEFAULT_PARAMETERS`), forcing series in memory, the benchmark's forcing hooks
+    (one station broadcast to all cells; monthly surface parameters)."""
+
+    parameters = DEFAULT_PARAMETERS
+    initial_theta = DEFAULT_INITIAL_THETA
+    look_up_tables = LOOK_UP_TABLES
+    identifier = "SVAT"
+
+    def __init__(self, forcing=None, nx=1, ny=1, ndays=None, override=None, parameters=None):
         super().__init__(override=override)
         self._forcing = forcing
         self._nx, self._ny = nx, ny
-        self._ndays = ndays if ndays is not None else (len(forcing["PREC"]) // 144 if forcing is not None else 0)
+        self._ndays = ndays if ndays is not None else (len(forcing["PREC"]) // SLOTS if forcing is not None else 0)
+        if parameters:
+            self.parameters = dict(self.parameters, **parameters)
 
     @roger_routine
     def set_settings(self, state):
         settings = state.settings
-        settings.identifier = "SVAT"
-        settings.output_frequency = 86400
-        settings.nx, settings.ny = self._nx, self._ny
-        settings.runlen = 24 * 60 * 60 * self._ndays
-        settings.nitt_forc = len(self._forcing["PREC"])
-        settings.dx = 1
-        settings.dy = 1
-        settings.x_origin = 0.0
-        settings.y_origin = 0.0
-        settings.enable_groundwater_boundary = False
-        settings.enable_macropore_lower_boundary_condition = False
-        settings.enable_adaptive_time_stepping = True
+        for name, value in dict(identifier=self.identifier, output_frequency=DAY, nx=self._nx, ny=self._ny, runlen=DAY * self._ndays,
+                                nitt_forc=len(self._forcing["PREC"]), dx=1, dy=1, x_origin=0.0, y_origin=0.0,
+                                enable_groundwater_boundary=False, enable_macropore_lower_boundary_condition=False,
+                                enable_adaptive_time_stepping=True).items():
+            setattr(settings, name, value)
 
     @roger_routine
     def read_data(self, state):
@@ -43,22 +62,16 @@ class SVATSetup(RogerSetup):
 
     @roger_routine
     def set_grid(self, state):
-        vs = state.variables
-        settings = state.settings
-        dx = allocate(state.dimensions, ("x",))
-        dx = update(dx, at[:], settings.dx)
-        dy = allocate(state.dimensions, ("y",))
-        dy = update(dy, at[:], settings.dy)
-        vs.x = update(vs.x, at[3:-2], settings.x_origin + npx.cumsum(dx[3:-2]))
-        vs.y = update(vs.y, at[3:-2], settings.y_origin + npx.cumsum(dy[3:-2]))
+        vs, settings = state.variables, state.settings
+        for axis, origin, spacing in (("x", settings.x_origin, settings.dx), ("y", settings.y_origin, settings.dy)):
+            d = update(allocate(state.dimensions, (axis,)), at[:], spacing)
+            setattr(vs, axis, update(getattr(vs, axis), at[3:-2], origin + npx.cumsum(d[3:-2])))   # distance from the origin
 
     @roger_routine
     def set_look_up_tables(self, state):
         vs = state.variables
-        vs.lut_ilu = update(vs.lut_ilu, at[:, :], lut.ARR_ILU)
-        vs.lut_gc = update(vs.lut_gc, at[:, :], lut.ARR_GC)
-        vs.lut_gcm = update(vs.lut_gcm, at[:, :], lut.ARR_GCM)
-        vs.lut_rdlu = update(vs.lut_rdlu, at[:, :], lut.ARR_RDLU)
+        for name, table in self.look_up_tables.items():
+            setattr(vs, name, update(getattr(vs, name), at[:, :], getattr(lut, table)))
 
     @roger_routine
     def set_topography(self, state):
@@ -66,23 +79,12 @@ class SVATSetup(RogerSetup):
 
     @roger_routine
     def set_parameters_setup(self, state):
-        vs = state.variables
-        vs.lu_id = update(vs.lu_id, at[2:-2, 2:-2], 8)
-        vs.sealing = update(vs.sealing, at[2:-2, 2:-2], 0)
-        vs.S_dep_tot = update(vs.S_dep_tot, at[2:-2, 2:-2], 0)
-        vs.z_soil = update(vs.z_soil, at[2:-2, 2:-2], 2000)
-        vs.dmpv = update(vs.dmpv, at[2:-2, 2:-2], 50)
-        vs.lmpv = update(vs.lmpv, at[2:-2, 2:-2], 500)
-        vs.theta_ac = update(vs.theta_ac, at[2:-2, 2:-2], 0.1)
-        vs.theta_ufc = update(vs.theta_ufc, at[2:-2, 2:-2], 0.1)
-        vs.theta_pwp = update(vs.theta_pwp, at[2:-2, 2:-2], 0.2)
-        vs.ks = update(vs.ks, at[2:-2, 2:-2], 5)
-        vs.kf = update(vs.kf, at[2:-2, 2:-2], 2500)
+        _fill_interior(state.variables, self.parameters)
 
     @roger_routine
     def set_parameters(self, state):
         vs = state.variables
-        if (vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1):
+        if (vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1):    # a new month: the land-use dependent surface parameters
             vs.update(calc_parameters_surface_kernel(state))
 
     @roger_routine
@@ -91,9 +93,7 @@ class SVATSetup(RogerSetup):
 
     @roger_routine
     def set_initial_conditions(self, state):
-        vs = state.variables
-        vs.theta_rz = update(vs.theta_rz, at[2:-2, 2:-2, : vs.taup1], 0.3)
-        vs.theta_ss = update(vs.theta_ss, at[2:-2, 2:-2, : vs.taup1], 0.3)
+        _fill_interior(state.variables, self.initial_theta, levels=True)
 
     @roger_routine
     def set_boundary_conditions_setup(self, state):
@@ -106,24 +106,21 @@ class SVATSetup(RogerSetup):
     @roger_routine
     def set_forcing_setup(self, state):
         vs = state.variables
-        F = self._forcing
-        for k in ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY"):
-            setattr(vs, k, update(getattr(vs, k), at[:], F[k]))
+        for name in FORCING_SERIES:
+            setattr(vs, name, update(getattr(vs, name), at[:], self._forcing[name]))
 
     @roger_routine
     def set_forcing(self, state):
         vs = state.variables
-        condt = vs.time % (24 * 60 * 60) == 0
-        if condt:
-            vs.itt_day = 0
-            vs.year = update(vs.year, at[1], vs.YEAR[vs.itt_forc])
-            vs.month = update(vs.month, at[1], vs.MONTH[vs.itt_forc])
-            vs.doy = update(vs.doy, at[1], vs.DOY[vs.itt_forc])
-            sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
-            vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, sl])
-            vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
-            vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
-            vs.itt_forc = vs.itt_forc + 6 * 24
+        if vs.time % DAY:
+            return
+        first = vs.itt_forc                       # midnight: the calendar entry and the next 144 ten-minute slots
+        vs.itt_day = 0
+        for name, series in (("year", vs.YEAR), ("month", vs.MONTH), ("doy", vs.DOY)):
+            setattr(vs, name, update(getattr(vs, name), at[1], series[first]))
+        for name, series in (("prec_day", vs.PREC), ("ta_day", vs.TA), ("pet_day", vs.PET)):
+            setattr(vs, name, update(getattr(vs, name), at[:, :, :], series[npx.newaxis, npx.newaxis, first:first + SLOTS]))
+        vs.itt_forc = first + SLOTS
 
     @roger_routine
     def set_diagnostics(self, state):
