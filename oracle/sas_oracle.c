@@ -55,6 +55,9 @@ typedef struct oc_sas {
     const int32_t *lu_id;                            /* (n) land use: 500 < lu_id < 599 is a crop */
     double *M[5];                                    /* (n) solute mass of the outgoing fluxes; [0] (evap_soil) unused */
     double *M_inf[3], *M_rz, *M_ss, *M_s;            /* (n) */
+    /* settings.sas_solver: 0 "deterministic" (calc_tt's sub-stepped solve per flux), 1 "Euler", 2 "RK4" (all fluxes of a sub-step from
+     * one StorAge, transport.py:2064-2414, 1139-2047; `substeps` sub-steps of h = 1 / substeps, calculate_storage_selection :3220-3300) */
+    int64_t solver;
 } oc_sas;
 
 /* numpy pairwise add.reduce (see svat_oracle.c) */
@@ -537,6 +540,165 @@ int oc_sas_num_threads(void) {
 #endif
 }
 
+
+/* storages of the oxygen-18 model: root_zone.py:189-217, subsoil.py:159-188, soil.py:1036-1090 */
+static void storages_iso(const oc_sas *P, int64_t i, double *work) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+    for (int64_t k = 0; k < A; ++k) sa_rz[k] = (sa_rz[k] < 1e-8 ? 0 : sa_rz[k]);
+    P->C_rz[i] = conc_storage(sa_rz, msa_rz, A, work) * mk;
+    P->C_iso_rz[i] = conc_to_delta(P, P->C_rz[i]) * mk;
+    for (int64_t k = 0; k < A; ++k) sa_ss[k] = (sa_ss[k] < 1e-8 ? 0 : sa_ss[k]);
+    P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work) * mk;
+    P->C_iso_ss[i] = conc_to_delta(P, P->C_ss[i]) * mk;
+    for (int64_t k = 0; k < A; ++k) {
+        sa_s[k] = sa_rz[k] + sa_ss[k] * mk;
+        const double tot = sa_rz[k] + sa_ss[k];
+        double v = (tot > 0 ? msa_rz[k] * (sa_rz[k] / tot) + msa_ss[k] * (sa_ss[k] / tot) : 0);
+        msa_s[k] = isnan(v) ? 0 : v;
+    }
+    P->C_s[i] = conc_storage(sa_s, msa_s, A, work) * mk;
+    P->C_iso_s[i] = conc_to_delta(P, P->C_s[i]) * mk;
+}
+
+/* ---- Euler / RK4 solvers (oxygen-18, deuterium) ------------------------------------------------------------------------------- */
+/* Mixing of an addition (dsa1 of water carrying dmsa1) into an age class, transport.py:2122-2137, 2276-2291.  The root zone's
+ * formula keeps the old signal only where it is positive (`& (msa > 0)`), the subsoil's does not: both as the reference has them. */
+static double euler_mix(double msa, double sa, double dsa1, double dmsa1, int need_pos) {
+    const double tot = dsa1 + sa;
+    const double a = ((tot > 0) && (!need_pos || (msa > 0))) ? msa * (sa / tot) : 0;
+    const double b = (tot > 0) ? dmsa1 * (dsa1 / tot) : 0;
+    double m = a + b;
+    m = ((dsa1 > 0) && (m <= 0)) ? dmsa1 : m;
+    return m;
+}
+/* calc_TT_num + calc_TT_num_nonneg + the clipped differences (transport.py:860-948, 2187-2199): the cumulative and the plain travel
+ * time distribution of one flux from the cumulative StorAge SA (NA points, masked) of its source.  work: 3 * NA doubles. */
+static void euler_tt(const oc_sas *P, double *TT, double *tt, const double *SA, const double *params, double flux_h, double mk, double *work) {
+    const int64_t A = P->ages, NA = A + 1;
+    double *Om = work, *nn = work + NA;
+    double p[8];
+    memcpy(p, params, sizeof(p));
+    sas_omega(Om, SA, NA, p, mk);
+    if (flux_h <= 0)
+        for (int64_t k = 0; k < NA; ++k) Om[k] = 0;
+    for (int64_t k = 0; k < A; ++k) {
+        const double sa_d = SA[k + 1] - SA[k], ttq = (Om[k + 1] - Om[k]) * flux_h;
+        double v = (sa_d + ttq < 0) ? -sa_d : ttq;
+        v = (v == 0) ? 0.0 : v;   /* where(x == -0, 0, x) */
+        nn[k] = v;
+    }
+    const double s = np_sum(nn, A);
+    for (int64_t k = 0; k < A; ++k) nn[k] = (nn[k] > 0) ? nn[k] / s : 0;
+    TT[0] = 0;
+    {
+        double acc = 0;
+        for (int64_t k = 0; k < A; ++k) {
+            acc = (k == 0) ? nn[0] : acc + nn[k];
+            TT[k + 1] = acc;
+        }
+    }
+    for (int64_t k = 0; k < A; ++k) {
+        const double d = TT[k + 1] - TT[k];
+        tt[k] = (d >= 0) ? d : 0;
+    }
+}
+static double conc_iso_flux(const double *mtt, const double *tt, int64_t A, double *scratch) { /* calc_conc_iso_flux :512-535 */
+    for (int64_t k = 0; k < A; ++k) scratch[k] = mtt[k] * tt[k];
+    const double s = np_sum(tt, A);
+    double conc = (s > 0 ? np_sum(scratch, A) / s : NAN);
+    return (conc != 0 ? conc : NAN);
+}
+/* the upper boundary condition of a sub-step: infiltration into age class 0, transport.py:2071-2145 (Euler), 1146-1220 (RK4) */
+static void euler_inflow(const oc_sas *P, int64_t i, double h) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double im = P->inf_mat_rz[i], ip = P->inf_pf_rz[i], is = P->inf_pf_ss[i], C_in = P->C_in[i];
+    for (int64_t k = 0; k < A; ++k) {
+        const double t0 = (k == 0) ? (im > 0 ? 1 : 0) * mk : 0, t1 = (k == 0) ? (ip > 0 ? 1 : 0) * mk : 0, t2 = (k == 0) ? (is > 0 ? 1 : 0) * mk : 0;
+        const double m0 = (k == 0) ? (im > 0 ? C_in : 0) * mk : 0, m1 = (k == 0) ? (ip > 0 ? C_in : 0) * mk : 0, m2 = (k == 0) ? (is > 0 ? C_in : 0) * mk : 0;
+        const double dsa_rz = (im * t0 + ip * t1) * h, dsa_ss = (is * t2) * h;
+        const double dmsa_rz1 = (isnan(m0) ? 0 : m0) * (dsa_rz > 0 ? ((im * t0 * h) / dsa_rz) : 0) + (isnan(m1) ? 0 : m1) * (dsa_rz > 0 ? ((ip * t1 * h) / dsa_rz) : 0);
+        const double dmsa_ss1 = (isnan(m2) ? 0 : m2) * (dsa_ss > 0 ? ((is * t2 * h) / dsa_ss) : 0);
+        msa_rz[k] = euler_mix(msa_rz[k], sa_rz[k], dsa_rz, dmsa_rz1, 1);
+        msa_ss[k] = euler_mix(msa_ss[k], sa_ss[k], dsa_ss, dmsa_ss1, 0);
+        sa_rz[k] += dsa_rz;
+        sa_ss[k] += dsa_ss;
+        msa_rz[k] = (sa_rz[k] <= 0) ? 0 : msa_rz[k];
+        msa_ss[k] = (sa_ss[k] <= 0) ? 0 : msa_ss[k];
+    }
+}
+/* order of the five outgoing fluxes in the arrays: evap_soil, transp, q_rz (root zone), q_ss, cpr_rz (subsoil) */
+static const int EULER_SRC_SS[5] = {0, 0, 0, 1, 1};
+/* the distributions of the five fluxes from the state as it stands; SA_rz / SA_ss: NA doubles each, work: 3 * NA */
+static void euler_distributions(const oc_sas *P, int64_t i, double h, double *SA_rz, double *SA_ss, double *work) {
+    const int64_t A = P->ages, NA = A + 1;
+    const double mk = (double)P->maskCatch[i];
+    const double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double flux[5] = {P->evap_soil[i], P->transp[i], P->q_rz[i], P->q_ss[i], P->cpr_rz[i]};
+    calc_SA(SA_rz, sa_rz, A);
+    calc_SA(SA_ss, sa_ss, A);
+    for (int64_t k = 0; k < NA; ++k) {
+        SA_rz[k] *= mk;
+        SA_ss[k] *= mk;
+    }
+    for (int f = 0; f < 5; ++f) {
+        double *tt = P->tt[f] + i * A, *mtt = P->mtt[f] + i * A, *TT = P->TT[f] + i * NA;
+        const double *msa = EULER_SRC_SS[f] ? msa_ss : msa_rz;
+        euler_tt(P, TT, tt, EULER_SRC_SS[f] ? SA_ss : SA_rz, P->sas_params[f] + i * 8, flux[f] * h, mk, work);
+        for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0;   /* calc_mtt :565-596, isotopes */
+    }
+}
+/* the StorAge update of a sub-step from the distributions in P->tt / P->mtt, transport.py:2266-2310 */
+static void euler_update(const oc_sas *P, int64_t i, double h) {
+    const int64_t A = P->ages;
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double ev = P->evap_soil[i], tr = P->transp[i], qrz = P->q_rz[i], qss = P->q_ss[i], cpr = P->cpr_rz[i];
+    const double *tt_ev = P->tt[0] + i * A, *tt_tr = P->tt[1] + i * A, *tt_qrz = P->tt[2] + i * A, *tt_qss = P->tt[3] + i * A, *tt_cpr = P->tt[4] + i * A;
+    const double *mtt_qrz = P->mtt[2] + i * A, *mtt_cpr = P->mtt[4] + i * A;
+    for (int64_t k = 0; k < A; ++k) {
+        double dsa_rz = (cpr * tt_cpr[k] - ev * tt_ev[k] - tr * tt_tr[k] - qrz * tt_qrz[k]) * h;
+        dsa_rz = (sa_rz[k] + dsa_rz < 0) ? -sa_rz[k] : dsa_rz;
+        double dsa_ss = (qrz * tt_qrz[k] - cpr * tt_cpr[k] - qss * tt_qss[k]) * h;
+        dsa_ss = (sa_ss[k] + dsa_ss < 0) ? -sa_ss[k] : dsa_ss;
+        const double dsa_rz1 = (cpr * tt_cpr[k]) * h;
+        const double dmsa_rz1 = (isnan(mtt_cpr[k]) ? 0 : mtt_cpr[k]) * (dsa_rz1 > 0 ? ((cpr * tt_cpr[k] * h) / dsa_rz1) : 0);
+        const double dsa_ss1 = (qrz * tt_qrz[k]) * h;
+        const double dmsa_ss1 = (isnan(mtt_qrz[k]) ? 0 : mtt_qrz[k]) * (dsa_ss1 > 0 ? ((qrz * tt_qrz[k] * h) / dsa_ss1) : 0);
+        msa_rz[k] = euler_mix(msa_rz[k], sa_rz[k], dsa_rz1, dmsa_rz1, 1);
+        msa_ss[k] = euler_mix(msa_ss[k], sa_ss[k], dsa_ss1, dmsa_ss1, 0);
+        sa_rz[k] += dsa_rz;
+        sa_ss[k] += dsa_ss;
+        msa_rz[k] = (sa_rz[k] <= 0) ? 0 : msa_rz[k];
+        msa_ss[k] = (sa_ss[k] <= 0) ? 0 : msa_ss[k];
+    }
+}
+/* concentrations of the fluxes of a sub-step, transport.py:2324-2357, and delta_fluxes_svat :3660-3697 */
+static void euler_concentrations(const oc_sas *P, int64_t i, double *work) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    const double inf[3] = {P->inf_mat_rz[i], P->inf_pf_rz[i], P->inf_pf_ss[i]};
+    for (int w = 0; w < 3; ++w) {
+        P->C_inf[w][i] = (inf[w] > 0 ? P->C_in[i] : NAN) * mk;
+        P->C_iso_inf[w][i] = conc_to_delta(P, P->C_inf[w][i]) * mk;
+    }
+    for (int f = 0; f < 5; ++f) {
+        P->C[f][i] = conc_iso_flux(P->mtt[f] + i * A, P->tt[f] + i * A, A, work) * mk;
+        P->C_iso[f][i] = conc_to_delta(P, P->C[f][i]) * mk;
+    }
+}
+/* svat_transport_model_euler, transport.py:2064-2414 (oxygen-18 / deuterium): one sub-step of length h */
+static void euler_substep(const oc_sas *P, int64_t i, double h, double *work) {
+    const int64_t NA = P->ages + 1;
+    euler_inflow(P, i, h);
+    euler_distributions(P, i, h, work, work + NA, work + 2 * NA);
+    euler_update(P, i, h);
+    euler_concentrations(P, i, work);
+}
+
 /* one day of svat_transport_model_deterministic for all columns; columns are independent and run on all host threads
  * once there are enough of them (bench.py's cpu_baseline) */
 void oc_sas_step(const oc_sas *P) {
@@ -548,9 +710,18 @@ void oc_sas_step(const oc_sas *P) {
     for (int64_t i = 0; i < P->n; ++i) {
         const double mk = (double)P->maskCatch[i];
         double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
-        double *sa_s = P->sa_s + i * A, *msa_s = P->msa_s + i * A;
+        double *sa_s = P->sa_s + i * A;
         if (P->tracer != 0) {
             step_anion(P, i, work);
+            goto statistics;
+        }
+        if (P->solver == 1) {   /* calculate_storage_selection, Euler branch :3220-3262: per sub-step the model, the storages,
+                                 * [the age statistics: they depend on the state of the moment only, the last ones remain] */
+            const double h = 1 / (double)P->substeps;
+            for (int64_t it = 0; it < P->substeps; ++it) {
+                euler_substep(P, i, h, work);
+                storages_iso(P, i, work);
+            }
             goto statistics;
         }
         inflow(P, i, 0, P->inf_mat_rz[i], sa_rz, msa_rz, mk);
@@ -561,21 +732,7 @@ void oc_sas_step(const oc_sas *P) {
         inflow(P, i, 2, P->inf_pf_ss[i], sa_ss, msa_ss, mk);
         outflux(P, i, 3, P->q_ss[i], sa_ss, msa_ss, NULL, NULL, mk, work);
         outflux(P, i, 4, P->cpr_rz[i], sa_ss, msa_ss, sa_rz, msa_rz, mk, work);
-        /* storages: root_zone.py:189-217, subsoil.py:159-188, soil.py:1036-1090 */
-        for (int64_t k = 0; k < A; ++k) sa_rz[k] = (sa_rz[k] < 1e-8 ? 0 : sa_rz[k]);
-        P->C_rz[i] = conc_storage(sa_rz, msa_rz, A, work) * mk;
-        P->C_iso_rz[i] = conc_to_delta(P, P->C_rz[i]) * mk;
-        for (int64_t k = 0; k < A; ++k) sa_ss[k] = (sa_ss[k] < 1e-8 ? 0 : sa_ss[k]);
-        P->C_ss[i] = conc_storage(sa_ss, msa_ss, A, work) * mk;
-        P->C_iso_ss[i] = conc_to_delta(P, P->C_ss[i]) * mk;
-        for (int64_t k = 0; k < A; ++k) {
-            sa_s[k] = sa_rz[k] + sa_ss[k] * mk;
-            const double tot = sa_rz[k] + sa_ss[k];
-            double v = (tot > 0 ? msa_rz[k] * (sa_rz[k] / tot) + msa_ss[k] * (sa_ss[k] / tot) : 0);
-            msa_s[k] = isnan(v) ? 0 : v;
-        }
-        P->C_s[i] = conc_storage(sa_s, msa_s, A, work) * mk;
-        P->C_iso_s[i] = conc_to_delta(P, P->C_s[i]) * mk;
+        storages_iso(P, i, work);
     statistics:
         if (P->stats[0][0]) { /* transport.py:59-312 */
             static const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};

@@ -46,7 +46,8 @@ def read_svat_output(rate_nc, collect_nc):
     return out
 
 
-def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0, tracer="oxygen18", extra=None):
+def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, warmup_days=0, tracer="oxygen18", extra=None,
+                         solver="deterministic"):
     top = importlib.import_module(pkg)
     RogerSetup, roger_kernel, roger_routine, KernelOutput = top.RogerSetup, top.roger_kernel, top.roger_routine, top.KernelOutput
     allocate = importlib.import_module(pkg + ".variables").allocate
@@ -68,8 +69,10 @@ def make_transport_model(pkg, svat, sas, ages, substeps, ndays, age_statistics, 
         def set_settings(self, state):
             s = state.settings
             s.identifier = "GoldenSAS"
-            s.sas_solver = "deterministic"
+            s.sas_solver = solver
             s.sas_solver_substeps = substeps
+            if solver in ("RK4", "Euler"):   # benchmarks/SVATOXYGEN18_benchmark.py:30-31
+                s.h = 1 / s.sas_solver_substeps
             s.nx, s.ny = nx, ny
             s.runlen = 24 * 60 * 60 * ndays
             s.runlen_warmup = 24 * 60 * 60 * warmup_days

@@ -144,7 +144,8 @@ def sas_params(nx, ny, variant, seed):
     return out
 
 
-def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed, warmup=False, tracer="oxygen18"):
+def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics, outdir, seed, warmup=False, tracer="oxygen18",
+             solver="deterministic"):
     from roger_amd.forcing import combo_forcing
 
     params = hetero_params(nx, ny, seed=seed)
@@ -166,12 +167,14 @@ def run_case(roger, name, nx, ny, ndays, ages, substeps, variant, age_statistics
             C_IN[:, :, 1:] = rng.uniform(0.5, 3.0, (nx, ny, ndays))
             extra.update(C_init_rz=4.0, C_init_ss=9.0)
     model = make_transport_model(roger, svat, sas, ages, substeps, ndays, age_statistics, ndays if warmup else 0,
-                                 tracer=tracer, extra=extra)
+                                 tracer=tracer, extra=extra, solver=solver)
     model.setup()
     vs = model.state.variables
     rec = {"meta": np.array([nx, ny, ndays, ages, substeps, int(age_statistics)])}
     if tracer != "oxygen18":
         rec["tracer"] = np.array(tracer)
+    if solver != "deterministic":
+        rec["solver"] = np.array(solver)
     if warmup:
         # RogerSetup.warmup (roger/roger.py:491-521): one whole run, soil.rescale_SA, itt = time = 0.  The state right
         # before the rescaling is recorded too, so that the rescaling kernel can be pinned on its own.
@@ -232,6 +235,9 @@ def main():
         # BASELINE configs[2] at its own shape: ages = 1000, 6 sub-steps, the benchmark's exponents, age statistics on
         # (SVATOXYGEN18_benchmark.py:28-44,59,129-138); three columns, the days 3-7 of the combo forcing (rain, heavy rain, dry)
         "sas_benchmark_a1000": (3, 1, 7, 1000, 6, "benchmark", True, 53),
+        # settings.sas_solver = "Euler" / "RK4" (transport.py:2064-2414, 1139-2047): all fluxes of a sub-step from one StorAge
+        "sas_euler_a40": (3, 2, 14, 40, 4, "mixed", True, 61, False, "oxygen18", "Euler"),
+        "sas_rk4_a40": (3, 2, 14, 40, 4, "mixed", True, 67, False, "oxygen18", "RK4"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():
         if args.only and args.only != name:

@@ -17,6 +17,8 @@ STAT_TARGETS = (("transp", "tt"), ("q_ss", "tt"), ("rz", "rt"), ("ss", "rt"), ("
 STAT_Q = ("10", "25", "50", "75", "90", "avg")
 SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40",
              "sas_deuterium_a40", "sas_benchmark_a1000")
+# settings.sas_solver = "Euler" / "RK4" (the explicit solvers of roger/core/transport.py:1139-2414)
+SOLVER_CASES = ("sas_euler_a40",)
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 
@@ -41,6 +43,7 @@ class OcSas(C.Structure):
         ("tracer", C.c_int64),
         ("alpha_transp", _P), ("alpha_q", _P), ("S_sat_rz", _P), ("lu_id", C.POINTER(C.c_int32)),
         ("M", _P * 5), ("M_inf", _P * 3), ("M_rz", _P), ("M_ss", _P), ("M_s", _P),
+        ("solver", C.c_int64),
     ]
 
 
@@ -72,8 +75,9 @@ class SasState:
     """All arrays of one SAS problem: state (sa/msa), daily inputs, outputs.  Used with the oracle
     (`step_oracle`) and, in the GPU tests, as the host mirror of the HIP context."""
 
-    def __init__(self, n, ages, substeps, age_statistics=False, tracer="oxygen18"):
+    def __init__(self, n, ages, substeps, age_statistics=False, tracer="oxygen18", solver="deterministic"):
         self.n, self.ages, self.substeps = int(n), int(ages), int(substeps)
+        self.solver = solver   # settings.sas_solver: "deterministic", "Euler", "RK4"
         self.age_statistics = bool(age_statistics)
         self.tracer = tracer
         self.anion = tracer in ("bromide", "chloride", "virtualtracer")   # the reference's anion kernels: msa is solute mass by age
@@ -134,6 +138,7 @@ class SasState:
                     s.stats[i][j] = _ptr(self.out[f"{p}{q}_{w}"])
         s.S_rz_init, s.S_ss_init = _ptr(self.S_init["S_rz_init"]), _ptr(self.S_init["S_ss_init"])
         s.tracer = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2, "virtualtracer": 3}[self.tracer]
+        s.solver = {"deterministic": 0, "Euler": 1, "RK4": 2}[self.solver]
         if self.anion:
             for k in ("alpha_transp", "alpha_q", "S_sat_rz"):
                 setattr(s, k, _ptr(self.par[k]))
@@ -161,12 +166,13 @@ class SasGolden:
         self.nx, self.ny, self.ndays, self.ages, self.substeps, self.stats = (int(v) for v in self.z["meta"])
         self.n = self.nx * self.ny
         self.tracer = str(self.z["tracer"]) if "tracer" in self.z.files else ("bromide" if "alpha_q" in self.z.files else "oxygen18")
+        self.solver = str(self.z["solver"]) if "solver" in self.z.files else "deterministic"
 
     def day(self, d, var):
         return self.z[f"d{d:03d}_{var}"]
 
     def new_state(self):
-        st = SasState(self.n, self.ages, self.substeps, bool(self.stats), tracer=self.tracer)
+        st = SasState(self.n, self.ages, self.substeps, bool(self.stats), tracer=self.tracer, solver=self.solver)
         st.maskCatch[:] = self.z["maskCatch"]
         for f in FLUXES:
             st.sas[f][:] = self.z[f"sas_{f}"]
@@ -226,7 +232,7 @@ DEVICE_TIES = {"sas_power_a40": 2, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_
                "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0}
 # ... and of the ORACLE (glibc's pow against numpy's AVX-512 pow), same criterion, measured in the build container
 ORACLE_TIES = {"sas_power_a40": 0, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_families_a50": 1, "sas_warmup_a30": 0, "sas_gamma_a40": 4,
-               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0}
+               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0, "sas_euler_a40": 0}
 # Random columns against the oracle (tests/test_hip_sas.py::test_random_columns_against_oracle), per configuration (n, ages,
 # substeps): columns that newly miss 1e-10 on day 0, 1, 2 (a column that tied stays off afterwards: its state carries on).
 DEVICE_NEW_TIES = {(96, 1000, 6): (0, 4, 1), (200, 300, 3): (2, 4, 3), (64, 1500, 2): (0, 3, 1), (64, 2500, 2): (0, 1, 0),

@@ -8,9 +8,9 @@ import os
 import numpy as np
 import pytest
 
-from sas_binding import FIRST_TIE, ORACLE_TIES, check_day_loose, FLUXES, INFS, SAS_CASES, STAT_Q, STAT_TARGETS, GOLDEN, SasGolden, compare_sas
+from sas_binding import FIRST_TIE, ORACLE_TIES, check_day_loose, FLUXES, INFS, SAS_CASES, SOLVER_CASES, STAT_Q, STAT_TARGETS, GOLDEN, SasGolden, compare_sas
 
-CASES = [c for c in SAS_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))]
+CASES = [c for c in SAS_CASES + SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))]
 
 
 def compare_msa(got, want, sa, what):
