@@ -127,14 +127,14 @@ def cpu_baseline(n_cells, steps, forcing):
 SAS_S_RZ, SAS_S_SS = 90.0, 260.0   # initial root zone / subsoil storage in mm (uniform benchmark soil)
 
 
-def cpu_baseline_sas(n_cells, ndays, ages, substeps, daily):
+def cpu_baseline_sas(n_cells, ndays, ages, substeps, daily, solver="deterministic"):
     """Oracle (oracle/sas_oracle.c) on the host: first n_cells columns, first ndays days of the same inputs."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import sas_binding as sb
     from roger_amd import sas as rsas
 
     sb.lib().oc_sas_set_num_threads(host_threads())
-    st = sb.SasState(n_cells, ages, substeps, age_statistics=True)
+    st = sb.SasState(n_cells, ages, substeps, age_statistics=True, solver=solver)
     for key, S in (("rz", SAS_S_RZ), ("ss", SAS_S_SS)):
         sa, msa = rsas.initial_age_state([S] * n_cells, ages)
         st.state[f"sa_{key}"][:] = sa
@@ -159,7 +159,9 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
     n = nx * ny
     ndays_resident = 8
     daily = rsas.synthetic_daily_inputs(n, ndays_resident, seed=42 + rank)
-    ctx = rsas.create_sas(n, args.ages, args.substeps, SAS_S_RZ, SAS_S_SS, daily=daily, device=local_rank, age_statistics=True)
+    ctx = rsas.create_sas(n, args.ages, args.substeps, SAS_S_RZ, SAS_S_SS, daily=daily, device=local_rank, age_statistics=True,
+                          solver=args.sas_solver)
+    euler = args.sas_solver != "deterministic"
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def fence():
@@ -188,14 +190,15 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = algo * n / k_avg_s / 1e9
         pows = 5 * args.substeps * (args.ages + 1)
-        traffic, trec = measured_traffic(f"k_sas_ages{args.ages}_sub{args.substeps}", n)
+        kname = "k_sas_euler" if euler else "k_sas"
+        traffic, trec = measured_traffic(f"{kname}_ages{args.ages}_sub{args.substeps}", n)
         traffic_note = f"; traffic = PMC FETCH_SIZE / WRITE_SIZE of this kernel at this column count ({trec['source']})" if trec else ""
         # compute side ("state the compute bound for SAS explicitly"): the kernel is bound by fp64 VALU ISSUE.  Per column-day it
         # issues `valu_wave_insts` wave-instructions (PMC SQ_INSTS_VALU / columns, profiles/sas_valu.json); an fp64 wave64 instruction
         # occupies its SIMD for 4 cycles (MI355X_MICROARCH.md: 64 lanes over 16-wide fp64 VALUs), the chip has 256 CUs x 4 SIMDs.
         compute = None
         try:
-            vrec = json.load(open(os.path.join(REPO, "profiles", "sas_valu.json")))[f"ages{args.ages}_sub{args.substeps}"]
+            vrec = json.load(open(os.path.join(REPO, "profiles", "sas_valu.json")))[("euler_" if euler else "") + f"ages{args.ages}_sub{args.substeps}"]
             cyc = vrec["valu_wave_insts_per_column"] * n * 4.0 / 1024.0
             clock_hz = vrec.get("clock_mhz", 2400) * 1e6
             compute = {
@@ -224,7 +227,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"SVATOXYGEN18_benchmark (offline oxygen-18 transport, deterministic SAS solver) nx*ny={n} per GPU, "
+                "workload": f"SVATOXYGEN18_benchmark (offline oxygen-18 transport, {args.sas_solver} SAS solver) nx*ny={n} per GPU, "
                             f"ages={args.ages}, sas_solver_substeps={args.substeps}, power-law SAS (benchmark exponents), "
                             "age statistics on, synthetic daily fluxes (seed 42); one step = one day",
                 "cells_per_gpu": n,
@@ -233,7 +236,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_sas",
+                "kernel": kname,
                 "note": f"algorithmic bytes = state read + written once per day; the kernel is fp64-ALU bound by "
                         f"<= {pows} pow per column-day (fluxes that are 0 on a day are skipped), see DESIGN.md" + traffic_note,
                 "achieved": achieved,
@@ -250,7 +253,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             cells = max(8, min(n, int(args.cpu_cells) // 25))
             days = min(ndays_resident, args.steps + args.warmup, 4)
-            v, secs, threads = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily)
+            v, secs, threads = cpu_baseline_sas(cells, days, args.ages, args.substeps, daily, args.sas_solver)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "cell-timesteps/s",
@@ -275,6 +278,8 @@ def main():
                          "sas: SVATOXYGEN18_benchmark (configs[2]: offline oxygen-18 transport, one step = one day)")
     ap.add_argument("--ages", type=int, default=1000, help="sas: age classes (benchmark: 1000)")
     ap.add_argument("--substeps", type=int, default=6, help="sas: sas_solver_substeps (benchmark: 6)")
+    ap.add_argument("--sas-solver", choices=("deterministic", "Euler"), default="deterministic",
+                    help="sas: settings.sas_solver (benchmark: deterministic; Euler = the explicit scheme, transport.py:2064-2414)")
     ap.add_argument("--station-weights", action="store_true",
                     help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
                          "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")

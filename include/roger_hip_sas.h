@@ -61,6 +61,11 @@ extern "C" {
 #define RH_SAS_TRACER_CHLORIDE 2 /* the anion kernels as for bromide; RH_SAS_RESCALE scales the solute with the water */
 #define RH_SAS_TRACER_VIRTUAL 3  /* settings.enable_virtualtracer: as chloride, and the soil evaporation takes the tracer along
                                     (calc_evaporation_transport_virtualtracer_kernel, core/evapotranspiration.py:722-791) */
+/* settings.sas_solver (roger/settings.py:119): "deterministic" (svat_transport_model_deterministic, core/transport.py:949-991) or the
+ * explicit "Euler" scheme (svat_transport_model_euler :2064-2414, isotopes only): every sub-step of length settings.h = 1 / substeps
+ * evaluates all five fluxes on the StorAge as it stands.  "RK4" is not implemented. */
+#define RH_SAS_SOLVER_DETERMINISTIC 0
+#define RH_SAS_SOLVER_EULER 1
 #define RH_SAS_MAX_NAGES 4096 /* ages + 1 <= this (benchmark: ages = 1000, SVATOXYGEN18_benchmark.py:28-44) */
 
 typedef struct rh_sas_config {
@@ -74,7 +79,7 @@ typedef struct rh_sas_config {
     double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78); for
                                        * settings.enable_deuterium: VSMOW_conc2H, d2H_min, d2H_max (:79-81), same kernels */
     int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 | _BROMIDE | _CHLORIDE | _VIRTUAL (settings.enable_oxygen18 / enable_bromide / enable_chloride / enable_virtualtracer) */
-    int32_t reserved;
+    int32_t solver;            /* RH_SAS_SOLVER_DETERMINISTIC | RH_SAS_SOLVER_EULER (settings.sas_solver) */
 } rh_sas_config;
 
 typedef struct rh_sas_ctx rh_sas_ctx;

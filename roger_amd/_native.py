@@ -129,12 +129,14 @@ class RhSasConfig(C.Structure):
     _fields_ = [("n_cells", C.c_int64), ("ages", C.c_int32), ("substeps", C.c_int32), ("device", C.c_int32),
                 ("forcing_days", C.c_int32), ("age_statistics", C.c_int32), ("keep_distributions", C.c_int32),
                 ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double),
-                ("tracer", C.c_int32), ("reserved", C.c_int32)]
+                ("tracer", C.c_int32), ("solver", C.c_int32)]
 
 
 # RH_SAS_TRACER_*.  Deuterium runs the isotope kernels of oxygen-18 with its own constants in the vsmow / d18O_min /
 # d18O_max fields of rh_sas_config (roger/core/transport.py:315-340, roger/settings.py:79-81)
 SAS_TRACERS = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2, "virtualtracer": 3}
+# RH_SAS_SOLVER_*: settings.sas_solver
+SAS_SOLVERS = {"deterministic": 0, "Euler": 1}
 DEUTERIUM_DEFAULTS = {"vsmow": 155.76e-6, "d18O_min": -160.0, "d18O_max": 0.0}
 
 
@@ -189,7 +191,7 @@ class SasContext:
     """One SAS / oxygen-18 transport problem on the device (rh_sas_ctx).  Thin, 1:1 with the C ABI."""
 
     def __init__(self, n_cells, ages, substeps=1, device=0, forcing_days=1, age_statistics=False,
-                 keep_distributions=False, tracer="oxygen18", **settings):
+                 keep_distributions=False, tracer="oxygen18", solver="deterministic", **settings):
         lib = load()
         cfg = RhSasConfig()
         lib.rh_sas_default_config(C.byref(cfg))
@@ -197,6 +199,10 @@ class SasContext:
             raise ValueError(f"tracer {tracer!r}: the hip backend transports {sorted(SAS_TRACERS)}")
         cfg.tracer = SAS_TRACERS[tracer]
         self.tracer = tracer
+        if solver not in SAS_SOLVERS:
+            raise ValueError(f"solver {solver!r}: the hip backend implements {sorted(SAS_SOLVERS)}")
+        cfg.solver = SAS_SOLVERS[solver]
+        self.solver = solver
         if tracer == "deuterium":
             settings = {**DEUTERIUM_DEFAULTS, **settings}
         cfg.n_cells, cfg.ages, cfg.substeps, cfg.device = int(n_cells), int(ages), int(substeps), int(device)

@@ -19,6 +19,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
 
+# translation units and what each depends on (besides its own .hip): compiled side by side, objects cached in roger_amd/_obj
+_SAS_DEPS = ("rh_sas_dev.h", "rh_sas_tables.inc", "include/roger_hip_sas.h", "include/rh_sas_arrays.def", "include/roger_hip.h")
+UNITS = {
+    "roger_hip": ("rh_physics.h", "rh_col.h", "rh_sets.inc", "include/roger_hip.h", "include/rh_fields.def"),
+    "rh_sas": _SAS_DEPS,            # the deterministic SAS kernels + the SAS C ABI (about four minutes)
+    "rh_sas_solvers": _SAS_DEPS,    # the explicit solvers
+}
+OBJ = os.path.join(PKG, "_obj")
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True
@@ -26,29 +36,31 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _dep_path(d):
+    return os.path.join(REPO, d) if d.startswith("include/") else os.path.join(CSRC, d)
+
+
 def build_native(force=False, verbose=False):
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_sets.py")], check=True)
-    sources = [os.path.join(CSRC, f) for f in ("roger_hip.hip", "rh_sas.hip", "rh_physics.h", "rh_col.h", "rh_sets.inc", "rh_sas_tables.inc")]
-    sources += [os.path.join(REPO, "include", f) for f in ("roger_hip.h", "rh_fields.def", "roger_hip_sas.h",
-                                                           "rh_sas_arrays.def")]
-    if force or _newer(LIB, sources):
-        # the two translation units compile side by side (each takes about a minute), then one link
-        import tempfile
-
-        with tempfile.TemporaryDirectory() as tmp:
-            jobs = []
-            for unit in ("roger_hip", "rh_sas"):
-                cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, unit + ".hip"), "-o", os.path.join(tmp, unit + ".o")]
-                if verbose:
-                    print(" ".join(cmd))
-                jobs.append((cmd, subprocess.Popen(cmd)))
-            for cmd, job in jobs:
-                if job.wait() != 0:
-                    raise subprocess.CalledProcessError(job.returncode, cmd)
-            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(tmp, u + ".o") for u in ("roger_hip", "rh_sas")] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    this = os.path.abspath(__file__)   # the flags live here
+    jobs, objs = [], []
+    for unit, deps in UNITS.items():
+        src, obj = os.path.join(CSRC, unit + ".hip"), os.path.join(OBJ, unit + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src, this] + [_dep_path(d) for d in deps]):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
+    if force or jobs or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -56,12 +56,25 @@ def calculate_storage_selection(state):
     """roger/core/transport.py:3136 for `(enable_oxygen18, enable_deuterium, enable_bromide or enable_chloride) and sas_solver == "deterministic"`:
     svat_transport_model_deterministic (:949-991) as one native launch (rh_sas_step).  What the user's
     set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
-    `vs.<name>` is read."""
+    `vs.<name>` is read.
+
+    `sas_solver == "Euler"` (:3220-3262, isotopes): the loop over the sub-steps -- svat_transport_model_euler, the storages, the age
+    statistics, the ageing at the end of the day -- is one native launch as well; the model time advances here, by the sub-steps'
+    `int(dt_secs / substeps)` (the reference ages the water when that reaches a full day, so the sub-steps must divide the day).
+    The variables hold the values after the last sub-step (the reference's per-sub-step `write_output` is not reproduced)."""
     vs = state.variables
+    settings = state.settings
     sas = state.sas_context
     if sas is None:
         raise RuntimeError("calculate_storage_selection needs settings.enable_offline_transport")
     vs.flush_to_device()
+    if settings.sas_solver == "Euler":
+        dt_secs = int(np.asarray(vs.dt_secs))
+        if dt_secs % settings.sas_solver_substeps or dt_secs != 24 * 60 * 60:
+            raise NotImplementedError("the Euler solver on the hip backend needs daily steps that the sub-steps divide evenly "
+                                      f"(dt_secs = {dt_secs}, sas_solver_substeps = {settings.sas_solver_substeps})")
+        with vs.unlock():
+            vs.time = vs.time + dt_secs
     sas.step(0)
     vs.mark_device_newer(_written_by_step(state.settings))
 

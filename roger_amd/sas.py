@@ -81,13 +81,13 @@ def synthetic_daily_inputs(n, ndays, seed=42, delta_prec=-7.0):
 
 
 def create_sas(n_cells, ages, substeps, S_rz, S_ss, sas_params=None, daily=None, device=0, age_statistics=False,
-               keep_distributions=False, chunk_cells=32768, delta0=-10.0):
+               keep_distributions=False, chunk_cells=32768, delta0=-10.0, solver="deterministic"):
     """A SasContext with the benchmark's initial conditions, parameters and daily inputs on the device.
     S_rz, S_ss: scalars or (n_cells,) arrays of the initial storages in mm."""
     daily = daily if daily is not None else synthetic_daily_inputs(n_cells, 1)
     ndays = next(iter(daily.values())).shape[0]
     ctx = _native.SasContext(n_cells, ages, substeps, device=device, forcing_days=ndays,
-                             age_statistics=age_statistics, keep_distributions=keep_distributions)
+                             age_statistics=age_statistics, keep_distributions=keep_distributions, solver=solver)
     sas_params = sas_params if sas_params is not None else benchmark_sas_params(n_cells)
     for f in FLUXES:
         ctx.upload(f"sas_params_{f}", sas_params[f])

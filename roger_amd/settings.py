@@ -35,6 +35,7 @@ _GROUPS = {
         "enable_deuterium": (False, bool), "enable_nitrate": (False, bool), "enable_virtualtracer": (False, bool),
         "tm_structure": ("UNNAMED", str), "enable_age_statistics": (False, bool),
         "sas_solver": (None, optional(str)), "sas_solver_substeps": (1, int),
+        "h": (1.0, float),   # temporal increment of the explicit SAS solvers as a fraction of the time step (roger/settings.py:121)
     },
     "switch": {   # process switches (what is native: check_setting_conflicts)
         "enable_distributed_input": (False, bool), "enable_film_flow": (False, bool),
@@ -73,9 +74,15 @@ def check_setting_conflicts(settings):
             raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, deuterium, bromide, chloride "
                                       "and the virtual tracer (exactly one of settings.enable_oxygen18 / enable_deuterium / "
                                       "enable_bromide / enable_chloride / enable_virtualtracer must be True)")
-        if settings.sas_solver != "deterministic":
+        if settings.sas_solver not in ("deterministic", "Euler"):
             raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
-                                      '"deterministic" SAS solver (Euler / RK4 are out of scope, SURVEY.md section 8)')
+                                      '"deterministic" and the explicit "Euler" SAS solver (RK4 is not implemented)')
+        if settings.sas_solver == "Euler":
+            if not (settings.enable_oxygen18 or settings.enable_deuterium):
+                raise NotImplementedError('settings.sas_solver="Euler" is implemented for the isotope tracers (oxygen-18, deuterium)')
+            # benchmarks/SVATOXYGEN18_benchmark.py:30-31: the increment of the numerical solver is the length of a sub-step
+            if abs(settings.h * settings.sas_solver_substeps - 1) > 1e-12:
+                raise ValueError("settings.h must be 1 / settings.sas_solver_substeps for the Euler solver")
         if settings.nages != settings.ages + 1:
             raise ValueError("settings.nages must be settings.ages + 1")
         return

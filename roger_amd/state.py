@@ -344,7 +344,7 @@ class RogerState:
             self._sas_ctx = _native.SasContext(
                 (s.nx // px) * (s.ny // py), s.ages, s.sas_solver_substeps, device=device, forcing_days=1,
                 age_statistics=s.enable_age_statistics, keep_distributions=True, tracer=tracer,
-                vsmow=iso[0], d18O_min=iso[1], d18O_max=iso[2])
+                solver=s.sas_solver or "deterministic", vsmow=iso[0], d18O_min=iso[1], d18O_max=iso[2])
             self._ctx = HostScalars()
             self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx, self._sas_ctx)
             return

@@ -12,11 +12,12 @@ from roger_amd._native import DAILY_INPUTS, NativeError
 
 class OracleSasContext:
     def __init__(self, n_cells, ages, substeps=1, device=0, forcing_days=1, age_statistics=False,
-                 keep_distributions=False, tracer="oxygen18", **settings):
+                 keep_distributions=False, tracer="oxygen18", solver="deterministic", **settings):
         assert forcing_days == 1
         self.n, self.ages, self.substeps, self.forcing_days = int(n_cells), int(ages), int(substeps), 1
         self.tracer = tracer
-        self.st = sb.SasState(self.n, self.ages, self.substeps, age_statistics, tracer=tracer)
+        self.solver = solver
+        self.st = sb.SasState(self.n, self.ages, self.substeps, age_statistics, tracer=tracer, solver=solver)
         self.keep = keep_distributions
         self.names = list(self._arrays())
 

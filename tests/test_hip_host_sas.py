@@ -14,11 +14,11 @@ from test_host_package_sas import bromide_model, golden_inputs, interior, run_an
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_power_a40", "sas_deuterium_a40"])
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_power_a40", "sas_deuterium_a40", "sas_euler_a40"])
 def test_transport_setup_on_device(case):
     g = sb.SasGolden(case)
     svat, sas = golden_inputs(g)
-    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer, solver=g.solver)
     model.setup()
     model.warmup(repeat=0)
     vs = model.state.variables
@@ -39,7 +39,7 @@ def test_transport_setup_on_device(case):
     assert tight.mean() >= 0.5, f"{np.count_nonzero(~tight)} of {tight.size} (day, column) pairs deviate"
     model.state.sas_context.close()
     # an assignment on the host reaches the device before the next step: empty the root zone after day 1
-    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer, solver=g.solver)
     model.setup()
     model.warmup(repeat=0)
     vs = model.state.variables

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from sas_binding import DEVICE_NEW_TIES, DEVICE_TIES, FLUXES, GOLDEN, SAS_CASES, TIE_WIPED, SasGolden, SasState, column_deviation, compare_sas
+from sas_binding import DEVICE_NEW_TIES, DEVICE_TIES, FLUXES, GOLDEN, SAS_CASES, SOLVER_CASES, TIE_WIPED, SasGolden, SasState, column_deviation, compare_sas
 from test_oracle_sas import compare_msa
 
 pytestmark = pytest.mark.gpu
@@ -19,6 +19,7 @@ CASES = [c for c in SAS_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz")
 def make_ctx(st, **kw):
     from roger_amd import _native
 
+    kw.setdefault("solver", st.solver)
     ctx = _native.SasContext(st.n, st.ages, st.substeps, age_statistics=st.age_statistics, keep_distributions=True,
                              tracer=st.tracer, **kw)
     ctx.upload("maskCatch", st.maskCatch)
@@ -103,9 +104,9 @@ def test_stage_by_stage_equals_fused(case):
     split.close()
 
 
-def random_problem(n, ages, substeps, seed, stats=False):
+def random_problem(n, ages, substeps, seed, stats=False, solver="deterministic"):
     rng = np.random.default_rng(seed)
-    st = SasState(n, ages, substeps, stats)
+    st = SasState(n, ages, substeps, stats, solver=solver)
     tot_rz, tot_ss = rng.uniform(30, 200, n), rng.uniform(50, 400, n)
     for key, tot in (("rz", tot_rz), ("ss", tot_ss)):
         w = rng.gamma(0.7, 1.0, (n, ages))
@@ -136,7 +137,7 @@ def random_problem(n, ages, substeps, seed, stats=False):
 
 
 def clone(st):
-    c = SasState(st.n, st.ages, st.substeps, st.age_statistics, tracer=st.tracer)
+    c = SasState(st.n, st.ages, st.substeps, st.age_statistics, tracer=st.tracer, solver=st.solver)
     c.maskCatch[:] = st.maskCatch
     for k in st.par:
         c.par[k][:] = st.par[k]
@@ -401,3 +402,99 @@ def test_closed_form_exponents_against_oracle():
             s = st.out[f"tt_{f}"].sum(axis=1)
             assert (s <= 1 + 1e-12).all()
         ctx.close()
+
+
+# ---- settings.sas_solver = "Euler" (roger_amd/csrc/rh_sas_solvers.hip) -----------------------------------------------------------
+@pytest.mark.parametrize("case", [c for c in SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))])
+def test_explicit_solver_single_days_from_reference_states(case):
+    """Each day of the reference's run with the explicit Euler solver (svat_transport_model_euler, transport.py:2064-2414) restarted
+    on the device from the reference's own state: every output within rtol 1e-10.  The explicit scheme empties a class by an exact
+    `dsa = -sa`, it has no residue ties."""
+    g = SasGolden(case)
+    st = g.new_state()
+    ctx = make_ctx(st)
+    assert ctx.solver == g.solver != "deterministic"
+    for d in range(1, g.ndays + 1):
+        g.load_state(st, d - 1)
+        g.load_inputs(st, d)
+        push(ctx, st)
+        ctx.step(0)
+        pull(ctx, st)
+        tight = column_deviation(st, lambda k: g.day(d, k), g.n, bool(g.stats))
+        assert tight.all(), f"{case} day {d}: columns {np.argwhere(~tight).ravel()} deviate"
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", [c for c in SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))])
+def test_explicit_solver_trajectory(case):
+    """Free-running on the device from the initial state of the reference's run (rh_sas_run_days keeps the state in HBM)."""
+    g = SasGolden(case)
+    st = g.new_state()
+    ctx = make_ctx(st)
+    g.load_state(st, 0)
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        if d == 1:
+            push(ctx, st)
+        else:
+            for k, a in st.inp.items():
+                ctx.upload(k, a[None, :])
+        ctx.step(0)
+    pull(ctx, st)
+    d = g.ndays
+    tight = column_deviation(st, lambda k: g.day(d, k), g.n, bool(g.stats))
+    assert tight.all(), f"{case}: columns {np.argwhere(~tight).ravel()} deviate after {d} days"
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,ages,substeps,stats", [(96, 1000, 6, True), (200, 300, 3, False), (64, 1500, 2, False),
+                                                  (64, 2500, 2, True), (300, 17, 4, True), (150, 100, 5, True)])
+def test_explicit_solver_random_columns_against_oracle(n, ages, substeps, stats):
+    """Every workgroup shape of the Euler kernel on random columns with all SAS families, three days in a row, against the oracle's
+    restatement on the host: all outputs at rtol 1e-10 (statistics 1e-9).  Columns with a kumaraswami flux are held to 1e-6: with an
+    exponent b < 1 its Omega = 1 - (1 - (SA / S)**a)**b is infinitely steep at SA = S, one ulp of the cumulative StorAge below the top
+    (sequential cumsum on the host, block scan on the device) moves Omega by (1e-16)**b."""
+    st = random_problem(n, ages, substeps, seed=7 * ages + n, stats=stats, solver="Euler")
+    ref = clone(st)
+    ctx = make_ctx(st)
+    steep = np.zeros(n, bool)
+    for f in FLUXES:
+        steep |= np.isin(st.sas[f][:, 0], [3, 31, 32, 33, 34, 35, 36, 37])
+    assert 0 < steep.sum() < n
+    for day in range(3):
+        if day == 0:
+            push(ctx, st)
+        ctx.step(0)
+        pull(ctx, st)
+        ref.step_oracle()
+        bad = np.zeros(n, bool)
+        for k in list(st.out) + list(st.state):
+            a = st.out[k] if k in st.out else st.state[k]
+            b = ref.out[k] if k in ref.out else ref.state[k]
+            if k.startswith("msa"):
+                w = (ref.out["sa_s"] if k == "msa_s" else ref.state["sa" + k[3:]]) > 0
+                a, b = np.where(w, a, 0), np.where(w, b, 0)
+            if k.startswith("mtt"):
+                a, b = a * st.out["tt" + k[3:]], b * ref.out["tt" + k[3:]]
+            is_stat = k[:2] in ("tt", "rt") and a.ndim == 1
+            ok = np.isclose(a, b, rtol=1e-9 if is_stat else 1e-10, atol=1e-12, equal_nan=True).reshape(n, -1).all(axis=1)
+            ok[steep] = np.isclose(a, b, rtol=1e-6, atol=1e-8, equal_nan=True).reshape(n, -1).all(axis=1)[steep]
+            bad |= ~ok
+            if not ok.all():
+                print(f"day {day} {k}: max dev {np.nanmax(np.abs(a - b))} in columns {np.argwhere(~ok).ravel()[:6]}")
+        assert not bad.any(), f"day {day}: columns {np.argwhere(bad).ravel()[:10]} deviate"
+    ctx.close()
+
+
+def test_explicit_solver_runs_the_day_in_one_launch():
+    """The explicit solvers evaluate all fluxes on one state: single stages are refused, the Euler solver with an anion tracer too."""
+    from roger_amd import _native
+
+    st = random_problem(8, 30, 2, seed=3, solver="Euler")
+    ctx = make_ctx(st)
+    push(ctx, st)
+    with pytest.raises(_native.NativeError, match="one launch"):
+        ctx.stages(0, _native.SAS_STAGES["TRANSP"])
+    ctx.close()
+    with pytest.raises(_native.NativeError, match="isotope"):
+        _native.SasContext(8, 30, 2, tracer="bromide", solver="Euler")

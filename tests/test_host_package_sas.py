@@ -64,11 +64,11 @@ def oracle_sas(monkeypatch):
     monkeypatch.setattr(_native, "SasContext", OracleSasContext)
 
 
-@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70", "sas_deuterium_a40"])
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70", "sas_deuterium_a40", "sas_euler_a40"])
 def test_transport_setup_through_host_package(oracle_sas, case):
     g = sb.SasGolden(case)
     svat, sas = golden_inputs(g)
-    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer)
+    model = make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), tracer=g.tracer, solver=g.solver)
     run_and_compare(g, model, first_tie=sb.FIRST_TIE.get(case))
 
 
@@ -87,6 +87,9 @@ def test_transport_settings_are_checked(oracle_sas):
     with pytest.raises(NotImplementedError, match="deterministic"):
         make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
             override=dict(sas_solver="RK4")).setup()
+    with pytest.raises(ValueError, match="settings.h"):   # benchmarks/SVATOXYGEN18_benchmark.py:30-31
+        make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
+            override=dict(sas_solver="Euler")).setup()
     with pytest.raises(NotImplementedError, match="oxygen-18"):
         make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
             override=dict(enable_oxygen18=False)).setup()

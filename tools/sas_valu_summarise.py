@@ -17,7 +17,7 @@ def main(pmc_dir, n_cells, out, source):
     vals, dur = {}, []
     for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_sas<" in r["Kernel_Name"]:
+            if "k_sas" in r["Kernel_Name"]:
                 vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                 kern = r["Kernel_Name"]
                 if r["Counter_Name"] == "SQ_INSTS_VALU":
