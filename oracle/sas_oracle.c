@@ -699,13 +699,89 @@ static void euler_substep(const oc_sas *P, int64_t i, double h, double *work) {
     euler_concentrations(P, i, work);
 }
 
+/* svat_transport_model_rk4, transport.py:1139-2047 (oxygen-18 / deuterium): one sub-step of length h with four evaluations of the
+ * travel time distributions.  For the isotopes the intermediate signals (msarkn, mttrkn) never reach the result -- the final mtt is
+ * calc_mtt on the state after the infiltration (:1878-1896) -- so only the intermediate StorAges are followed:
+ *   stage 1 on the state, fluxes * h;          the trial StorAge moves by (net outflow) * h      (:1388-1466, isotope branch)
+ *   stage 2 on that,      fluxes * h / 2;      it moves by (net outflow) * h / 2                 (:1552-1580)
+ *   stage 3 on that,      fluxes * h / 2;      it moves by (net outflow) * h / 2, limited by `sarkn - dsarkn < 0` as written (:1700-1728)
+ *   stage 4 on that,      fluxes * h
+ *   tt = (tt1 + 2 tt2 + 2 tt3 + tt4) / 6 (:1835-1855), then the update of Euler's scheme with it (:1898-1941).
+ * work: 3 * NA (euler_tt) + 2 * NA (SA) + 2 * A (trial StorAges) + 5 * A (the stage's tt) doubles. */
+static void rk4_substep(const oc_sas *P, int64_t i, double h, double *work) {
+    const int64_t A = P->ages, NA = A + 1;
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double flux[5] = {P->evap_soil[i], P->transp[i], P->q_rz[i], P->q_ss[i], P->cpr_rz[i]};
+    double *tw = work, *SA_rz = work + 3 * NA, *SA_ss = SA_rz + NA, *s_rz = SA_ss + NA, *s_ss = s_rz + A, *tts = s_ss + A;
+    double *TT = P->TT[0] + i * NA; /* scratch for the stages' cumulative distributions (overwritten at the end) */
+    euler_inflow(P, i, h);
+    calc_SA(SA_rz, sa_rz, A);
+    calc_SA(SA_ss, sa_ss, A);
+    for (int64_t k = 0; k < NA; ++k) {
+        SA_rz[k] *= mk;
+        SA_ss[k] *= mk;
+    }
+    memcpy(s_rz, sa_rz, sizeof(double) * A);
+    memcpy(s_ss, sa_ss, sizeof(double) * A);
+    for (int f = 0; f < 5; ++f)
+        for (int64_t k = 0; k < A; ++k) P->tt[f][i * A + k] = 0;
+    for (int stage = 0; stage < 4; ++stage) {
+        const int half = (stage == 1 || stage == 2);
+        const double w = half ? 2.0 : 1.0;
+        for (int f = 0; f < 5; ++f) {
+            double *t = tts + f * A;
+            const double fh = half ? flux[f] * h / 2 : flux[f] * h;
+            euler_tt(P, TT, t, EULER_SRC_SS[f] ? SA_ss : SA_rz, P->sas_params[f] + i * 8, fh, mk, tw);
+            double *acc = P->tt[f] + i * A;
+            /* (tt1 + 2 * tt2 + 2 * tt3 + tt4): left to right */
+            for (int64_t k = 0; k < A; ++k) acc[k] = (stage == 0) ? t[k] : acc[k] + w * t[k];
+        }
+        if (stage == 3) break;
+        const double *t_ev = tts, *t_tr = tts + A, *t_qrz = tts + 2 * A, *t_qss = tts + 3 * A, *t_cpr = tts + 4 * A;
+        for (int64_t k = 0; k < A; ++k) {
+            double d_rz = (flux[4] * t_cpr[k] - flux[0] * t_ev[k] - flux[1] * t_tr[k] - flux[2] * t_qrz[k]) * h;
+            double d_ss = (flux[2] * t_qrz[k] - flux[4] * t_cpr[k] - flux[3] * t_qss[k]) * h;
+            if (stage > 0) {
+                d_rz = d_rz / 2;
+                d_ss = d_ss / 2;
+            }
+            if (stage == 2) { /* as written: `sarkn - dsarkn < 0` */
+                d_rz = (s_rz[k] - d_rz < 0) ? -s_rz[k] : d_rz;
+                d_ss = (s_ss[k] - d_ss < 0) ? -s_ss[k] : d_ss;
+            } else {
+                d_rz = (s_rz[k] + d_rz < 0) ? -s_rz[k] : d_rz;
+                d_ss = (s_ss[k] + d_ss < 0) ? -s_ss[k] : d_ss;
+            }
+            s_rz[k] += d_rz;
+            s_ss[k] += d_ss;
+        }
+        calc_SA(SA_rz, s_rz, A); /* SArkn[1:] = cumsum(sarkn): no mask from here on */
+        calc_SA(SA_ss, s_ss, A);
+    }
+    for (int f = 0; f < 5; ++f) {
+        double *tt = P->tt[f] + i * A, *mtt = P->mtt[f] + i * A, *TTf = P->TT[f] + i * NA;
+        const double *msa = EULER_SRC_SS[f] ? msa_ss : msa_rz;
+        for (int64_t k = 0; k < A; ++k) tt[k] = tt[k] / 6.;
+        TTf[0] = 0;
+        double acc = 0;
+        for (int64_t k = 0; k < A; ++k) {
+            acc = (k == 0) ? tt[0] : acc + tt[k];
+            TTf[k + 1] = acc;
+        }
+        for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0; /* calc_mtt :565-596, isotopes */
+    }
+    euler_update(P, i, h);
+    euler_concentrations(P, i, work);
+}
+
 /* one day of svat_transport_model_deterministic for all columns; columns are independent and run on all host threads
  * once there are enough of them (bench.py's cpu_baseline) */
 void oc_sas_step(const oc_sas *P) {
     const int64_t A = P->ages, NA = A + 1;
 #pragma omp parallel if (P->n >= 256)
     {
-    double *work = (double *)malloc(sizeof(double) * (8 * NA + 4));
+    double *work = (double *)malloc(sizeof(double) * (12 * NA + 4));
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < P->n; ++i) {
         const double mk = (double)P->maskCatch[i];
@@ -715,11 +791,12 @@ void oc_sas_step(const oc_sas *P) {
             step_anion(P, i, work);
             goto statistics;
         }
-        if (P->solver == 1) {   /* calculate_storage_selection, Euler branch :3220-3262: per sub-step the model, the storages,
-                                 * [the age statistics: they depend on the state of the moment only, the last ones remain] */
+        if (P->solver == 1 || P->solver == 2) {   /* calculate_storage_selection, Euler / RK4 branches :3220-3304: per sub-step the model, the
+                                 * storages, [the age statistics: they depend on the state of the moment only, the last ones remain] */
             const double h = 1 / (double)P->substeps;
             for (int64_t it = 0; it < P->substeps; ++it) {
-                euler_substep(P, i, h, work);
+                if (P->solver == 1) euler_substep(P, i, h, work);
+                else rk4_substep(P, i, h, work);
                 storages_iso(P, i, work);
             }
             goto statistics;
