@@ -190,7 +190,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = algo * n / k_avg_s / 1e9
         pows = 5 * args.substeps * (args.ages + 1)
-        kname = "k_sas_euler" if euler else "k_sas"
+        kname = {"Euler": "k_sas_euler", "RK4": "k_sas_rk4"}.get(args.sas_solver, "k_sas")
         traffic, trec = measured_traffic(f"{kname}_ages{args.ages}_sub{args.substeps}", n)
         traffic_note = f"; traffic = PMC FETCH_SIZE / WRITE_SIZE of this kernel at this column count ({trec['source']})" if trec else ""
         # compute side ("state the compute bound for SAS explicitly"): the kernel is bound by fp64 VALU ISSUE.  Per column-day it
@@ -198,7 +198,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
         # occupies its SIMD for 4 cycles (MI355X_MICROARCH.md: 64 lanes over 16-wide fp64 VALUs), the chip has 256 CUs x 4 SIMDs.
         compute = None
         try:
-            vrec = json.load(open(os.path.join(REPO, "profiles", "sas_valu.json")))[("euler_" if euler else "") + f"ages{args.ages}_sub{args.substeps}"]
+            vrec = json.load(open(os.path.join(REPO, "profiles", "sas_valu.json")))[("" if not euler else args.sas_solver.lower() + "_") + f"ages{args.ages}_sub{args.substeps}"]
             cyc = vrec["valu_wave_insts_per_column"] * n * 4.0 / 1024.0
             clock_hz = vrec.get("clock_mhz", 2400) * 1e6
             compute = {
@@ -278,8 +278,8 @@ def main():
                          "sas: SVATOXYGEN18_benchmark (configs[2]: offline oxygen-18 transport, one step = one day)")
     ap.add_argument("--ages", type=int, default=1000, help="sas: age classes (benchmark: 1000)")
     ap.add_argument("--substeps", type=int, default=6, help="sas: sas_solver_substeps (benchmark: 6)")
-    ap.add_argument("--sas-solver", choices=("deterministic", "Euler"), default="deterministic",
-                    help="sas: settings.sas_solver (benchmark: deterministic; Euler = the explicit scheme, transport.py:2064-2414)")
+    ap.add_argument("--sas-solver", choices=("deterministic", "Euler", "RK4"), default="deterministic",
+                    help="sas: settings.sas_solver (benchmark: deterministic; Euler / RK4 = the explicit schemes, transport.py:2064-2414, 1139-2047)")
     ap.add_argument("--station-weights", action="store_true",
                     help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
                          "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")

@@ -63,9 +63,11 @@ extern "C" {
                                     (calc_evaporation_transport_virtualtracer_kernel, core/evapotranspiration.py:722-791) */
 /* settings.sas_solver (roger/settings.py:119): "deterministic" (svat_transport_model_deterministic, core/transport.py:949-991) or the
  * explicit "Euler" scheme (svat_transport_model_euler :2064-2414, isotopes only): every sub-step of length settings.h = 1 / substeps
- * evaluates all five fluxes on the StorAge as it stands.  "RK4" is not implemented. */
+ * evaluates all five fluxes on the StorAge as it stands; "RK4" (svat_transport_model_rk4 :1139-2047, isotopes only) evaluates them
+ * four times per sub-step on trial StorAges and updates with the weighted mean of the four travel time distributions. */
 #define RH_SAS_SOLVER_DETERMINISTIC 0
 #define RH_SAS_SOLVER_EULER 1
+#define RH_SAS_SOLVER_RK4 2
 #define RH_SAS_MAX_NAGES 4096 /* ages + 1 <= this (benchmark: ages = 1000, SVATOXYGEN18_benchmark.py:28-44) */
 
 typedef struct rh_sas_config {
@@ -79,7 +81,7 @@ typedef struct rh_sas_config {
     double vsmow, d18O_min, d18O_max; /* settings.VSMOW_conc18O, d18O_min, d18O_max (roger/settings.py:76-78); for
                                        * settings.enable_deuterium: VSMOW_conc2H, d2H_min, d2H_max (:79-81), same kernels */
     int32_t tracer;            /* RH_SAS_TRACER_OXYGEN18 | _BROMIDE | _CHLORIDE | _VIRTUAL (settings.enable_oxygen18 / enable_bromide / enable_chloride / enable_virtualtracer) */
-    int32_t solver;            /* RH_SAS_SOLVER_DETERMINISTIC | RH_SAS_SOLVER_EULER (settings.sas_solver) */
+    int32_t solver;            /* RH_SAS_SOLVER_DETERMINISTIC | _EULER | _RK4 (settings.sas_solver) */
 } rh_sas_config;
 
 typedef struct rh_sas_ctx rh_sas_ctx;

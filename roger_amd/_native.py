@@ -136,7 +136,7 @@ class RhSasConfig(C.Structure):
 # d18O_max fields of rh_sas_config (roger/core/transport.py:315-340, roger/settings.py:79-81)
 SAS_TRACERS = {"oxygen18": 0, "deuterium": 0, "bromide": 1, "chloride": 2, "virtualtracer": 3}
 # RH_SAS_SOLVER_*: settings.sas_solver
-SAS_SOLVERS = {"deterministic": 0, "Euler": 1}
+SAS_SOLVERS = {"deterministic": 0, "Euler": 1, "RK4": 2}
 DEUTERIUM_DEFAULTS = {"vsmow": 155.76e-6, "d18O_min": -160.0, "d18O_max": 0.0}
 
 

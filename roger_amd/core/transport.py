@@ -58,7 +58,7 @@ def calculate_storage_selection(state):
     set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
     `vs.<name>` is read.
 
-    `sas_solver == "Euler"` (:3220-3262, isotopes): the loop over the sub-steps -- svat_transport_model_euler, the storages, the age
+    `sas_solver == "Euler"` / `"RK4"` (:3220-3304, isotopes): the loop over the sub-steps -- svat_transport_model_euler / _rk4, the storages, the age
     statistics, the ageing at the end of the day -- is one native launch as well; the model time advances here, by the sub-steps'
     `int(dt_secs / substeps)` (the reference ages the water when that reaches a full day, so the sub-steps must divide the day).
     The variables hold the values after the last sub-step (the reference's per-sub-step `write_output` is not reproduced)."""
@@ -68,10 +68,10 @@ def calculate_storage_selection(state):
     if sas is None:
         raise RuntimeError("calculate_storage_selection needs settings.enable_offline_transport")
     vs.flush_to_device()
-    if settings.sas_solver == "Euler":
+    if settings.sas_solver in ("Euler", "RK4"):
         dt_secs = int(np.asarray(vs.dt_secs))
         if dt_secs % settings.sas_solver_substeps or dt_secs != 24 * 60 * 60:
-            raise NotImplementedError("the Euler solver on the hip backend needs daily steps that the sub-steps divide evenly "
+            raise NotImplementedError("the explicit solvers on the hip backend need daily steps that the sub-steps divide evenly "
                                       f"(dt_secs = {dt_secs}, sas_solver_substeps = {settings.sas_solver_substeps})")
         with vs.unlock():
             vs.time = vs.time + dt_secs

@@ -765,10 +765,10 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
     if (cfg->substeps < 1 || cfg->forcing_days < 1) return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: substeps and forcing_days must be >= 1");
     if (cfg->tracer < RH_SAS_TRACER_OXYGEN18 || cfg->tracer > RH_SAS_TRACER_VIRTUAL)
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18, _BROMIDE, _CHLORIDE or _VIRTUAL");
-    if (cfg->solver != RH_SAS_SOLVER_DETERMINISTIC && cfg->solver != RH_SAS_SOLVER_EULER)
-        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: solver must be RH_SAS_SOLVER_DETERMINISTIC or RH_SAS_SOLVER_EULER");
-    if (cfg->solver == RH_SAS_SOLVER_EULER && cfg->tracer != RH_SAS_TRACER_OXYGEN18)
-        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: the Euler solver is implemented for the isotope tracers (oxygen-18, deuterium) only");
+    if (cfg->solver < RH_SAS_SOLVER_DETERMINISTIC || cfg->solver > RH_SAS_SOLVER_RK4)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: solver must be RH_SAS_SOLVER_DETERMINISTIC, _EULER or _RK4");
+    if (cfg->solver != RH_SAS_SOLVER_DETERMINISTIC && cfg->tracer != RH_SAS_TRACER_OXYGEN18)
+        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: the explicit solvers are implemented for the isotope tracers (oxygen-18, deuterium) only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");

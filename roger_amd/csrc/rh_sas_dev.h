@@ -645,5 +645,5 @@ SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E
     }
 }
 
-// rh_sas_solvers.hip: the whole day of an explicit solver (RH_SAS_SOLVER_EULER) in one launch on `stream`
+// rh_sas_solvers.hip: the whole day of an explicit solver (RH_SAS_SOLVER_EULER, _RK4) in one launch on `stream`
 int rh_sas_launch_solver(int solver, hipStream_t stream, const SasArgs &args);

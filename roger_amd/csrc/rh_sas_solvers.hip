@@ -1,4 +1,4 @@
-// rh_sas_solvers.hip -- the explicit solvers of the SAS / oxygen-18 transport step (settings.sas_solver = "Euler") for gfx950.
+// rh_sas_solvers.hip -- the explicit solvers of the SAS / oxygen-18 transport step (settings.sas_solver = "Euler", "RK4") for gfx950.
 //
 // The reference's explicit Euler scheme (svat_transport_model_euler, roger/core/transport.py:2064-2414, driven by
 // calculate_storage_selection :3220-3262) splits the day into `substeps` sub-steps of length h = 1 / substeps.  In each of them
@@ -61,12 +61,13 @@ __device__ __attribute__((noinline)) void omega_library_families(int fam, const 
 }
 
 // tt of one flux on the cumulative StorAge of its source: calc_TT_num + calc_TT_num_nonneg + the clipped differences (:2187-2199).
-//   SA_hi: cumulative StorAge (masked) at the upper edges of the thread's classes; sa: the StorAge itself (masked)
+//   SA_hi: cumulative StorAge (masked) at the upper edges of the thread's classes; sa: its differences, diff(SA) (one_flux)
 template <int W, int E>
 SAS_DEV void euler_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux_h, const double (&SA_hi)[E], const double (&sa)[E],
-                      double Smax, double mk, int base, double (&tt)[E]) {
+                      double Smax, double mk, int base, bool nonneg, double (&tt)[E]) {
     const int A = P.ages;
-    if (!(flux_h > 0)) {  // TTq = where(flux <= 0, 0, .) :893-896 -> every difference 0 -> nothing is selected
+    const bool no_flux = !(flux_h > 0);   // TTq = where(flux <= 0, 0, .) :893-896: every difference of Omega is 0
+    if (no_flux && nonneg) {              // ... and with non-negative classes nothing is selected
 #pragma unroll
         for (int j = 0; j < E; ++j) tt[j] = 0.0;
         return;
@@ -75,7 +76,11 @@ SAS_DEV void euler_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux_
     const double code = pr[0];
     const PowConsts C = load_pow_consts(B.logt);   // (here, not at the top of the kernel: the coefficients live in scalar registers)
     double Om[E], Om_edge0 = 0.0;
-    if (code == 6 || code == 61 || code == 62) sas_omega<W, E, FAM_POWER>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
+    if (no_flux) {
+        // a trial StorAge of RK4 with a negative class: the limiter below selects `-sa` of it although no water leaves (as the reference does)
+#pragma unroll
+        for (int j = 0; j < E; ++j) Om[j] = 0.0;
+    } else if (code == 6 || code == 61 || code == 62) sas_omega<W, E, FAM_POWER>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
     else if (code == 1) sas_omega<W, E, FAM_UNIFORM>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
     else if (code == 2) sas_omega<W, E, FAM_DIRAC>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
     else if (code == 3 || (code >= 31 && code <= 37) || code == 51 || code == 4) {
@@ -90,21 +95,18 @@ SAS_DEV void euler_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux_
         for (int j = 0; j < E; ++j) Om[j] = o[j];
     } else {
         // 52 (the exponential with reversed age order, sas.py:186-190) selects nothing: its Omega decreases along the age axis, every
-        // difference is negative and `where(ttq_nonneg > 0, ., 0)` (:931-934) leaves 0.  Any other code is none of the reference's families.
+        // difference is negative and `where(ttq_nonneg > 0, ., 0)` (:931-934) leaves 0 -- evaluated as Omega = 0.  Any other code is none
+        // of the reference's families.
         if (code != 52 && B.tid == 0) *P.unsupported = 1;
 #pragma unroll
-        for (int j = 0; j < E; ++j) tt[j] = 0.0;
-        return;
+        for (int j = 0; j < E; ++j) Om[j] = 0.0;
     }
     double Om_lo, unused;
     blk_prev2<W>(B, Om[E - 1], 0.0, Om_edge0, 0.0, Om_lo, unused);
     double nn[E], s[1] = {0.0};
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        // :920-923  diff(SA).  The reference's sequential cumsum returns the class itself up to one rounding of SA, and exactly 0 for an
-        // empty class; the differences of the block scan are only that consistent inside a thread (one ulp of either sign across
-        // lanes, which the limiter below would turn into a selected 1e-14 mm of an EMPTY class): the class itself is used.
-        const double sa_d = sa[j];
+        const double sa_d = sa[j];                                                          // :920-923  diff(SA), see one_flux
         const double ttq = (Om[j] - (j == 0 ? Om_lo : Om[j > 0 ? j - 1 : 0])) * flux_h;     // :924-927
         const double v = (sa_d + ttq < 0) ? -sa_d : ttq;                                     // :928-930
         nn[j] = (base + j < A) ? v : 0.0;
@@ -172,16 +174,139 @@ SAS_DEV void storages_iso(Blk<W> &B, const SasArgs &P, int64_t cell, int base, d
     }
 }
 
-// One sub-step of length h.  LAST: the last of the day, which also forms everything the reference overwrites in every sub-step --
-// concentrations of the fluxes, distributions, statistics.  An instantiation of its own rather than a flag: inside the loop over the
-// sub-steps the compiler hoists the addresses of all those output arrays out of the loop and spills them (measured: 85 VGPRs, with
-// their reloads in every sub-step).
-template <int W, int E, bool LAST>
-SAS_DEV void euler_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int base, double h, double mk, double im, double ip, double is, double C_in,
-                           double (&sa_rz)[E], double (&msa_rz)[E], double (&sa_ss)[E], double (&msa_ss)[E]) {
+// What the reference overwrites in every sub-step and the day keeps from the last one, for one flux: its concentration (:2336-2357,
+// calc_conc_iso_flux :512-535, delta_fluxes_svat :3660-3697), the age statistics of transpiration and percolation, the diagnostics arrays
+template <int W, int E>
+SAS_DEV void flux_outputs(Blk<W> &B, const SasArgs &P, int64_t cell, int base, int f, const double (&tt)[E], const double (&msa_rz)[E],
+                          const double (&msa_ss)[E], double mk) {
     const int A = P.ages;
-    // 1. upper boundary condition :2071-2145.  tt_inf is 1 in age class 0 and 0 elsewhere: for the other classes the mixing reduces
-    //    to msa * (sa / sa) where the class holds water (and, in the root zone, a positive signal), 0 otherwise
+    const bool from_ss = f >= 3;
+    double mtt[E], s[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        mtt[j] = (tt[j] > 0 ? (from_ss ? msa_ss[j] : msa_rz[j]) : 0);   // calc_mtt :565-596, isotopes
+        s[0] += mtt[j] * tt[j];
+        s[1] += tt[j];
+    }
+    blk_sum<W, 2>(B, s);
+    if (B.tid == 0) {
+        double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
+        conc = (conc != 0 ? conc : NAN);
+        const double Cf = conc * mk;
+        ((double *)arr5(P, SA_C_evap_soil, f))[cell] = Cf;
+        ((double *)arr5(P, SA_C_iso_evap_soil, f))[cell] = conc_to_delta(P, Cf) * mk;
+    }
+    const bool want_stats = P.stats && (f == 1 || f == 3);
+    if (P.diag || want_stats) {
+        double TT_hi[E], TT_lo;
+        blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
+        if (want_stats) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
+        if (P.diag) {
+            double *o_tt = (double *)arr5(P, SA_tt_evap_soil, f) + cell * A;
+            double *o_mtt = (double *)arr5(P, SA_mtt_evap_soil, f) + cell * A;
+            double *o_TT = (double *)arr5(P, SA_TT_evap_soil, f) + cell * (A + 1);
+            if (B.tid == 0) o_TT[0] = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (base + j < A) {
+                    o_tt[base + j] = tt[j];
+                    o_mtt[base + j] = mtt[j];
+                    o_TT[base + j + 1] = TT_hi[j];
+                }
+        }
+    }
+}
+
+// The five per-flux arrays of a sub-step: separate local arrays, declared by FIVE(name).  The flux index is a run-time value (one call
+// site of the SAS function for all five); the arrays are addressed through chains of selects over constant indices so that they stay
+// in registers (as members of one struct the compiler turns the chain back into an indexed access to scratch memory).
+#define FIVE(name) double name##_ev[E], name##_tr[E], name##_qrz[E], name##_qss[E], name##_cpr[E]
+#define FIVE_ARGS(name) name##_ev, name##_tr, name##_qrz, name##_qss, name##_cpr
+#define SET5(name, f, j, v)              \
+    do {                                 \
+        const double v_ = (v);           \
+        if ((f) == 0) name##_ev[j] = v_;       \
+        else if ((f) == 1) name##_tr[j] = v_;  \
+        else if ((f) == 2) name##_qrz[j] = v_; \
+        else if ((f) == 3) name##_qss[j] = v_; \
+        else name##_cpr[j] = v_;               \
+    } while (0)
+template <int E>
+SAS_DEV double get5(int f, int j, const double (&ev)[E], const double (&tr)[E], const double (&qrz)[E], const double (&qss)[E],
+                    const double (&cpr)[E]) {
+    double v = ev[j];
+    v = (f == 1) ? tr[j] : v;
+    v = (f == 2) ? qrz[j] : v;
+    v = (f == 3) ? qss[j] : v;
+    v = (f == 4) ? cpr[j] : v;
+    return v;
+}
+
+// tt of flux f (0..4: evap_soil, transp, q_rz from the root zone; q_ss, cpr_rz from the subsoil; called with f ascending) on the StorAges
+// s_rz / s_ss, the flux scaled by `scale` [/ 2]: SA = cumsum(s) [* maskCatch] of the source is formed when the loop over the fluxes
+// reaches the storage's first flux (neither StorAge changes inside that loop) and kept in SA / sa_src / S_top.  The equality of the
+// cumulative sum above the top of the stored water is restored exactly (blk_cumsum): the differences of Omega there are exact zeros,
+// as with the reference's sequential cumsum.  masked: the state itself (non-negative classes); otherwise a trial StorAge of RK4.
+// Returns the flux of the day.
+template <int W, int E>
+SAS_DEV double one_flux(Blk<W> &B, const SasArgs &P, int64_t cell, int base, int f, double scale, bool halve, double mk, bool masked,
+                        const double (&s_rz)[E], const double (&s_ss)[E], double (&SA)[E], double (&sa_src)[E], double &S_top, double (&tt)[E]) {
+    const bool from_ss = f >= 3;
+    if (f == 0 || f == 3) {
+        const double m = masked ? mk : 1.0;
+        double lo, raw[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) raw[j] = from_ss ? s_ss[j] : s_rz[j];
+        blk_cumsum<W, E, true>(B, raw, SA, lo, &S_top, base, P.ages - 1);
+        // diff(SA) of calc_TT_num_nonneg (:920-923) as the reference's sequential cumsum returns it: fl(SA[k] + sa[k]) - SA[k], which is the
+        // class up to one rounding and exactly 0 for a class that the cumulative sum absorbs (empty, or a residue of 1e-17 mm of either
+        // sign under 100 mm).  Formed on the thread's own lower edge: the plain differences of the block scan are only that consistent
+        // inside a thread (one ulp of either sign across lanes, which the limiter would turn into a selected 1e-14 mm of an empty
+        // class, or -- a negative residue in a trial StorAge of RK4 under a flux of 0 -- into the whole distribution).
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double edge = (j == 0) ? lo : SA[j > 0 ? j - 1 : 0];
+            sa_src[j] = (edge + raw[j]) - edge;
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            SA[j] *= m;
+            sa_src[j] *= m;
+        }
+        S_top *= m;
+        if (!masked) {
+            // a trial StorAge of the Runge-Kutta scheme may hold negative classes (its third stage limits the change by
+            // `sarkn - dsarkn < 0`): the cumulative sum is then not monotone and max(SA) (over all nages edges, SA[0] = 0 included) is
+            // not its top value
+            double mx = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) mx = fmax(mx, SA[j]);
+            S_top = blk_max<W>(B, mx);
+        }
+    }
+    const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
+    const double *p = (const double *)arr5(P, SA_sas_params_evap_soil, f) + cell * 8;
+    euler_tt<W, E>(B, P, p, halve ? flux * scale / 2 : flux * scale, SA, sa_src, S_top, mk, base, masked, tt);
+    return flux;
+}
+
+// One sub-step of length h of the explicit Euler scheme (svat_transport_model_euler :2064-2414) or, RK4, of the Runge-Kutta scheme
+// (svat_transport_model_rk4 :1139-2047).
+// LAST: the last of the day, which also forms everything the reference overwrites in every sub-step -- concentrations of the fluxes,
+// distributions, statistics.  An instantiation of its own rather than a flag: inside the loop over the sub-steps the compiler hoists
+// the addresses of all those output arrays out of the loop and spills them (measured: 85 VGPRs, with their reloads in every sub-step).
+//
+// RK4 for the isotopes: the intermediate signals (msarkn, mttrkn) never reach the result -- the final mtt is calc_mtt on the state after
+// the infiltration (:1878-1896) -- so only the trial StorAges are followed:
+//   stage 1 on the state, fluxes * h;      the trial StorAge moves by (net outflow) * h       (:1388-1466, isotope branch)
+//   stage 2 on that,      fluxes * h / 2;  it moves by (net outflow) * h / 2                  (:1552-1580)
+//   stage 3 on that,      fluxes * h / 2;  it moves by (net outflow) * h / 2, limited by `sarkn - dsarkn < 0` as written (:1700-1728)
+//   stage 4 on that,      fluxes * h;      tt = (tt1 + 2 tt2 + 2 tt3 + tt4) / 6 (:1835-1855), then Euler's update with it (:1898-1941)
+template <int W, int E, bool LAST, bool RK4>
+SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int base, double h, double mk, double im, double ip, double is,
+                              double C_in, double (&sa_rz)[E], double (&msa_rz)[E], double (&sa_ss)[E], double (&msa_ss)[E]) {
+    // 1. upper boundary condition :2071-2145 (:1146-1220).  tt_inf is 1 in age class 0 and 0 elsewhere: for the other classes the mixing
+    //    reduces to msa * (sa / sa) where the class holds water (and, in the root zone, a positive signal), 0 otherwise
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         if (base + j == 0) {
@@ -211,79 +336,71 @@ SAS_DEV void euler_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int base, 
             ((double *)P.a[SA_C_iso_inf_mat_rz + w])[cell] = conc_to_delta(P, Ci) * mk;
         }
     }
-    // 2. + 3. the five fluxes (evap_soil, transp, q_rz from the root zone; q_ss, cpr_rz from the subsoil): flux * tt per class on
-    //    SA = calc_SA(sa) * maskCatch of the source (:2147-2155), formed when the loop reaches the storage's first flux (neither
-    //    StorAge changes before the update below).  The equality of the cumulative sum above the top of the stored water is restored
-    //    exactly (blk_cumsum): the differences of Omega there are exact zeros, as with the reference's sequential cumsum
-    double e_ev[E], e_tr[E], e_qrz[E], e_qss[E], e_cpr[E];
+    // 2. + 3. flux * tt per class of the five fluxes
+    FIVE(e);
     double SA[E], sa_src[E], S_top = 0.0;
+    if constexpr (!RK4) {
 #pragma unroll 1
-    for (int f = 0; f < 5; ++f) {
-        const bool from_ss = f >= 3;
-        if (f == 0 || f == 3) {
-            double lo_unused;
+        for (int f = 0; f < 5; ++f) {
+            double tt[E];
+            const double flux = one_flux<W, E>(B, P, cell, base, f, h, false, mk, true, sa_rz, sa_ss, SA, sa_src, S_top, tt);
+            if constexpr (LAST) flux_outputs<W, E>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk);
 #pragma unroll
-            for (int j = 0; j < E; ++j) sa_src[j] = from_ss ? sa_ss[j] : sa_rz[j];
-            blk_cumsum<W, E, true>(B, sa_src, SA, lo_unused, &S_top, base, A - 1);
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                SA[j] *= mk;
-                sa_src[j] *= mk;
-            }
-            S_top *= mk;
+            for (int j = 0; j < E; ++j) SET5(e, f, j, flux * tt[j]);
         }
-        const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
-        const double *p = (const double *)arr5(P, SA_sas_params_evap_soil, f) + cell * 8;
-        double tt[E];
-        euler_tt<W, E>(B, P, p, flux * h, SA, sa_src, S_top, mk, base, tt);
-        if constexpr (LAST) {   // concentrations, distributions and their statistics are those of the last sub-step
-            double mtt[E], s[2] = {0.0, 0.0};
+    } else {
+        double s_rz[E], s_ss[E];
+        FIVE(acc);
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                mtt[j] = (tt[j] > 0 ? (from_ss ? msa_ss[j] : msa_rz[j]) : 0);   // calc_mtt :565-596, isotopes
-                s[0] += mtt[j] * tt[j];
-                s[1] += tt[j];
-            }
-            blk_sum<W, 2>(B, s);
-            if (B.tid == 0) {   // calc_conc_iso_flux :512-535
-                double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
-                conc = (conc != 0 ? conc : NAN);
-                const double Cf = conc * mk;
-                ((double *)arr5(P, SA_C_evap_soil, f))[cell] = Cf;
-                ((double *)arr5(P, SA_C_iso_evap_soil, f))[cell] = conc_to_delta(P, Cf) * mk;
-            }
-            const bool want_stats = P.stats && (f == 1 || f == 3);
-            if (P.diag || want_stats) {
-                double TT_hi[E], TT_lo;
-                blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-                if (want_stats) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
-                if (P.diag) {
-                    double *o_tt = (double *)arr5(P, SA_tt_evap_soil, f) + cell * A;
-                    double *o_mtt = (double *)arr5(P, SA_mtt_evap_soil, f) + cell * A;
-                    double *o_TT = (double *)arr5(P, SA_TT_evap_soil, f) + cell * (A + 1);
-                    if (B.tid == 0) o_TT[0] = 0.0;
+        for (int j = 0; j < E; ++j) {
+            s_rz[j] = sa_rz[j];
+            s_ss[j] = sa_ss[j];
+        }
+#pragma unroll 1
+        for (int stage = 0; stage < 4; ++stage) {
+            const bool half = (stage == 1 || stage == 2);
+            const double w = half ? 2.0 : 1.0;
+#pragma unroll 1
+            for (int f = 0; f < 5; ++f) {
+                double tt[E];
+                const double flux = one_flux<W, E>(B, P, cell, base, f, h, half, mk, stage == 0, s_rz, s_ss, SA, sa_src, S_top, tt);
 #pragma unroll
-                    for (int j = 0; j < E; ++j)
-                        if (base + j < A) {
-                            o_tt[base + j] = tt[j];
-                            o_mtt[base + j] = mtt[j];
-                            o_TT[base + j + 1] = TT_hi[j];
-                        }
+                for (int j = 0; j < E; ++j) {
+                    SET5(acc, f, j, stage == 0 ? tt[j] : get5<E>(f, j, FIVE_ARGS(acc)) + w * tt[j]);   // (tt1 + 2 * tt2 + 2 * tt3 + tt4), left to right
+                    SET5(e, f, j, flux * tt[j]);
+                }
+            }
+            if (stage < 3) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    double d_rz = (e_cpr[j] - e_ev[j] - e_tr[j] - e_qrz[j]) * h;
+                    double d_ss = (e_qrz[j] - e_cpr[j] - e_qss[j]) * h;
+                    if (stage > 0) {
+                        d_rz = d_rz / 2;
+                        d_ss = d_ss / 2;
+                    }
+                    const double t_rz = (stage == 2) ? s_rz[j] - d_rz : s_rz[j] + d_rz;
+                    const double t_ss = (stage == 2) ? s_ss[j] - d_ss : s_ss[j] + d_ss;
+                    d_rz = (t_rz < 0) ? -s_rz[j] : d_rz;
+                    d_ss = (t_ss < 0) ? -s_ss[j] : d_ss;
+                    s_rz[j] += d_rz;
+                    s_ss[j] += d_ss;
                 }
             }
         }
+#pragma unroll 1
+        for (int f = 0; f < 5; ++f) {
+            const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
+            double tt[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const double e = flux * tt[j];
-            if (f == 0) e_ev[j] = e;
-            else if (f == 1) e_tr[j] = e;
-            else if (f == 2) e_qrz[j] = e;
-            else if (f == 3) e_qss[j] = e;
-            else e_cpr[j] = e;
+            for (int j = 0; j < E; ++j) tt[j] = get5<E>(f, j, FIVE_ARGS(acc)) / 6.;
+            if constexpr (LAST) flux_outputs<W, E>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk);
+#pragma unroll
+            for (int j = 0; j < E; ++j) SET5(e, f, j, flux * tt[j]);
         }
     }
 
-    // 4. update of both StorAges :2266-2310
+    // 4. update of both StorAges :2266-2310 (:1898-1941)
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         double dsa_rz = (e_cpr[j] - e_ev[j] - e_tr[j] - e_qrz[j]) * h;
@@ -312,8 +429,18 @@ SAS_DEV void euler_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int base, 
 #ifndef RH_EULER_WAVES
 #define RH_EULER_WAVES 2
 #endif
+template <int W, int E, bool RK4>
+__device__ __forceinline__ void explicit_body(const SasArgs &P);
 template <int W, int E>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER_WAVES, RH_EULER_WAVES))) void k_sas_euler(const SasArgs P) {
+    explicit_body<W, E, false>(P);
+}
+template <int W, int E>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER_WAVES, RH_EULER_WAVES))) void k_sas_rk4(const SasArgs P) {
+    explicit_body<W, E, true>(P);
+}
+template <int W, int E, bool RK4>
+__device__ __forceinline__ void explicit_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     __shared__ double2 s_logt[64];
@@ -349,8 +476,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER
     const double im = ((const double *)P.a[SA_inf_mat_rz])[P.day_off + cell], ip = ((const double *)P.a[SA_inf_pf_rz])[P.day_off + cell];
     const double is = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell], C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
 
-    for (int it = 0; it + 1 < P.substeps; ++it) euler_substep<W, E, false>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
-    euler_substep<W, E, true>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
+    for (int it = 0; it + 1 < P.substeps; ++it)
+        explicit_substep<W, E, false, RK4>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
+    explicit_substep<W, E, true, RK4>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
 
     ageing<W, E>(B, A, base, sa_rz, msa_rz);
     ageing<W, E>(B, A, base, sa_ss, msa_ss);
@@ -369,19 +497,20 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER
 }
 
 template <int W, int E>
-static void launch_euler(hipStream_t stream, const SasArgs &args) {
-    hipLaunchKernelGGL((k_sas_euler<W, E>), dim3((unsigned)args.n), dim3(W * 64), 0, stream, args);
+static void launch_explicit(int solver, hipStream_t stream, const SasArgs &args) {
+    if (solver == RH_SAS_SOLVER_RK4) hipLaunchKernelGGL((k_sas_rk4<W, E>), dim3((unsigned)args.n), dim3(W * 64), 0, stream, args);
+    else hipLaunchKernelGGL((k_sas_euler<W, E>), dim3((unsigned)args.n), dim3(W * 64), 0, stream, args);
 }
 
 // The whole day of an explicit solver in one launch; the smallest workgroup whose blocked layout covers the age classes.
 int rh_sas_launch_solver(int solver, hipStream_t stream, const SasArgs &args) {
-    if (solver != RH_SAS_SOLVER_EULER) return RH_ERR_ARG;
+    if (solver != RH_SAS_SOLVER_EULER && solver != RH_SAS_SOLVER_RK4) return RH_ERR_ARG;
     const int nages = args.ages + 1;
-    if (nages <= 64) launch_euler<1, 1>(stream, args);
-    else if (nages <= 256) launch_euler<1, 4>(stream, args);
-    else if (nages <= 512) launch_euler<2, 4>(stream, args);
-    else if (nages <= 1024) launch_euler<4, 4>(stream, args);
-    else if (nages <= 2048) launch_euler<8, 4>(stream, args);
-    else launch_euler<8, 8>(stream, args);   // (sixteen waves would leave 128 registers per thread: 700 spilled)
+    if (nages <= 64) launch_explicit<1, 1>(solver, stream, args);
+    else if (nages <= 256) launch_explicit<1, 4>(solver, stream, args);
+    else if (nages <= 512) launch_explicit<2, 4>(solver, stream, args);
+    else if (nages <= 1024) launch_explicit<4, 4>(solver, stream, args);
+    else if (nages <= 2048) launch_explicit<8, 4>(solver, stream, args);
+    else launch_explicit<8, 8>(solver, stream, args);   // (sixteen waves would leave 128 registers per thread: 700 spilled)
     return RH_OK;
 }

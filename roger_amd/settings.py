@@ -74,15 +74,15 @@ def check_setting_conflicts(settings):
             raise NotImplementedError("offline transport on the hip backend is implemented for oxygen-18, deuterium, bromide, chloride "
                                       "and the virtual tracer (exactly one of settings.enable_oxygen18 / enable_deuterium / "
                                       "enable_bromide / enable_chloride / enable_virtualtracer must be True)")
-        if settings.sas_solver not in ("deterministic", "Euler"):
-            raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the hip backend implements the '
-                                      '"deterministic" and the explicit "Euler" SAS solver (RK4 is not implemented)')
-        if settings.sas_solver == "Euler":
+        if settings.sas_solver not in ("deterministic", "Euler", "RK4"):
+            raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the SAS solvers are "deterministic" and the '
+                                      'explicit "Euler" and "RK4" (roger/settings.py:119)')
+        if settings.sas_solver in ("Euler", "RK4"):
             if not (settings.enable_oxygen18 or settings.enable_deuterium):
-                raise NotImplementedError('settings.sas_solver="Euler" is implemented for the isotope tracers (oxygen-18, deuterium)')
+                raise NotImplementedError(f'settings.sas_solver="{settings.sas_solver}" is implemented for the isotope tracers (oxygen-18, deuterium)')
             # benchmarks/SVATOXYGEN18_benchmark.py:30-31: the increment of the numerical solver is the length of a sub-step
             if abs(settings.h * settings.sas_solver_substeps - 1) > 1e-12:
-                raise ValueError("settings.h must be 1 / settings.sas_solver_substeps for the Euler solver")
+                raise ValueError("settings.h must be 1 / settings.sas_solver_substeps for the explicit solvers")
         if settings.nages != settings.ages + 1:
             raise ValueError("settings.nages must be settings.ages + 1")
         return

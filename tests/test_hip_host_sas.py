@@ -14,7 +14,7 @@ from test_host_package_sas import bromide_model, golden_inputs, interior, run_an
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_power_a40", "sas_deuterium_a40", "sas_euler_a40"])
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_power_a40", "sas_deuterium_a40", "sas_euler_a40", "sas_rk4_a40"])
 def test_transport_setup_on_device(case):
     g = sb.SasGolden(case)
     svat, sas = golden_inputs(g)

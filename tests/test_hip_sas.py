@@ -407,7 +407,7 @@ def test_closed_form_exponents_against_oracle():
 # ---- settings.sas_solver = "Euler" (roger_amd/csrc/rh_sas_solvers.hip) -----------------------------------------------------------
 @pytest.mark.parametrize("case", [c for c in SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))])
 def test_explicit_solver_single_days_from_reference_states(case):
-    """Each day of the reference's run with the explicit Euler solver (svat_transport_model_euler, transport.py:2064-2414) restarted
+    """Each day of the reference's run with an explicit solver (svat_transport_model_euler, transport.py:2064-2414; _rk4 :1139-2047) restarted
     on the device from the reference's own state: every output within rtol 1e-10.  The explicit scheme empties a class by an exact
     `dsa = -sa`, it has no residue ties."""
     g = SasGolden(case)
@@ -447,20 +447,28 @@ def test_explicit_solver_trajectory(case):
     ctx.close()
 
 
+@pytest.mark.parametrize("solver", ["Euler", "RK4"])
 @pytest.mark.parametrize("n,ages,substeps,stats", [(96, 1000, 6, True), (200, 300, 3, False), (64, 1500, 2, False),
                                                   (64, 2500, 2, True), (300, 17, 4, True), (150, 100, 5, True)])
-def test_explicit_solver_random_columns_against_oracle(n, ages, substeps, stats):
-    """Every workgroup shape of the Euler kernel on random columns with all SAS families, three days in a row, against the oracle's
+def test_explicit_solver_random_columns_against_oracle(n, ages, substeps, stats, solver):
+    """Every workgroup shape of the Euler / RK4 kernels on random columns with all SAS families, three days in a row, against the oracle's
     restatement on the host: all outputs at rtol 1e-10 (statistics 1e-9).  Columns with a kumaraswami flux are held to 1e-6: with an
     exponent b < 1 its Omega = 1 - (1 - (SA / S)**a)**b is infinitely steep at SA = S, one ulp of the cumulative StorAge below the top
-    (sequential cumsum on the host, block scan on the device) moves Omega by (1e-16)**b."""
-    st = random_problem(n, ages, substeps, seed=7 * ages + n, stats=stats, solver="Euler")
+    (sequential cumsum on the host, block scan on the device) moves Omega by (1e-16)**b.
+
+    RK4 has a tie of its own: the trial StorAges of its stages keep residues of either sign (1e-17 mm) where a class was emptied, the
+    reference's limiter `where(diff(SA) + ttq < 0, -diff(SA), ttq)` selects a negative residue and the normalisation blows it up to a whole
+    distribution when the flux itself is 0 -- unless the sequential cumsum absorbs the residue (diff(SA) == 0).  Whether it does depends on
+    the last bit of the cumulative sum below the class, which the block scan does not share: single columns (measured: 2 of 300, 1 of 150)
+    flip a sixth of a distribution.  They are counted (at most max(2, 1 %) new ones per day) and left out afterwards."""
+    st = random_problem(n, ages, substeps, seed=7 * ages + n, stats=stats, solver=solver)
     ref = clone(st)
     ctx = make_ctx(st)
     steep = np.zeros(n, bool)
     for f in FLUXES:
         steep |= np.isin(st.sas[f][:, 0], [3, 31, 32, 33, 34, 35, 36, 37])
     assert 0 < steep.sum() < n
+    tied = np.zeros(n, bool)
     for day in range(3):
         if day == 0:
             push(ctx, st)
@@ -480,9 +488,13 @@ def test_explicit_solver_random_columns_against_oracle(n, ages, substeps, stats)
             ok = np.isclose(a, b, rtol=1e-9 if is_stat else 1e-10, atol=1e-12, equal_nan=True).reshape(n, -1).all(axis=1)
             ok[steep] = np.isclose(a, b, rtol=1e-6, atol=1e-8, equal_nan=True).reshape(n, -1).all(axis=1)[steep]
             bad |= ~ok
-            if not ok.all():
-                print(f"day {day} {k}: max dev {np.nanmax(np.abs(a - b))} in columns {np.argwhere(~ok).ravel()[:6]}")
-        assert not bad.any(), f"day {day}: columns {np.argwhere(bad).ravel()[:10]} deviate"
+            if not (ok | tied).all():
+                print(f"day {day} {k}: max dev {np.nanmax(np.abs(a - b))} in columns {np.argwhere(~ok & ~tied).ravel()[:6]}")
+        new = bad & ~tied
+        allowed = max(2, n // 100) if solver == "RK4" else 0
+        print(f"TIES {solver} random columns {(n, ages, substeps)} day {day}: {int(new.sum())} new, allowed {allowed}")
+        assert new.sum() <= allowed, f"day {day}: columns {np.argwhere(new).ravel()[:10]} deviate"
+        tied |= bad
     ctx.close()
 
 

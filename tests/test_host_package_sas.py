@@ -64,7 +64,7 @@ def oracle_sas(monkeypatch):
     monkeypatch.setattr(_native, "SasContext", OracleSasContext)
 
 
-@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70", "sas_deuterium_a40", "sas_euler_a40"])
+@pytest.mark.parametrize("case", ["sas_stats_a30", "sas_mixed_a70", "sas_deuterium_a40", "sas_euler_a40", "sas_rk4_a40"])
 def test_transport_setup_through_host_package(oracle_sas, case):
     g = sb.SasGolden(case)
     svat, sas = golden_inputs(g)
@@ -86,7 +86,7 @@ def test_transport_settings_are_checked(oracle_sas):
     svat, sas = golden_inputs(g)
     with pytest.raises(NotImplementedError, match="deterministic"):
         make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
-            override=dict(sas_solver="RK4")).setup()
+            override=dict(sas_solver="Heun")).setup()
     with pytest.raises(ValueError, match="settings.h"):   # benchmarks/SVATOXYGEN18_benchmark.py:30-31
         make_transport_model("roger_amd", svat, sas, g.ages, g.substeps, g.ndays, False).__class__(
             override=dict(sas_solver="Euler")).setup()
