@@ -11,6 +11,8 @@ what=${2:-all}
 out=gpurun_out/profiles
 scratch=gpurun_out/prof_scratch
 mkdir -p $out $scratch
+# records of kernels / sizes that this call does not measure again stay as they are
+for f in traffic.json sas_valu.json; do [ -f $out/$f ] || cp profiles/$f $out/$f 2> /dev/null; done
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export PYTHONUNBUFFERED=1
 last() { tail -n 1 "$1"; }
@@ -28,6 +30,18 @@ pmc_pair() {   # key, kernel substring, n_cells, calib_cells, program args... (e
 }
 
 if [ "$what" = all ] || [ "$what" = svat ]; then
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 1000000 1000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=oned RH_PMC_SIZE=1000x1000
+  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 1000000 1000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=3200x3125
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 10000000 10000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=oned RH_PMC_SIZE=3200x3125
+  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 10000000 10000000 python3 tools/pmc_workload.py
+  export RH_PMC_MODEL=svat RH_PMC_SIZE=80x53
+  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 4240 4240 python3 tools/pmc_workload.py
+  unset RH_PMC_MODEL RH_PMC_SIZE
+  cp $out/traffic.json profiles/   # the bench lines take roofline.traffic from the records just written
   bench svat_1e6 --steps 200 --warmup 10
   bench svat_1e6_default
   bench svat_1e6_dt_classes --steps 600 --warmup 10 --no-cpu-baseline
@@ -43,37 +57,41 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_svat -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_svat.out 2> $scratch/stats_svat.err \
     && last $scratch/stats_svat.out > $out/${tag}_bench_svat_1e6_under_rocprof.json \
     && cp "$(find $scratch/stats_svat -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_svat_1e6.csv && echo "kernel stats svat ok"
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 1000000 1000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=oned RH_PMC_SIZE=1000x1000
-  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 1000000 1000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=3200x3125
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 10000000 10000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=oned RH_PMC_SIZE=3200x3125
-  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 10000000 10000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=80x53
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 4240 4240 python3 tools/pmc_workload.py
-  unset RH_PMC_MODEL RH_PMC_SIZE
 fi
 if [ "$what" = all ] || [ "$what" = sas ]; then
+  export RH_PMC_CALIB=1
+  pmc_pair k_sas_ages1000_sub6 "k_sas8<" 100000 1000000 python3 tools/sas_workload.py 100000 4
+  pmc_pair k_sas_euler_ages1000_sub6 "k_sas_euler<" 100000 1000000 python3 tools/sas_workload.py 100000 3 6 1 Euler
+  unset RH_PMC_CALIB
+  # VALU issue: wave-instructions of the SAS kernels per launch (SQ block, one pass), and the busy cycles beside them
+  valu() {   # key, workload args...
+    local key=$1; shift
+    rm -rf $scratch/pmc_valu
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $scratch/pmc_valu -- python3 tools/sas_workload.py "$@" > $scratch/pmc_valu.log 2>&1 \
+      && python3 tools/sas_valu_summarise.py $scratch/pmc_valu 100000 $out/sas_valu.json "tools/make_profiles.sh $tag: rocprofv3 --pmc SQ_INSTS_VALU ... on tools/sas_workload.py $*" $key \
+      && cp "$(find $scratch/pmc_valu -name '*counter_collection.csv' | head -1)" $scratch/sas_counters_$key.csv
+  }
+  valu ages1000_sub6 100000 4
+  valu euler_ages1000_sub6 100000 3 6 1 Euler
+  valu rk4_ages1000_sub6 100000 2 6 1 RK4
+  # the bench lines take roofline.traffic / roofline.compute from the records just written
+  cp $out/traffic.json $out/sas_valu.json profiles/
   bench sas_1e6 --model sas --steps 8 --warmup 2
+  # 10^5 columns: the size the counters below are collected at (bench.py fills roofline.traffic / roofline.compute from them on a later run)
+  bench sas_1e5 --model sas --size 1000 100 --steps 20 --warmup 2 --no-cpu-baseline
+  bench sas_1e5_euler --model sas --size 1000 100 --steps 10 --warmup 2 --sas-solver Euler --no-cpu-baseline
+  bench sas_1e5_rk4 --model sas --size 1000 100 --steps 6 --warmup 2 --sas-solver RK4 --no-cpu-baseline
   rm -rf $scratch/stats_sas
-  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_sas -- python3 bench.py --model sas --size 316 316 --steps 8 --warmup 2 --no-cpu-baseline > $scratch/stats_sas.out 2> $scratch/stats_sas.err \
+  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_sas -- python3 bench.py --model sas --size 1000 100 --steps 8 --warmup 2 --no-cpu-baseline > $scratch/stats_sas.out 2> $scratch/stats_sas.err \
     && last $scratch/stats_sas.out > $out/${tag}_bench_sas_1e5_under_rocprof.json \
     && cp "$(find $scratch/stats_sas -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_sas_1e5.csv && echo "kernel stats sas ok"
-  export RH_PMC_CALIB=1
-  pmc_pair k_sas_ages1000_sub6 "k_sas<" 100000 1000000 python3 tools/sas_workload.py 100000 4
-  unset RH_PMC_CALIB
-  # VALU issue: wave-instructions of the SAS kernel per launch (SQ block, one pass), and the busy cycles beside them
-  rm -rf $scratch/pmc_valu
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $scratch/pmc_valu -- python3 tools/sas_workload.py 100000 4 > $scratch/pmc_valu.log 2>&1 \
-    && python3 tools/sas_valu_summarise.py $scratch/pmc_valu 100000 $out/sas_valu.json "tools/make_profiles.sh $tag: rocprofv3 --pmc SQ_INSTS_VALU ... on tools/sas_workload.py 100000 4" \
-    && cp "$(find $scratch/pmc_valu -name '*counter_collection.csv' | head -1)" $scratch/sas_counters.csv && python3 - <<'PY'
-import csv, collections
+  python3 - <<'PY'
+import csv, collections, glob, os
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open("gpurun_out/prof_scratch/sas_counters.csv")):
-    rows[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open("gpurun_out/profiles/TAG_pmc_sas_valu_by_kernel.csv".replace("TAG", __import__("os").environ.get("RH_TAG", "r02")), "w") as f:
+for path in sorted(glob.glob("gpurun_out/prof_scratch/sas_counters_*.csv")):
+    for r in csv.DictReader(open(path)):
+        rows[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("gpurun_out/profiles/TAG_pmc_sas_valu_by_kernel.csv".replace("TAG", os.environ.get("RH_TAG", "r02")), "w") as f:
     f.write("kernel,counter,launches,average\n")
     for k, c in rows.items():
         for name, v in sorted(c.items()):
