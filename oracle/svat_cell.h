@@ -86,7 +86,11 @@
     X(F, q_sub_mp_share) X(F, q_sub_rz) X(F, q_sub_mat_rz) X(F, q_sub_mp_rz)    \
     X(F, q_sub_mp_pot_rz) X(F, q_sub_mat_pot_ss) X(F, q_sub_mp_pot_ss)          \
     X(F, q_sub_pot_ss) X(F, q_sub_ss) X(F, q_sub_mat_ss) X(F, q_sub_mp_ss)      \
-    X(F, q_sub_mat) X(F, q_sub_mp) X(F, q_sub)
+    X(F, q_sub_mat) X(F, q_sub_mp) X(F, q_sub)                                  \
+    /* unidirectional routing of surface and subsurface runoff (settings.enable_routing_1D) */ \
+    X(I, flow_dir_topo) X(I, outer_boundary) X(F, k_st) X(F, q_sur_out)         \
+    X(F, q_sur_in) X(F, q_sub_out) X(F, q_sub_in) X(F, q_sub_in_rz)             \
+    X(F, q_sub_in_ss)
 
 typedef struct oc_cell {
 #define OC_DECL_F(n) double n;
@@ -118,6 +122,9 @@ typedef struct oc_settings {
     int64_t end_event, hpi;
     int64_t enable_lateral_flow; /* oneD model: lateral subsurface runoff, settings.py:88 */
     double dx;                   /* grid spacing (m), enters the lateral flow rates */
+    int64_t enable_routing_1D;   /* settings.py:108: D8 routing of surface and subsurface runoff to the neighbour cell */
+    double dy;                   /* grid spacing in y (m), enters the routed surface runoff */
+    int64_t nx, ny;              /* the (local) interior grid, C order (x slow): routing gathers from the eight neighbours */
 } oc_settings;
 
 #endif

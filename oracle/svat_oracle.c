@@ -1280,6 +1280,80 @@ static void storage_cell(oc_cell *c, int64_t month_tau) {
     c->dS = c->S - c->S_m1 * mk;
 }
 
+/* ======================================================================== */
+/* unidirectional (D8) routing, settings.enable_routing_1D                    */
+/*   surface_runoff.calc_surface_runoff_routing_1D :14-227                    */
+/*   subsurface_runoff.calc_subsurface_runoff_routing_1D :1158-1437           */
+/* ======================================================================== */
+/* the reference's direction order of the *_d8 arrays: N, NE, E, SE, S, SW, W, NW; flow_dir_topo codes and where the water
+ * goes in (x, y) index space (`at[2:-2, 1:-3, 0]` for north: y - 1; `at[3:-1, 2:-2, 2]` for east: x + 1) */
+static const int D8_CODE[8] = {64, 128, 1, 2, 4, 8, 16, 32};
+static const int D8_DX[8] = {0, -1, 1, 1, 0, -1, -1, -1};
+static const int D8_DY[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+/* q_out of a cell: sum over the eight directions of where(flow_dir == code_d, q, 0) * maskCatch -- at most one term */
+static double d8_out(double q, int flow_dir, double mk) {
+    for (int d = 0; d < 8; ++d)
+        if (flow_dir == D8_CODE[d]) return (q * mk) * mk;
+    return 0.0 * mk;
+}
+/* q_in of cell (ix, iy): np.sum over the eight *_in_d8 entries, in_d8[c, d] = where(mask_d[s], out_d8[s, d], 0) * maskCatch[s] with
+ * s = c - (dx_d, dy_d) an INTERIOR cell (the slices only read [2:-2, 2:-2]); a sum of 8 contiguous values is numpy's unrolled
+ * pairwise block ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)) */
+static double d8_in(const double *q_out, const int32_t *flow_dir, const int32_t *mask, int64_t nx, int64_t ny, int64_t ix, int64_t iy) {
+    double a[8];
+    for (int d = 0; d < 8; ++d) {
+        const int64_t sx = ix - D8_DX[d], sy = iy - D8_DY[d];
+        a[d] = 0.0;
+        if (sx < 0 || sx >= nx || sy < 0 || sy >= ny) continue;
+        const int64_t s = sx * ny + sy;
+        a[d] = (flow_dir[s] == D8_CODE[d] ? q_out[s] : 0.0) * (double)mask[s];
+    }
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+static void route_surface_out_cell(oc_cell *c, const oc_settings *st, double dt_secs) {
+    const double mk = (double)c->maskCatch;
+    c->z0 += c->q_sof * mk;
+    const double area = (c->z0 / 1000) * 0.5 * (2 * st->dx) * mk;
+    const double perimeter = 2 * (c->z0 / 1000) + st->dx * mk;
+    const double radius = area / perimeter * mk;
+    /* surface runoff (m3/s to mm/dt) */
+    c->q_sur = c->k_st * pow(c->slope, 0.5) * pow(radius, 2.0 / 3.0) * area * (dt_secs / (st->dx * st->dy * 1000)) * mk;
+    c->q_sur = (c->q_sur > c->z0 ? c->z0 : c->q_sur) * mk;
+    c->q_sur_out = d8_out(c->q_sur, c->flow_dir_topo, mk);
+}
+static void route_surface_in_cell(oc_cell *c) {
+    const double mk = (double)c->maskCatch;
+    c->q_sur_in = c->q_sur_in * mk;
+    c->q_sur_in = (c->outer_boundary == 1 ? 0 : c->q_sur_in) * mk;
+    c->z0 += -c->q_sur_out * mk;
+    c->z0 += c->q_sur_in * mk;
+}
+static void route_subsurface_out_cell(oc_cell *c) {
+    c->q_sub_out = d8_out(c->q_sub, c->flow_dir_topo, (double)c->maskCatch);
+}
+static void route_subsurface_in_cell(oc_cell *c) { /* :1311-1437 */
+    const double mk = (double)c->maskCatch;
+    const double S1_rz = c->S_fp_rz + c->S_lp_rz, S1_ss = c->S_fp_ss + c->S_lp_ss;
+    c->q_sub_in = c->q_sub_in * mk;
+    c->q_sub_in = (c->outer_boundary == 1 ? 0 : c->q_sub_in) * mk;
+    c->z_sat += (c->q_sub_in / c->theta_ac) * mk;
+    c->z_sat = (c->z_sat < 0 ? 0 : c->z_sat) * mk;
+    c->S_zsat = c->z_sat * c->theta_ac * mk;
+    c->S_lp_ss += c->q_sub_in * mk;
+    const int over = c->S_lp_ss > c->S_ac_ss;
+    c->S_lp_rz += (over ? c->S_lp_ss - c->S_ac_ss : 0) * mk;
+    c->S_lp_ss = (over ? c->S_ac_ss : c->S_lp_ss) * mk;
+    /* saturation overland flow */
+    c->q_sof += (((c->S_lp_rz + c->S_fp_rz) > (c->S_ac_rz + c->S_ufc_rz)) ? (c->S_lp_rz + c->S_fp_rz) - (c->S_ac_rz + c->S_ufc_rz) : 0) * mk;
+    c->q_sur += c->q_sof * mk;
+    c->z0 += c->q_sof * mk;
+    const int sof = c->q_sof > 0;
+    c->S_fp_rz = (sof ? c->S_ufc_rz : c->S_fp_rz) * mk;
+    c->S_lp_rz = (sof ? c->S_ac_rz : c->S_lp_rz) * mk;
+    c->q_sub_in_rz = (c->S_fp_rz + c->S_lp_rz) - S1_rz;
+    c->q_sub_in_ss = (c->S_fp_ss + c->S_lp_ss) - S1_ss;
+}
+
 /* a13 numerics.calc_dS_num_error :303-345 and sanity_check :979-1011 */
 static int np_isclose(double a, double b, double atol, double rtol) {
     if (isfinite(a) && isfinite(b)) return fabs(a - b) <= atol + rtol * fabs(b);
@@ -1288,6 +1362,10 @@ static int np_isclose(double a, double b, double atol, double rtol) {
 static double nan0(double x) { return isnan(x) ? 0 : x; }
 
 static int num_error_cell(oc_cell *c, const oc_settings *st) {
+    if (st->enable_lateral_flow && st->enable_routing_1D) { /* numerics.py:247-270 */
+        c->dS_num_error = fabs((c->S - c->S_m1) - (c->prec - c->q_sur_out + c->q_sur_in - c->aet - c->q_ss - c->q_sub_out + c->q_sub_in));
+        return 0;
+    }
     if (st->enable_lateral_flow) { /* numerics.py:226-245: only dS_num_error in this branch */
         c->dS_num_error = fabs((c->S - c->S_m1) - (c->prec - c->q_sur - c->aet - c->q_ss - c->q_sub));
         return 0;
@@ -1301,6 +1379,8 @@ static int num_error_cell(oc_cell *c, const oc_settings *st) {
 static int sanity_cell(const oc_cell *c, const oc_settings *st) {
     double rhs = st->enable_lateral_flow ? c->prec - c->q_sur - c->aet - c->q_ss - c->q_sub /* numerics.py:744-759 */
                                          : c->prec - c->q_sur - c->aet - c->q_ss;
+    if (st->enable_lateral_flow && st->enable_routing_1D) /* numerics.py:778-798 */
+        rhs = c->prec - c->q_sur_out + c->q_sur_in - c->aet - c->q_ss - c->q_sub_out + c->q_sub_in;
     int check1 = c->maskCatch ? np_isclose(c->S - c->S_m1, rhs, st->atol, st->rtol) : 1;
     int check2 = (nan0(c->S_fp_rz) > -st->atol) && (nan0(c->S_lp_rz) > -st->atol) && (nan0(c->S_fp_ss) > -st->atol) &&
                  (nan0(c->S_lp_ss) > -st->atol);
@@ -1629,7 +1709,7 @@ static void infiltration_cell(oc_cell *c, const oc_settings *st, double dt, inf_
     inf_sc_cell(c, st, dt);
     inf_rz_cell(c);
     hof_sof_cell(c);
-    surface_runoff_cell(c);
+    if (!st->enable_routing_1D) surface_runoff_cell(c); /* infiltration.py:2189-2190 */
     if (k.cond4) reset_event_vars_cell(c);
 }
 
@@ -1639,6 +1719,25 @@ void oc_infiltration(void *const *planes, int64_t n, const oc_scalars *s, const 
 }
 void oc_subsurface_runoff(void *const *planes, int64_t n, const oc_scalars *s, const oc_settings *st) {
     FOR_CELLS(subsurface_runoff_cell(c, s->dt, st))
+}
+/* the gathers of the routing: q_in of every cell from its eight neighbours' q_out (whole local grid; a decomposed run would need the
+ * neighbour rank's edge column -- the reference itself never exchanges it, roger/core/utilities.py:79 is not called on this path) */
+static void route_gather(void *const *planes, const oc_settings *st, const char *src, const char *dst) {
+    const double *q_out = planes[plane_index(src)];
+    double *q_in = planes[plane_index(dst)];
+    const int32_t *fd = planes[plane_index("flow_dir_topo")], *mk = planes[plane_index("maskCatch")];
+    for (int64_t ix = 0; ix < st->nx; ++ix)
+        for (int64_t iy = 0; iy < st->ny; ++iy) q_in[ix * st->ny + iy] = d8_in(q_out, fd, mk, st->nx, st->ny, ix, iy);
+}
+void oc_surface_routing(void *const *planes, int64_t n, const oc_scalars *s, const oc_settings *st) {
+    FOR_CELLS(route_surface_out_cell(c, st, (double)s->dt_secs))
+    route_gather(planes, st, "q_sur_out", "q_sur_in");
+    FOR_CELLS(route_surface_in_cell(c))
+}
+void oc_subsurface_routing(void *const *planes, int64_t n, const oc_settings *st) {
+    FOR_CELLS(route_subsurface_out_cell(c))
+    route_gather(planes, st, "q_sub_out", "q_sub_in");
+    FOR_CELLS(route_subsurface_in_cell(c))
 }
 void oc_capillary_rise(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(capillary_rise_cell(c, s->dt)) }
 void oc_storage(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(storage_cell(c, s->month[1])) }
@@ -1685,6 +1784,31 @@ int oc_step_after_adt(void *const *planes, int64_t n, oc_scalars *s, const oc_se
     int ok = 1;
     s->itt += 1;
     s->time += s->dt_secs;
+    if (st->enable_routing_1D) { /* the routing couples the columns twice per step: three passes over the grid (roger/roger.py:410-447) */
+        FOR_CELLS(
+            if (monthly) params_surface_cell(c, &L, s->month[1]);
+            interception_cell(c, st);
+            evapotranspiration_cell(c, st);
+            snow_cell(c, st, s->dt);
+            infiltration_cell(c, st, s->dt, k);)
+        oc_surface_routing(planes, n, s, st);
+        FOR_CELLS(subsurface_runoff_cell(c, s->dt, st))
+        oc_subsurface_routing(planes, n, st);
+        FOR_CELLS_OK(
+            capillary_rise_cell(c, s->dt);
+            storage_cell(c, s->month[1]);
+            ok &= sanity_cell(c, st);
+            num_error_cell(c, st);
+            if (!core_only) after_timestep_cell(c, !st->enable_lateral_flow);)
+        s->sanity_ok = ok;
+        if (!core_only) {
+            s->event_id[0] = s->event_id[1];
+            s->year[0] = s->year[1];
+            s->month[0] = s->month[1];
+            s->doy[0] = s->doy[1];
+        }
+        return ok;
+    }
     FOR_CELLS_OK(
         if (monthly) params_surface_cell(c, &L, s->month[1]);
         interception_cell(c, st);

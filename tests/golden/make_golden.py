@@ -119,7 +119,7 @@ def tutorial_params():
     )
 
 
-def make_model(roger, params, forcing, ndays, lateral=False, weights=None, stations=None):
+def make_model(roger, params, forcing, ndays, lateral=False, weights=None, stations=None, routing=None):
     from roger import roger_routine
     from roger.models.svat import SVATSetup
     from roger.models.oneD import ONEDSetup
@@ -140,6 +140,9 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None, stati
             s.nitt_forc = len(F["PREC"])
             s.dx = 1
             s.dy = 1
+            if routing is not None:   # examples/hillslope_scale/oneD_distributed_routing_tutorial/oneD.py:72-85
+                s.enable_routing_1D = True
+                s.dx, s.dy = routing["dx"], routing["dy"]
             s.x_origin = 0.0
             s.y_origin = 0.0
             s.time_origin = "2018-01-01 00:00:00"
@@ -158,11 +161,23 @@ def make_model(roger, params, forcing, ndays, lateral=False, weights=None, stati
             vs.y = update(vs.y, at[3:-2], npx.cumsum(npx.ones(vs.y[3:-2].shape)))
 
         @roger_routine
+        def set_topography(self, state):
+            if routing is None:
+                return
+            vs = state.variables   # oneD_distributed_routing_tutorial/oneD.py:127-203: D8 flow direction, catchment boundary
+            vs.flow_dir_topo = update(vs.flow_dir_topo, at[2:-2, 2:-2], routing["flow_dir_topo"])
+            vs.inner_boundary = update(vs.inner_boundary, at[2:-2, 2:-2], 1)
+            vs.outer_boundary = update(vs.outer_boundary, at[2:-2, 2:-2], routing["outer_boundary"])
+            vs.maskCatch = update(vs.maskCatch, at[2:-2, 2:-2], 1)
+
+        @roger_routine
         def set_parameters_setup(self, state):
             vs = state.variables
             for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf",
                       "sealing", "S_dep_tot"):
                 setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], params[k]))
+            if routing is not None:   # Strickler coefficient, oneD.py:330-335
+                vs.k_st = update(vs.k_st, at[2:-2, 2:-2], routing["k_st"])
             if lateral:   # benchmarks/oneD_benchmark.py:106-117
                 vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
                 vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)
@@ -283,6 +298,7 @@ ROUTINES = (
     ("evapotranspiration", "calculate_evapotranspiration"),
     ("snow", "calculate_snow"),
     ("infiltration", "calculate_infiltration"),
+    ("surface_runoff", "calculate_surface_runoff"),   # (does nothing unless settings.enable_routing_1D)
     ("subsurface_runoff", "calculate_subsurface_runoff"),
     ("capillary_rise", "calculate_capillary_rise"),
     ("soil", "calculate_soil"),  # last of the four storage routines
@@ -291,10 +307,10 @@ ROUTINES = (
 
 
 def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine_steps, outdir, lateral=False,
-             pair_every=0, weights=None, stations=None):
+             pair_every=0, weights=None, stations=None, routing=None):
     import importlib
 
-    model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights, stations=stations)
+    model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights, stations=stations, routing=routing)
     planes = plane_names()
     rec = {}
     routine_log = {}
@@ -359,6 +375,9 @@ def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine
         rec["lut_gcm"] = np.asarray(vs.lut_gcm, dtype=np.float64)
         rec["lut_rdlu"] = np.asarray(vs.lut_rdlu, dtype=np.float64)
         rec["lateral"] = np.array(int(lateral))
+        if routing is not None:
+            rec["routing"] = np.array(1)
+            rec["routing_dx_dy"] = np.array([routing["dx"], routing["dy"]], dtype=np.float64)
         if lateral:
             rec["lut_mlms"] = np.asarray(vs.lut_mlms, dtype=np.float64)[:200]  # slopes 1..200 %
         for k, v in forcing.items():
@@ -494,6 +513,23 @@ def main():
         # rounding residue; parity is therefore also pinned step by step from reference states
         run_case(roger, name, params, forcing, ndays, max_steps, snap_every, rsteps, args.out, lateral=True,
                  pair_every=10)
+
+    # settings.enable_routing_1D (examples/hillslope_scale/oneD_distributed_routing_tutorial): surface and subsurface runoff move to the
+    # D8 neighbour.  A 4 x 6 hillslope draining mostly towards +y with diagonal and sideways cells, one pit (no direction), one interior
+    # outlet cell (outer_boundary = 1: takes no inflow), water leaving over the edge of the grid
+    if not args.only or args.only == "oned_routing":
+        nx, ny = 4, 6
+        rng = np.random.default_rng(31)
+        flow = np.full((nx, ny), 4)
+        flow[0, 1], flow[1, 2], flow[2, 0], flow[3, 3] = 2, 8, 1, 16     # SE, SW, E, W
+        flow[1, 4], flow[2, 3], flow[0, 4] = 128, 32, 64                 # NE, NW, N
+        flow[3, 1] = 0                                                   # a pit
+        outer = np.zeros((nx, ny), dtype=int)
+        outer[2, 5] = 1
+        p = oned_params(nx, ny, 23)
+        routing = dict(flow_dir_topo=flow, outer_boundary=outer, k_st=rng.uniform(8, 30, (nx, ny)), dx=5, dy=5)
+        run_case(roger, "oned_routing", p, toy_forcing("heavyrain", ndays=4), 4, 100000, 25, {1, 2, 30, 31, 60}, args.out,
+                 lateral=True, pair_every=10, routing=routing)
 
 
 if __name__ == "__main__":

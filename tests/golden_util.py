@@ -8,6 +8,8 @@ SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrai
               "svat_tutorial")   # the last: BASELINE configs[0], one cell, a year of measured forcing
 # oneD model: lateral subsurface flow; the last: BASELINE configs[3]'s own uniform parameter set (benchmarks/oneD_benchmark.py:99-135)
 ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo", "oned_uniform_benchmark")
+# settings.enable_routing_1D: surface and subsurface runoff routed to the D8 neighbour (oneD_distributed_routing_tutorial)
+ROUTING_CASES = ("oned_routing",)
 CASES = SVAT_CASES + ONED_CASES
 # BASELINE configs[4] (Eberbaechle, svat_distributed): the station's measured series x per-cell prec_weight / ta_offset / pet_weight
 WEIGHTED_CASES = ("svat_eberbaechle_weights",)
@@ -48,6 +50,20 @@ def load_stations(g):
 
 def is_lateral(g):
     return bool(int(g["lateral"])) if "lateral" in g.files else False
+
+
+def is_routing(g):
+    return bool(int(g["routing"])) if "routing" in g.files else False
+
+
+def configure_settings(settings, g):
+    """The model switches of a golden case on an oracle-side settings struct (oracle_binding.OcSettings)."""
+    settings.enable_lateral_flow = int(is_lateral(g))
+    nx, ny = (int(v) for v in g["nx_ny"])
+    settings.nx, settings.ny = nx, ny
+    if is_routing(g):
+        settings.enable_routing_1D = 1
+        settings.dx, settings.dy = (float(v) for v in g["routing_dx_dy"])
 
 
 def compare(got, ref, names, rtol=RTOL, atol=ATOL, what=""):

@@ -30,7 +30,8 @@ class OcSettings(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min", "clay_max",
         "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max", "a_bc", "b_bc",
-    )] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("enable_lateral_flow", C.c_int64), ("dx", C.c_double)]
+    )] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("enable_lateral_flow", C.c_int64), ("dx", C.c_double),
+         ("enable_routing_1D", C.c_int64), ("dy", C.c_double), ("nx", C.c_int64), ("ny", C.c_int64)]
 
 
 def default_settings():
@@ -39,7 +40,7 @@ def default_settings():
         pi=3.14159265358979323846264338327950588, r_mp=2.5, l_sc=10000, sf=3, ta_fm=0, rmax=30,
         transp_water_stress=0.75, atol=1e-2, rtol=1e-2, clay_min=0.01, clay_max=0.71, theta_rew_min=0.02,
         theta_rew_max=0.24, rew_min=2, rew_max=12, z_evap_max=150, zroot_to_zsoil_max=0.7, a_bc=2, b_bc=2,
-        end_event=21600, hpi=5, enable_lateral_flow=0, dx=1.0,
+        end_event=21600, hpi=5, enable_lateral_flow=0, dx=1.0, enable_routing_1D=0, dy=1.0, nx=0, ny=0,
     )
 
 
@@ -95,13 +96,18 @@ class OracleState:
 
     # -- loading from golden snapshots -------------------------------------------------
     def load_snapshot(self, snap, names=None):
+        """`names`: the plane list of the golden file the snapshot comes from (files written before a field was added to the
+        oracle hold fewer planes); snapshot() then returns that list's planes, in its order."""
+        if names is not None:
+            self._view = [nm for nm in names]
         names = list(names) if names is not None else self.names
         for row, nm in zip(snap, names):
             if nm in self.planes:
                 self.planes[nm][:] = row.astype(self.planes[nm].dtype)
 
-    def snapshot(self):
-        return np.stack([self.planes[nm].astype(np.float64) for nm in self.names])
+    def snapshot(self, names=None):
+        names = names if names is not None else getattr(self, "_view", self.names)
+        return np.stack([self.planes[nm].astype(np.float64) for nm in names])
 
     def load_scalars(self, row):
         i = 0
@@ -151,6 +157,14 @@ class OracleState:
 
     def subsurface_runoff(self):
         lib().oc_subsurface_runoff(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings))
+
+    def surface_routing(self):
+        """surface_runoff.calculate_surface_runoff (settings.enable_routing_1D)"""
+        lib().oc_surface_routing(self._ptrs, C.c_int64(self.n), C.byref(self.scal), C.byref(self.settings))
+
+    def subsurface_routing(self):
+        """the routing part of subsurface_runoff.calculate_subsurface_runoff"""
+        lib().oc_subsurface_routing(self._ptrs, C.c_int64(self.n), C.byref(self.settings))
 
     def capillary_rise(self):
         lib().oc_capillary_rise(self._ptrs, C.c_int64(self.n), C.byref(self.scal))

@@ -3,8 +3,8 @@ backend (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import (CASES, ONED_CASES, ONED_TIE_COLUMNS, STATION_CASES, WEIGHTED_CASES, compare, deviating_columns, is_lateral, load_case,
-                         load_stations, load_weights)
+from golden_util import (CASES, ONED_CASES, ONED_TIE_COLUMNS, ROUTING_CASES, STATION_CASES, WEIGHTED_CASES, compare, configure_settings,
+                         deviating_columns, is_lateral, load_case, load_stations, load_weights)
 
 
 def _start(ob, g, names, key="state0"):
@@ -13,7 +13,7 @@ def _start(ob, g, names, key="state0"):
     st.load_snapshot(g[key], names)
     st.load_scalars(g["scal0"])
     st.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
-    st.settings.enable_lateral_flow = int(is_lateral(g))
+    configure_settings(st.settings, g)
     return st
 
 
@@ -34,7 +34,7 @@ def single_step_pairs(g):
     return [k for k in have if k - 1 in have and k >= 2]
 
 
-@pytest.mark.parametrize("case", ONED_CASES)
+@pytest.mark.parametrize("case", ONED_CASES + ROUTING_CASES)
 def test_single_steps_from_reference_states(oracle, case):
     """oneD model: one step from the reference's state k-1 must give the reference's state k.  (The
     oneD model keeps the rounding residue of emptied stores -- no snap-to-zero as in the SVAT
@@ -53,10 +53,10 @@ def test_single_steps_from_reference_states(oracle, case):
         pd, td, ed, monthly = drv.before_step(st)
         st.step(pd, td, ed, monthly)
         np.testing.assert_array_equal(st.scalars_row(), g["scal"][k - 1], err_msg=f"{case} scalars step {k}")
-        compare(st.snapshot(), g[f"s{k:05d}"], st.names, what=f"{case} single step {k}")
+        compare(st.snapshot(), g[f"s{k:05d}"], names, what=f"{case} single step {k}")
 
 
-@pytest.mark.parametrize("case", CASES + WEIGHTED_CASES + STATION_CASES)
+@pytest.mark.parametrize("case", CASES + WEIGHTED_CASES + STATION_CASES + ROUTING_CASES)
 def test_trajectory(oracle, case):
     """Full steps (all routines fused per cell) reproduce the reference trajectory.  The weighted case pins the oracle's per-cell
     forcing path (a (n, 144) day per variable, `fstride = 144`) against the reference's own per-cell prec_day / ta_day / pet_day."""
@@ -76,15 +76,15 @@ def test_trajectory(oracle, case):
                 off |= deviating_columns(st.snapshot(), g[key])
                 assert len(off) <= ONED_TIE_COLUMNS[case] + 1, f"{case} step {step}: columns {sorted(off)} deviate"
             else:
-                compare(st.snapshot(), g[key], st.names, what=f"{case} step {step}")
+                compare(st.snapshot(), g[key], names, what=f"{case} step {step}")
             checked += 1
-        assert st.scal.sanity_ok == 1
+        assert st.scal.sanity_ok == 1 or case in ROUTING_CASES   # (the reference's routed water balance does not close: its own check fails)
     if case in ONED_TIE_COLUMNS:
         print(f"TIES {case}: columns {sorted(off)} parted from the reference")
     assert checked >= 3
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + ROUTING_CASES)
 def test_per_routine(oracle, case):
     """Each routine separately: start from the reference state before the routine, run the
     oracle routine, compare with the reference state after it."""
@@ -92,6 +92,9 @@ def test_per_routine(oracle, case):
     order = ["adaptive_time_stepping", "calculate_interception", "calculate_evapotranspiration", "calculate_snow",
              "calculate_infiltration", "calculate_subsurface_runoff", "calculate_capillary_rise", "calculate_soil",
              "calc_storage"]
+    routed = case in ROUTING_CASES
+    if routed:
+        order.insert(5, "calculate_surface_runoff")
     steps = sorted({int(k[1:6]) for k in g.files if k.startswith("r") and k.endswith("_calc_storage")})
     assert steps
     nchecked = 0
@@ -105,7 +108,8 @@ def test_per_routine(oracle, case):
                 "calculate_evapotranspiration": st.evapotranspiration,
                 "calculate_snow": st.snow,
                 "calculate_infiltration": st.infiltration,
-                "calculate_subsurface_runoff": st.subsurface_runoff,
+                "calculate_surface_runoff": st.surface_routing,
+                "calculate_subsurface_runoff": (lambda: (st.subsurface_runoff(), st.subsurface_routing())) if routed else st.subsurface_runoff,
                 "calculate_capillary_rise": st.capillary_rise,
                 "calculate_soil": st.storage,       # surface+root zone+subsoil+soil+calc_storage
                 "calc_storage": st.storage,
