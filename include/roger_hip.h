@@ -63,8 +63,11 @@ typedef struct rh_config {
     int32_t placement_probes; /* where the arena lands in HBM decides which of three bandwidth levels the fused kernel
                                  runs at (0.35 / 0.39 / 0.41 ms per step at 10^6 columns): rh_create
                                  allocates up to this many candidate arenas, times a streaming kernel on each and keeps
-                                 the fastest (default 8; 0 or 1: take the first; never more than free memory allows) */
-    int32_t reserved;
+                                 the fastest (default 1 = take the first; never more than a quarter of the free memory) */
+    int32_t enable_routing_1D; /* settings.enable_routing_1D (with enable_lateral_flow): surface and subsurface runoff move to
+                                  the D8 neighbour (rh_surface_routing / rh_subsurface_routing); the columns are then coupled
+                                  twice per step and the fused step (rh_svat_step, rh_run_steps) is not available */
+    double dy;        /* settings.dy, grid spacing in m (with dx: the routed surface runoff, surface_runoff.py:48-58) */
 } rh_config;
 
 /* Per-domain scalars of the reference (roger/variables.py:189-330).  event_id/year/month/doy
@@ -170,6 +173,30 @@ int rh_evapotranspiration(rh_ctx *ctx); /* calculate_evapotranspiration, core/ev
 int rh_snow(rh_ctx *ctx);               /* calculate_snow, core/snow.py:294-304 */
 int rh_infiltration(rh_ctx *ctx);       /* calculate_infiltration, core/infiltration.py:2148-2193 */
 int rh_subsurface_runoff(rh_ctx *ctx);  /* calculate_subsurface_runoff (SVAT branch), core/subsurface_runoff.py:1473-1479 */
+/* settings.enable_routing_1D (rh_config.enable_routing_1D): the D8 routing of surface and subsurface runoff.
+ *   rh_surface_routing    = calculate_surface_runoff, core/surface_runoff.py:240-250 -> calc_surface_runoff_routing_1D :14-227
+ *   rh_subsurface_routing = the routing part of calculate_subsurface_runoff, core/subsurface_runoff.py:1468-1469 ->
+ *                           calc_subsurface_runoff_routing_1D :1158-1437 (call it after rh_subsurface_runoff)
+ * Each is rh_route_out (per column: the outflow), the exchange of the edge columns with the x-neighbours over the context's RCCL
+ * communicator when it has more than one rank (rh_comm_init / rh_set_comm; the reference itself never exchanges them: with MPI its
+ * routed water is lost at the process boundaries), and rh_route_in (the gather from the eight neighbours + per column: the inflow).
+ * The pieces are exported for drivers that exchange the halos themselves: rh_route_get_edges / rh_route_get_static_edges return the
+ * rank's own edge columns x = 0 ("lo") and x = nx - 1 ("hi") (ny values each: q_out of the step; flow direction and mask, once),
+ * rh_route_set_halo hands in the neighbour's column for side 0 (x = -1) or 1 (x = nx); q may be NULL when only the static part is
+ * set, flow_dir / mask may be NULL afterwards.  `which`: 0 surface, 1 subsurface. */
+int rh_surface_routing(rh_ctx *ctx);
+int rh_subsurface_routing(rh_ctx *ctx);
+/* One whole step with the routing in the order of RogerSetup.step (roger/roger.py:396-457), routine by routine on the device:
+ * adaptive time stepping (over several ranks: the two predicate words all-reduced over the context's communicator), [monthly surface
+ * parameters], interception ... infiltration, rh_surface_routing, the lateral subsurface runoff, rh_subsurface_routing, capillary rise,
+ * storages, numerics, itt / time, after_timestep.  monthly: 1 / 0 = the caller's set_parameters decision, -1 = the device's (rh_run_steps
+ * takes this entry for a routing context). */
+int rh_step_routed(rh_ctx *ctx, int monthly);
+int rh_route_out(rh_ctx *ctx, int which);
+int rh_route_in(rh_ctx *ctx, int which);
+int rh_route_get_edges(rh_ctx *ctx, int which, double *q_lo, double *q_hi);
+int rh_route_get_static_edges(rh_ctx *ctx, int32_t *flow_dir_lo, int32_t *flow_dir_hi, int32_t *mask_lo, int32_t *mask_hi);
+int rh_route_set_halo(rh_ctx *ctx, int side, const double *q, const int32_t *flow_dir, const int32_t *mask);
 int rh_capillary_rise(rh_ctx *ctx);     /* calculate_capillary_rise, core/capillary_rise.py:346-358 */
 int rh_storage(rh_ctx *ctx);            /* calculate_surface/root_zone/subsoil/soil + numerics.calc_storage */
 int rh_num_error(rh_ctx *ctx);          /* numerics.sanity_check + calculate_num_error, core/numerics.py:716-1011 */

@@ -18,7 +18,8 @@ class RhConfig(C.Structure):
             "pi", "r_mp", "l_sc", "sf", "ta_fm", "rmax", "transp_water_stress", "atol", "rtol", "clay_min",
             "clay_max", "theta_rew_min", "theta_rew_max", "rew_min", "rew_max", "z_evap_max", "zroot_to_zsoil_max",
             "a_bc", "b_bc")
-    ] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("dx", C.c_double), ("placement_probes", C.c_int32), ("reserved", C.c_int32)]
+    ] + [("end_event", C.c_int64), ("hpi", C.c_int64), ("dx", C.c_double), ("placement_probes", C.c_int32), ("enable_routing_1D", C.c_int32),
+         ("dy", C.c_double)]
 
 
 class RhScalars(C.Structure):
@@ -40,7 +41,7 @@ _ENTRY_POINTS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise", "rh_storage",
     "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_sync", "rh_hooks_phase", "rh_step_core", "rh_params_lateral",
-    "rh_step_summary", "rh_adaptive_dt_finish",
+    "rh_step_summary", "rh_adaptive_dt_finish", "rh_surface_routing", "rh_subsurface_routing",
 )
 
 
@@ -99,6 +100,12 @@ def load():
     lib.rh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.rh_set_comm.argtypes = [vp, vp]
     lib.rh_run_steps_dist.argtypes = [vp, i64]
+    lib.rh_step_routed.argtypes = [vp, i32]
+    lib.rh_route_out.argtypes = [vp, i32]
+    lib.rh_route_in.argtypes = [vp, i32]
+    lib.rh_route_get_edges.argtypes = [vp, i32, vp, vp]
+    lib.rh_route_get_static_edges.argtypes = [vp, vp, vp, vp, vp]
+    lib.rh_route_set_halo.argtypes = [vp, i32, vp, vp, vp]
     lib.rh_diag_set_interval.argtypes = [vp, i64]
     lib.rh_diag_slot_times.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.rh_step_summary_expand.argtypes = [vp, vp]
@@ -350,6 +357,7 @@ DECLARED_SYMBOLS = (
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
+    "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
 
 
@@ -483,6 +491,37 @@ class Context:
 
     def run_steps(self, nsteps):
         self._check(self._lib.rh_run_steps(self._h, int(nsteps)), "rh_run_steps")
+
+    # -- routing (settings.enable_routing_1D) -----------------------------------------------------
+    def step_routed(self, monthly=False):
+        self._check(self._lib.rh_step_routed(self._h, -1 if monthly is None else int(bool(monthly))), "rh_step_routed")
+
+    def route_out(self, which):
+        self._check(self._lib.rh_route_out(self._h, int(which)), "rh_route_out")
+
+    def route_in(self, which):
+        self._check(self._lib.rh_route_in(self._h, int(which)), "rh_route_in")
+
+    def route_edges(self, which):
+        """(lo, hi): q_out of the rank's edge columns x = 0 and x = nx - 1 (what the x-neighbours' halos take)."""
+        lo, hi = np.empty(self.ny), np.empty(self.ny)
+        self._check(self._lib.rh_route_get_edges(self._h, int(which), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)),
+                    "rh_route_get_edges")
+        return lo, hi
+
+    def route_static_edges(self):
+        """(flow_dir_lo, flow_dir_hi, mask_lo, mask_hi) of the rank's edge columns."""
+        a = [np.empty(self.ny, dtype=np.int32) for _ in range(4)]
+        self._check(self._lib.rh_route_get_static_edges(self._h, *[x.ctypes.data_as(C.c_void_p) for x in a]), "rh_route_get_static_edges")
+        return tuple(a)
+
+    def route_set_halo(self, side, q=None, flow_dir=None, mask=None):
+        keep = [None if x is None else np.ascontiguousarray(x, dtype=dt) for x, dt in ((q, np.float64), (flow_dir, np.int32), (mask, np.int32))]
+        for x in keep:
+            if x is not None and x.size != self.ny:
+                raise ValueError(f"a halo column has ny = {self.ny} values, got {x.size}")
+        self._check(self._lib.rh_route_set_halo(self._h, int(side), *[None if x is None else x.ctypes.data_as(C.c_void_p) for x in keep]),
+                    "rh_route_set_halo")
 
     # -- routines -----------------------------------------------------------------------------
     def call(self, entry):

@@ -57,6 +57,15 @@ RH_DEV T *rh_cell(const Arena &a, int plane, int64_t i) {
     return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
 #endif
 }
+// Address of ANY cell of a plane (the routing's gather reads the eight neighbours: the tile is not uniform over the wavefront).
+template <typename T>
+RH_DEV T *rh_cell_any(const Arena &a, int plane, int64_t i) {
+#if RH_TILED
+    return reinterpret_cast<T *>(a.base + (size_t)(i >> 6) * a.stride + (size_t)plane * RH_SLOT_BYTES) + (int)(i & (RH_TILE_CELLS - 1));
+#else
+    return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
+#endif
+}
 // RH_NT: plane accesses as non-temporal (streaming) loads / stores -- every plane is touched once per kernel, nothing is worth
 // keeping in the caches.  bit 0: loads, bit 1: stores.  Measured on the fused step at 10^6 columns, alternating in one call
 // (tools/ab_variants.sh): 0.3158 ms plain, 0.3136 loads only, 0.3108 stores only, 0.3016 both (- 4.5 %); a plain copy with the
@@ -87,6 +96,8 @@ struct Consts {
     int64_t end_event, hpi;
     double dx;      // grid spacing in m (settings.dx), enters the lateral flow rates
     int lateral;    // settings.enable_lateral_flow (oneD model)
+    double dy;      // settings.dy (routing)
+    int routing;    // settings.enable_routing_1D
 };
 
 // Look-up tables, row-major (roger/lookuptables.py).

@@ -551,7 +551,8 @@ RH_DEV void h_inf_sc(Col &c, const Consts &K, double dt, int substeps, double mk
 }
 
 // root-zone bookkeeping, overland flow :1322-1532
-RH_DEV void h_inf_finish(Col &c, double mk) {
+// calc_inf_rz, calc_inf, calc_hof_and_sof :1322-1476
+RH_DEV void h_inf_rz_hof_sof(Col &c, double mk) {
     c.inf_mat_rz = c.inf_mat * mk;
     c.inf_sc_rz = c.inf_sc * mk;
     c.inf_rz = (c.inf_mat_rz + c.inf_mp_rz + c.inf_sc_rz) * mk;
@@ -577,11 +578,17 @@ RH_DEV void h_inf_finish(Col &c, double mk) {
     m = c.q_sof > 0;
     c.S_fp_rz = (m ? c.S_ufc_rz : c.S_fp_rz) * mk;
     c.S_lp_rz = (m ? c.S_ac_rz : c.S_lp_rz) * mk;
-    // surface runoff :1480-1516
+}
+// surface runoff :1480-1516 (not with settings.enable_routing_1D, :2189-2190: the ponded water stays and is routed)
+RH_DEV void h_surface_runoff(Col &c, double mk) {
     c.z0 += -c.q_hof * mk;
     c.z0 = (c.z0 < 0 ? 0.0 : c.z0) * mk;
     c.q_sur = 0.0 + (c.q_hof + c.q_sof) * mk;
     c.q_sur += (c.maskRiver || c.maskLake) ? c.prec : 0.0;
+}
+RH_DEV void h_inf_finish(Col &c, double mk) {
+    h_inf_rz_hof_sof(c, mk);
+    h_surface_runoff(c, mk);
 }
 
 // calculate_infiltration :2148-2193; X.cond1..5 are the host-side `if cond.any()` branches
@@ -617,6 +624,16 @@ RH_DEV void rt_infiltration(Col &c, const Consts &K, const StepCtx &X) {
     rt_inf_macropores(c, K, X);
     rt_inf_cracks(c, K, X);
     rt_inf_finish(c, K, X);
+}
+// ... with settings.enable_routing_1D: calc_surface_runoff is skipped (:2189-2190)
+RH_DEV void rt_infiltration_routed(Col &c, const Consts &K, const StepCtx &X) {
+    rt_inf_events(c, K, X);
+    rt_inf_matrix(c, K, X);
+    rt_inf_macropores(c, K, X);
+    rt_inf_cracks(c, K, X);
+    const double mk = (double)c.maskCatch;
+    h_inf_rz_hof_sof(c, mk);
+    if (X.cond4) h_event_end(c, mk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -924,6 +941,71 @@ RH_DEV bool rt_num_error(Col &c, const Consts &K) {
 // oneD model: numerics.py:226-245 (only dS_num_error) and the sanity check with q_sub :744-759
 RH_DEV bool rt_num_error_lateral(Col &c, const Consts &K) {
     const double lhs = c.S - c.S_m1, rhs = c.prec - c.q_sur - c.aet - c.q_ss - c.q_sub;
+    c.dS_num_error = fabs(lhs - rhs);
+    bool close = (isfinite(lhs) && isfinite(rhs)) ? (fabs(lhs - rhs) <= K.atol + K.rtol * fabs(rhs)) : (lhs == rhs);
+    close = c.maskCatch ? close : true;
+    const double a = h_nan0(c.S_fp_rz), b = h_nan0(c.S_lp_rz), d = h_nan0(c.S_fp_ss), e = h_nan0(c.S_lp_ss);
+    const bool lower = (a > -K.atol) && (b > -K.atol) && (d > -K.atol) && (e > -K.atol);
+    const bool upper = (a - K.atol <= h_nan0(c.S_ufc_rz)) && (b - K.atol <= h_nan0(c.S_ac_rz)) &&
+                       (d - K.atol <= h_nan0(c.S_ufc_ss)) && (e - K.atol <= h_nan0(c.S_ac_ss));
+    return !(close && lower && upper);
+}
+
+// ---------------------------------------------------------------------------------------------
+// unidirectional (D8) routing, settings.enable_routing_1D: the per-column parts.  Between `_out` and `_in` the gather kernel
+// (k_route_gather, roger_hip.hip) forms q_*_in of every cell from the q_*_out of its eight neighbours.
+//   surface_runoff.calc_surface_runoff_routing_1D :14-227, subsurface_runoff.calc_subsurface_runoff_routing_1D :1158-1437
+// ---------------------------------------------------------------------------------------------
+// sum over the eight directions of where(flow_dir == code_d, q, 0) * maskCatch: at most one term
+RH_DEV double h_d8_out(double q, int flow_dir, double mk) {
+    const bool has = flow_dir == 64 || flow_dir == 128 || flow_dir == 1 || flow_dir == 2 || flow_dir == 4 || flow_dir == 8 ||
+                     flow_dir == 16 || flow_dir == 32;
+    return has ? (q * mk) * mk : 0.0 * mk;
+}
+RH_DEV void rt_route_surface_out(Col &c, const Consts &K, const StepCtx &X, double dt_secs) {
+    const double mk = (double)c.maskCatch;
+    c.z0 += c.q_sof * mk;
+    const double area = (c.z0 / 1000) * 0.5 * (2 * K.dx) * mk;
+    const double perimeter = 2 * (c.z0 / 1000) + K.dx * mk;
+    const double radius = area / perimeter * mk;
+    // Manning-Strickler, m3/s to mm per step
+    c.q_sur = c.k_st * pow(c.slope, 0.5) * pow(radius, 2.0 / 3.0) * area * (dt_secs / (K.dx * K.dy * 1000)) * mk;
+    c.q_sur = (c.q_sur > c.z0 ? c.z0 : c.q_sur) * mk;
+    c.q_sur_out = h_d8_out(c.q_sur, c.flow_dir_topo, mk);
+}
+RH_DEV void rt_route_surface_in(Col &c) {
+    const double mk = (double)c.maskCatch;
+    c.q_sur_in = c.q_sur_in * mk;
+    c.q_sur_in = (c.outer_boundary == 1 ? 0.0 : c.q_sur_in) * mk;
+    c.z0 += -c.q_sur_out * mk;
+    c.z0 += c.q_sur_in * mk;
+}
+RH_DEV void rt_route_subsurface_out(Col &c) { c.q_sub_out = h_d8_out(c.q_sub, c.flow_dir_topo, (double)c.maskCatch); }
+RH_DEV void rt_route_subsurface_in(Col &c) {   // :1311-1437
+    const double mk = (double)c.maskCatch;
+    const double S1_rz = c.S_fp_rz + c.S_lp_rz, S1_ss = c.S_fp_ss + c.S_lp_ss;
+    c.q_sub_in = c.q_sub_in * mk;
+    c.q_sub_in = (c.outer_boundary == 1 ? 0.0 : c.q_sub_in) * mk;
+    c.z_sat += (c.q_sub_in / c.theta_ac) * mk;
+    c.z_sat = (c.z_sat < 0 ? 0.0 : c.z_sat) * mk;
+    c.S_zsat = c.z_sat * c.theta_ac * mk;
+    c.S_lp_ss += c.q_sub_in * mk;
+    const bool over = c.S_lp_ss > c.S_ac_ss;
+    c.S_lp_rz += (over ? c.S_lp_ss - c.S_ac_ss : 0.0) * mk;
+    c.S_lp_ss = (over ? c.S_ac_ss : c.S_lp_ss) * mk;
+    // saturation overland flow
+    c.q_sof += (((c.S_lp_rz + c.S_fp_rz) > (c.S_ac_rz + c.S_ufc_rz)) ? (c.S_lp_rz + c.S_fp_rz) - (c.S_ac_rz + c.S_ufc_rz) : 0.0) * mk;
+    c.q_sur += c.q_sof * mk;
+    c.z0 += c.q_sof * mk;
+    const bool sof = c.q_sof > 0;
+    c.S_fp_rz = (sof ? c.S_ufc_rz : c.S_fp_rz) * mk;
+    c.S_lp_rz = (sof ? c.S_ac_rz : c.S_lp_rz) * mk;
+    c.q_sub_in_rz = (c.S_fp_rz + c.S_lp_rz) - S1_rz;
+    c.q_sub_in_ss = (c.S_fp_ss + c.S_lp_ss) - S1_ss;
+}
+// numerics.py:247-270 (dS_num_error) and the sanity check with the routed fluxes :778-815
+RH_DEV bool rt_num_error_routed(Col &c, const Consts &K) {
+    const double lhs = c.S - c.S_m1, rhs = c.prec - c.q_sur_out + c.q_sur_in - c.aet - c.q_ss - c.q_sub_out + c.q_sub_in;
     c.dS_num_error = fabs(lhs - rhs);
     bool close = (isfinite(lhs) && isfinite(rhs)) ? (fabs(lhs - rhs) <= K.atol + K.rtol * fabs(rhs)) : (lhs == rhs);
     close = c.maskCatch ? close : true;

@@ -151,6 +151,12 @@ struct rh_ctx {
     bool own_comm;
     int *exch_buf;
     bool exch_valid;      // exch_buf[0..63] holds the summary word of the columns as they are now (written by the last fused kernel's tail)
+    int comm_nranks, comm_rank;
+    // routing (settings.enable_routing_1D): edge columns of this rank and halo columns of its x-neighbours, ny values each
+    double *route_q;      // [0, 2 ny): own edges lo / hi of q_out; [2 ny, 4 ny): halo lo / hi
+    int *route_i;         // flow direction and mask: [0, 4 ny) own edges (fd lo, fd hi, mk lo, mk hi), [4 ny, 8 ny) halos (same order)
+    bool route_halo[2];   // a halo column is present on that side (rh_route_set_halo or the RCCL exchange)
+    bool route_static_done;   // the neighbours' flow direction and mask have been exchanged over RCCL
     std::string err;
 };
 #define RH_DT_LOG_CAP 65536
@@ -1262,6 +1268,74 @@ RH_CELL_KERNEL(k_num_error_lateral, rt_num_error_lateral, if (rt_num_error_later
 RH_CELL_KERNEL(k_after_timestep_oned, rt_after_timestep_oned, rt_after_timestep_oned(c))
 RH_CELL_KERNEL(k_step_core_lateral, rt_step_core_lateral, if (rt_step_core_lateral(c, K, X)) atomicOr(&D->words[2], 1ull))
 RH_CELL_KERNEL(k_params_lateral, rt_params_lateral, rt_params_lateral(c, D->mlms, D->mlms_rows, D->max_slope_per))
+// settings.enable_routing_1D: the per-column parts of the D8 routing (rh_physics.h) ...
+RH_CELL_KERNEL(k_infiltration_routed, rt_infiltration_routed, rt_infiltration_routed(c, K, X))
+RH_CELL_KERNEL(k_route_surface_out, rt_route_surface_out, rt_route_surface_out(c, K, X, (double)D->S.dt_secs))
+RH_CELL_KERNEL(k_route_surface_in, rt_route_surface_in, rt_route_surface_in(c))
+RH_CELL_KERNEL(k_route_subsurface_out, rt_route_subsurface_out, rt_route_subsurface_out(c))
+RH_CELL_KERNEL(k_route_subsurface_in, rt_route_subsurface_in, rt_route_subsurface_in(c))
+RH_CELL_KERNEL(k_num_error_routed, rt_num_error_routed, if (rt_num_error_routed(c, K)) atomicOr(&D->words[2], 1ull))
+// set_parameters' month-change test was evaluated on the device by the set_forcing hook (D->monthly)
+__global__ __launch_bounds__(RH_BLOCK) void k_params_surface_if_monthly(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n || !D->monthly) return;
+    const StepCtx X = D->X;
+    Col c;
+    RH_SET_LOAD_rt_params_surface(LD) rt_params_surface(c, D->L, X);
+    RH_SET_STORE_rt_params_surface(ST)
+}
+
+// ... and the gather between them: q_in of cell (ix, iy) = np.sum over the eight *_in_d8 entries, in_d8[c, d] = where(flow_dir[s] ==
+// code_d, q_out[s], 0) * maskCatch[s] with s = c - (dx_d, dy_d) an interior cell (surface_runoff.py:137-204; the reference scatters
+// into shifted slices, a cell next to the edge of the grid receives nothing from outside).  The reference's direction order
+// N, NE, E, SE, S, SW, W, NW and numpy's sum of 8 contiguous values, ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)).
+// Several ranks (decomposition along x, the slow index): the neighbour ranks' edge columns -- q_out per step, flow direction and mask
+// once -- arrive in halo[0] (the column x = -1) and halo[1] (x = nx); null where the rank has no neighbour.
+struct RouteHalo {
+    const double *q[2];
+    const int *flow_dir[2];
+    const int *mask[2];
+};
+__global__ __launch_bounds__(RH_BLOCK) void k_route_gather(Arena a, int nx, int ny, int src_plane, int dst_plane, RouteHalo H) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const int ix = (int)(i / ny), iy = (int)(i % ny);
+    const int CODE[8] = {64, 128, 1, 2, 4, 8, 16, 32};
+    const int DX[8] = {0, -1, 1, 1, 0, -1, -1, -1};
+    const int DY[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+    double v[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int sx = ix - DX[d], sy = iy - DY[d];
+        double q = 0.0;
+        int fd = 0, mk = 0;
+        if (sy >= 0 && sy < ny) {
+            if (sx >= 0 && sx < nx) {
+                const int64_t s = (int64_t)sx * ny + sy;
+                q = *rh_cell_any<const double>(a, src_plane, s);
+                fd = *rh_cell_any<const int>(a, RH_P_flow_dir_topo, s);
+                mk = *rh_cell_any<const int>(a, RH_P_maskCatch, s);
+            } else {
+                const int side = sx < 0 ? 0 : 1;
+                if (H.q[side]) {
+                    q = H.q[side][sy];
+                    fd = H.flow_dir[side][sy];
+                    mk = H.mask[side][sy];
+                }
+            }
+        }
+        v[d] = (fd == CODE[d] ? q : 0.0) * (double)mk;
+    }
+    *rh_cell_any<double>(a, dst_plane, i) = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+// the rank's own edge columns (x = 0 and x = nx - 1) of a plane into two contiguous rows of ny (what the neighbours' halos take)
+template <typename T>
+__global__ void k_route_edges(Arena a, int nx, int ny, int plane, T *lo, T *hi) {
+    const int iy = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iy >= ny) return;
+    lo[iy] = *rh_cell_any<const T>(a, plane, iy);
+    hi[iy] = *rh_cell_any<const T>(a, plane, (int64_t)(nx - 1) * ny + iy);
+}
 
 // max over the columns of slope_per (the trip count of the reference's look-up loop, soil.py:621)
 __global__ __launch_bounds__(RH_BLOCK) void k_max_slope(Arena a, DevState *D) {
@@ -1453,6 +1527,12 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
     const char *(*GetErrorString)(ncclResult_t);
     bool ok;
     std::string why;
@@ -1473,8 +1553,15 @@ static RcclApi *rccl_api() {
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
         a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+        a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+        a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
+        a.CommUserRank = (decltype(a.CommUserRank))dlsym(h, "ncclCommUserRank");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString && a.Send && a.Recv && a.GroupStart &&
+               a.GroupEnd && a.CommCount && a.CommUserRank;
         if (!a.ok) a.why = "librccl lacks an expected entry point";
         return a;
     }();
@@ -1484,6 +1571,9 @@ static void release_comm(rh_ctx *ctx) {
     if (ctx->comm && ctx->own_comm && rccl_api()->ok) (void)rccl_api()->CommDestroy(ctx->comm);
     ctx->comm = nullptr;
     ctx->own_comm = false;
+    ctx->comm_nranks = 1;
+    ctx->comm_rank = 0;
+    ctx->route_static_done = false;
 }
 #define NCCLCHK(ctx, call)                                                                                                   \
     do {                                                                                                                     \
@@ -1522,6 +1612,8 @@ void rh_default_config(rh_config *cfg) {
     cfg->hpi = 5;
     cfg->dx = 1;
     cfg->enable_lateral_flow = 0;
+    cfg->enable_routing_1D = 0;
+    cfg->dy = 1.0;
     cfg->placement_probes = 1;   // placement probing is opt-in (rh_config.placement_probes or RH_PLACEMENT_PROBES)
 }
 
@@ -1592,6 +1684,16 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->own_comm = false;
     ctx->exch_buf = nullptr;
     ctx->exch_valid = false;
+    ctx->comm_nranks = 1;
+    ctx->comm_rank = 0;
+    ctx->route_q = nullptr;
+    ctx->route_i = nullptr;
+    ctx->route_halo[0] = ctx->route_halo[1] = false;
+    ctx->route_static_done = false;
+    if (cfg->enable_routing_1D && !cfg->enable_lateral_flow) {
+        delete ctx;
+        return fail(nullptr, RH_ERR_ARG, "rh_create: enable_routing_1D needs enable_lateral_flow (the routed subsurface runoff is the lateral flow)");
+    }
     auto bail = [&](hipError_t e, const char *what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         rh_destroy(ctx);
@@ -1675,6 +1777,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     K.z_evap_max = cfg->z_evap_max; K.zroot_to_zsoil_max = cfg->zroot_to_zsoil_max; K.a_bc = cfg->a_bc; K.b_bc = cfg->b_bc;
     K.end_event = cfg->end_event; K.hpi = cfg->hpi;
     K.dx = cfg->dx; K.lateral = cfg->enable_lateral_flow ? 1 : 0;
+    K.dy = cfg->dy; K.routing = cfg->enable_routing_1D ? 1 : 0;
     if ((e = hipMemcpyAsync(&ctx->dev->K, &K, sizeof(K), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(Consts)");
     // scalars: roger/variables.py initial values (dt=1, dt_secs=3600, event_id_counter=1, year=1900, month=doy=1)
@@ -1728,6 +1831,8 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->arena_alloc) (void)hipFree(ctx->arena_alloc);
     if (ctx->stage_buf) (void)hipFree(ctx->stage_buf);
     if (ctx->exch_buf) (void)hipFree(ctx->exch_buf);
+    if (ctx->route_q) (void)hipFree(ctx->route_q);
+    if (ctx->route_i) (void)hipFree(ctx->route_i);
     release_comm(ctx);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1931,7 +2036,8 @@ int rh_infiltration(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     LAUNCH_CELLS(ctx, k_inf_pred);
     LAUNCH_ONE(ctx, k_inf_conds, ctx->dev);
-    LAUNCH_CELLS(ctx, k_infiltration);
+    if (ctx->cfg.enable_routing_1D) LAUNCH_CELLS(ctx, k_infiltration_routed);
+    else LAUNCH_CELLS(ctx, k_infiltration);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
@@ -1940,7 +2046,9 @@ int rh_num_error(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->sanity_last, 0, sizeof(unsigned long long), ctx->stream));
-    if (ctx->cfg.enable_lateral_flow)
+    if (ctx->cfg.enable_routing_1D)
+        LAUNCH_CELLS(ctx, k_num_error_routed);
+    else if (ctx->cfg.enable_lateral_flow)
         LAUNCH_CELLS(ctx, k_num_error_lateral);
     else
         LAUNCH_CELLS(ctx, k_num_error);
@@ -1974,6 +2082,153 @@ int rh_after_timestep(rh_ctx *ctx) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
+
+// ---- settings.enable_routing_1D -------------------------------------------------------------------------------------------------
+static int route_buffers(rh_ctx *ctx) {
+    if (ctx->route_q) return RH_OK;
+    const size_t ny = (size_t)ctx->cfg.ny;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->route_q, 4 * ny * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->route_i, 8 * ny * sizeof(int)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->route_q, 0, 4 * ny * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->route_i, 0, 8 * ny * sizeof(int), ctx->stream));
+    return RH_OK;
+}
+static int route_check(rh_ctx *ctx, int which, const char *who) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->cfg.enable_routing_1D) return fail(ctx, RH_ERR_STATE, std::string(who) + ": the context was created without enable_routing_1D");
+    if (which != 0 && which != 1) return fail(ctx, RH_ERR_ARG, std::string(who) + ": which must be 0 (surface) or 1 (subsurface)");
+    return route_buffers(ctx);
+}
+static void route_pack_edges(rh_ctx *ctx, int plane, bool ints, int slot) {
+    const int ny = (int)ctx->cfg.ny, nx = (int)ctx->cfg.nx;
+    const dim3 grid((ny + 255) / 256), block(256);
+    if (ints)
+        hipLaunchKernelGGL(k_route_edges<int>, grid, block, 0, ctx->stream, ctx->arena, nx, ny, plane, ctx->route_i + (size_t)slot * ny,
+                           ctx->route_i + (size_t)(slot + 1) * ny);
+    else
+        hipLaunchKernelGGL(k_route_edges<double>, grid, block, 0, ctx->stream, ctx->arena, nx, ny, plane, ctx->route_q, ctx->route_q + ny);
+}
+int rh_route_out(rh_ctx *ctx, int which) {
+    int rc = route_check(ctx, which, "rh_route_out");
+    if (rc) return rc;
+    if (which == 0) LAUNCH_CELLS(ctx, k_route_surface_out);
+    else LAUNCH_CELLS(ctx, k_route_subsurface_out);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+int rh_route_get_edges(rh_ctx *ctx, int which, double *q_lo, double *q_hi) {
+    int rc = route_check(ctx, which, "rh_route_get_edges");
+    if (rc) return rc;
+    if (!q_lo || !q_hi) return fail(ctx, RH_ERR_ARG, "rh_route_get_edges: null pointer");
+    const size_t ny = (size_t)ctx->cfg.ny;
+    route_pack_edges(ctx, which == 0 ? RH_P_q_sur_out : RH_P_q_sub_out, false, 0);
+    CHECK_LAUNCH(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(q_lo, ctx->route_q, ny * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q_hi, ctx->route_q + ny, ny * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_route_get_static_edges(rh_ctx *ctx, int32_t *fd_lo, int32_t *fd_hi, int32_t *mk_lo, int32_t *mk_hi) {
+    int rc = route_check(ctx, 0, "rh_route_get_static_edges");
+    if (rc) return rc;
+    if (!fd_lo || !fd_hi || !mk_lo || !mk_hi) return fail(ctx, RH_ERR_ARG, "rh_route_get_static_edges: null pointer");
+    const size_t ny = (size_t)ctx->cfg.ny;
+    route_pack_edges(ctx, RH_P_flow_dir_topo, true, 0);
+    route_pack_edges(ctx, RH_P_maskCatch, true, 2);
+    CHECK_LAUNCH(ctx);
+    int32_t *dst[4] = {fd_lo, fd_hi, mk_lo, mk_hi};
+    for (int k = 0; k < 4; ++k) HIPCHK(ctx, hipMemcpyAsync(dst[k], ctx->route_i + k * ny, ny * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_route_set_halo(rh_ctx *ctx, int side, const double *q, const int32_t *flow_dir, const int32_t *mask) {
+    int rc = route_check(ctx, 0, "rh_route_set_halo");
+    if (rc) return rc;
+    if (side != 0 && side != 1) return fail(ctx, RH_ERR_ARG, "rh_route_set_halo: side must be 0 (x = -1) or 1 (x = nx)");
+    const size_t ny = (size_t)ctx->cfg.ny;
+    if (flow_dir && mask) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->route_i + (4 + side) * ny, flow_dir, ny * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->route_i + (6 + side) * ny, mask, ny * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        ctx->route_halo[side] = true;
+    }
+    if (q) {
+        if (!ctx->route_halo[side]) return fail(ctx, RH_ERR_STATE, "rh_route_set_halo: the side's flow direction and mask must be set first");
+        HIPCHK(ctx, hipMemcpyAsync(ctx->route_q + (2 + side) * ny, q, ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RH_OK;
+}
+int rh_route_in(rh_ctx *ctx, int which) {
+    int rc = route_check(ctx, which, "rh_route_in");
+    if (rc) return rc;
+    const size_t ny = (size_t)ctx->cfg.ny;
+    RouteHalo H;
+    for (int side = 0; side < 2; ++side) {
+        const bool have = ctx->route_halo[side];
+        H.q[side] = have ? ctx->route_q + (2 + side) * ny : nullptr;
+        H.flow_dir[side] = have ? ctx->route_i + (4 + side) * ny : nullptr;
+        H.mask[side] = have ? ctx->route_i + (6 + side) * ny : nullptr;
+    }
+    planes_touched(ctx);
+    hipLaunchKernelGGL(k_route_gather, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, (int)ctx->cfg.nx, (int)ctx->cfg.ny,
+                       which == 0 ? (int)RH_P_q_sur_out : (int)RH_P_q_sub_out, which == 0 ? (int)RH_P_q_sur_in : (int)RH_P_q_sub_in, H);
+    if (which == 0) LAUNCH_CELLS(ctx, k_route_surface_in);
+    else LAUNCH_CELLS(ctx, k_route_subsurface_in);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+// the neighbours' edge columns over RCCL (decomposition along x: rank r - 1 holds x < 0, rank r + 1 holds x >= nx)
+static int route_exchange(rh_ctx *ctx, int which) {
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(ctx, RH_ERR_STATE, "routing: " + api->why);
+    const size_t ny = (size_t)ctx->cfg.ny;
+    const int r = ctx->comm_rank, N = ctx->comm_nranks;
+    if (!ctx->route_static_done) {
+        route_pack_edges(ctx, RH_P_flow_dir_topo, true, 0);
+        route_pack_edges(ctx, RH_P_maskCatch, true, 2);
+        CHECK_LAUNCH(ctx);
+        NCCLCHK(ctx, api->GroupStart());
+        for (int k = 0; k < 2; ++k) {   // k = 0: flow direction, 1: mask
+            int *own = ctx->route_i + (size_t)(2 * k) * ny, *halo = ctx->route_i + (size_t)(4 + 2 * k) * ny;
+            if (r > 0) {
+                NCCLCHK(ctx, api->Send(own, ny, ncclInt32, r - 1, ctx->comm, ctx->stream));
+                NCCLCHK(ctx, api->Recv(halo, ny, ncclInt32, r - 1, ctx->comm, ctx->stream));
+            }
+            if (r < N - 1) {
+                NCCLCHK(ctx, api->Send(own + ny, ny, ncclInt32, r + 1, ctx->comm, ctx->stream));
+                NCCLCHK(ctx, api->Recv(halo + ny, ny, ncclInt32, r + 1, ctx->comm, ctx->stream));
+            }
+        }
+        NCCLCHK(ctx, api->GroupEnd());
+        ctx->route_halo[0] = r > 0;
+        ctx->route_halo[1] = r < N - 1;
+        ctx->route_static_done = true;
+    }
+    route_pack_edges(ctx, which == 0 ? RH_P_q_sur_out : RH_P_q_sub_out, false, 0);
+    CHECK_LAUNCH(ctx);
+    NCCLCHK(ctx, api->GroupStart());
+    if (r > 0) {
+        NCCLCHK(ctx, api->Send(ctx->route_q, ny, ncclDouble, r - 1, ctx->comm, ctx->stream));
+        NCCLCHK(ctx, api->Recv(ctx->route_q + 2 * ny, ny, ncclDouble, r - 1, ctx->comm, ctx->stream));
+    }
+    if (r < N - 1) {
+        NCCLCHK(ctx, api->Send(ctx->route_q + ny, ny, ncclDouble, r + 1, ctx->comm, ctx->stream));
+        NCCLCHK(ctx, api->Recv(ctx->route_q + 3 * ny, ny, ncclDouble, r + 1, ctx->comm, ctx->stream));
+    }
+    NCCLCHK(ctx, api->GroupEnd());
+    return RH_OK;
+}
+static int route_all(rh_ctx *ctx, int which) {
+    int rc = rh_route_out(ctx, which);
+    if (rc) return rc;
+    if (ctx->comm && ctx->comm_nranks > 1) {
+        rc = route_exchange(ctx, which);
+        if (rc) return rc;
+    }
+    return rh_route_in(ctx, which);
+}
+int rh_surface_routing(rh_ctx *ctx) { return route_all(ctx, 0); }
+int rh_subsurface_routing(rh_ctx *ctx) { return route_all(ctx, 1); }
 
 #define LAUNCH_PRED(ctx, kern)                                                                                           \
     do {                                                                                                                 \
@@ -2080,6 +2335,10 @@ int rh_step_phase3(rh_ctx *ctx, int monthly) {
 static void launch_hooks(rh_ctx *ctx);
 // single GPU: the same step with the reductions folded into the single-workgroup kernels
 static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
+    if (ctx->cfg.enable_routing_1D)
+        return fail(ctx, RH_ERR_STATE, "enable_routing_1D couples the columns twice per step: the fused step is not available, run the step "
+                                       "routine by routine (rh_adaptive_dt ... rh_infiltration, rh_surface_routing, rh_subsurface_runoff, "
+                                       "rh_subsurface_routing, ... rh_after_timestep)");
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
     if (!ctx->per_cell) {
         // summary path: the previous fused kernel left what the predicates need; one control kernel, one fused kernel
@@ -2258,6 +2517,47 @@ int rh_hooks_phase(rh_ctx *ctx) {
     return RH_OK;
 }
 
+// One whole step with the routing, routine by routine in the order of RogerSetup.step (roger/roger.py:396-457): the columns are
+// coupled twice (after the infiltration and after the lateral flow), so the step is eleven per-column passes with two gathers in
+// between instead of the fused kernel.  monthly: 1 / 0 = the caller's set_parameters decision, -1 = the device's (after the
+// device-side set_forcing hook, rh_run_steps).  Several ranks: the two predicate words of the adaptive time stepping are all-reduced
+// over the context's communicator (64 int32 each, as rh_run_steps_dist's summary word), the edge columns go to the x-neighbours.
+static int allreduce_word(rh_ctx *ctx, int word) {
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_step_routed: " + api->why);
+    if (!ctx->exch_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->exch_buf, 128 * sizeof(int)));
+    int rc = rh_predicates_expand(ctx, word, ctx->exch_buf);
+    if (rc) return rc;
+    NCCLCHK(ctx, api->AllReduce(ctx->exch_buf, ctx->exch_buf + 64, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+    ctx->exch_valid = false;
+    return rh_predicates_compress(ctx, word, ctx->exch_buf + 64);
+}
+int rh_step_routed(rh_ctx *ctx, int monthly) {
+    if (!ctx) return RH_ERR_ARG;
+    if (!ctx->cfg.enable_routing_1D) return fail(ctx, RH_ERR_STATE, "rh_step_routed: the context was created without enable_routing_1D");
+    int rc;
+    if (ctx->comm && ctx->comm_nranks > 1) {
+        if ((rc = rh_step_phase1(ctx)) || (rc = allreduce_word(ctx, 0)) || (rc = rh_step_phase2(ctx)) || (rc = allreduce_word(ctx, 1)) ||
+            (rc = rh_adaptive_dt_finish(ctx)))
+            return rc;
+    } else if ((rc = rh_adaptive_dt(ctx)))
+        return rc;
+    if (monthly < 0) LAUNCH_CELLS(ctx, k_params_surface_if_monthly);
+    else if (monthly) LAUNCH_CELLS(ctx, k_params_surface);
+    LAUNCH_CELLS(ctx, k_interception);
+    LAUNCH_CELLS(ctx, k_evapotranspiration);
+    LAUNCH_CELLS(ctx, k_snow);
+    if ((rc = rh_infiltration(ctx)) || (rc = rh_surface_routing(ctx))) return rc;
+    LAUNCH_CELLS(ctx, k_subsurface_runoff_lateral);
+    if ((rc = rh_subsurface_routing(ctx))) return rc;
+    LAUNCH_CELLS(ctx, k_capillary_rise);
+    LAUNCH_CELLS(ctx, k_storage);
+    if ((rc = rh_num_error(ctx))) return rc;
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    return rh_after_timestep(ctx);
+}
+
 int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double *ta_offset, const double *pet_weight) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
@@ -2296,7 +2596,12 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     for (int64_t k = 0; k < nsteps; ++k) {
-        int rc = step_fused_launches(ctx, -1, 1);
+        int rc;
+        if (ctx->cfg.enable_routing_1D) {   // the hooks, then the step routine by routine (rh_step_routed)
+            launch_hooks(ctx);
+            rc = rh_step_routed(ctx, -1);
+        } else
+            rc = step_fused_launches(ctx, -1, 1);
         if (rc) return rc;
     }
     return RH_OK;
@@ -2321,12 +2626,20 @@ int rh_comm_init(rh_ctx *ctx, const void *id128, int nranks, int rank) {
     std::memcpy(&id, id128, sizeof(id));
     NCCLCHK(ctx, api->CommInitRank(&ctx->comm, nranks, id, rank));
     ctx->own_comm = true;
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
     return RH_OK;
 }
 int rh_set_comm(rh_ctx *ctx, void *nccl_comm) {
     if (!ctx) return RH_ERR_ARG;
     release_comm(ctx);
     ctx->comm = (ncclComm_t)nccl_comm;
+    if (ctx->comm) {
+        RcclApi *api = rccl_api();
+        if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_set_comm: " + api->why);
+        NCCLCHK(ctx, api->CommCount(ctx->comm, &ctx->comm_nranks));
+        NCCLCHK(ctx, api->CommUserRank(ctx->comm, &ctx->comm_rank));
+    }
     return RH_OK;
 }
 int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {

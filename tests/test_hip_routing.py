@@ -1,0 +1,171 @@
+"""GPU: settings.enable_routing_1D -- the D8 routing of surface and subsurface runoff (rh_surface_routing, rh_subsurface_routing,
+rh_step_routed) against the reference's own run of a routed hillslope (tests/golden/oned_routing.npz: 4 x 6 cells with all eight
+flow directions, a pit, an interior outlet; 240 steps) and, for the halo path of a decomposed run, a domain cut in two."""
+import numpy as np
+import pytest
+
+from golden_util import ROUTING_CASES, compare, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from roger_amd import _native as N
+
+    N.load()
+    return N
+
+
+def routed_ctx(native, g, names, key="state0", scal_key="scal0", columns=None):
+    """A routing context holding the golden snapshot `key`; columns = (x0, x1): only that slab of the grid."""
+    import hip_util as H
+
+    nx, ny = (int(v) for v in g["nx_ny"])
+    dx, dy = (float(v) for v in g["routing_dx_dy"])
+    snap = np.asarray(g[key])
+    if columns is not None:
+        x0, x1 = columns
+        snap = snap.reshape(snap.shape[0], nx, ny)[:, x0:x1].reshape(snap.shape[0], -1)
+        nx = x1 - x0
+    ctx = native.Context(nx, ny, enable_lateral_flow=1, enable_routing_1D=1, dx=dx, dy=dy)
+    H.upload_snapshot(ctx, snap, names)
+    ctx.set_scalars(H.scalars_from_row(g[scal_key] if isinstance(scal_key, str) else scal_key))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    ctx.set_lut_mlms(g["lut_mlms"])
+    return ctx
+
+
+@pytest.mark.parametrize("case", ROUTING_CASES)
+def test_single_steps_from_reference_states(native, case):
+    """One routed step from the reference's state k-1 gives the reference's state k (every pair of consecutive snapshots)."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    have = sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit())
+    pairs = [k for k in have if k - 1 in have and k >= 2]
+    assert len(pairs) >= 20
+    for k in pairs:
+        ctx = routed_ctx(native, g, names, key=f"s{k - 1:05d}", scal_key=g["scal"][k - 2])
+        s = ctx.get_scalars()
+        if s.time % 86400:   # mid-day: hand over the forcing the reference took at midnight
+            i0 = s.itt_forc - 144
+            ctx.set_forcing_day(*[forcing[v][i0:i0 + 144] for v in ("PREC", "TA", "PET")])
+        monthly = H.HipForcingDriver(ctx, forcing).before_step()
+        ctx.step_routed(monthly)
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][k - 1], err_msg=f"step {k}")
+        compare(H.download_snapshot(ctx, names), g[f"s{k:05d}"], names, what=f"{case} single step {k}")
+        ctx.close()
+
+
+@pytest.mark.parametrize("case", ROUTING_CASES)
+def test_trajectory_golden(native, case):
+    """Free-running from the initial state: all planes at the stored steps, the integer scalars exactly at every step."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    ctx = routed_ctx(native, g, names)
+    drv = H.HipForcingDriver(ctx, forcing)
+    checked = 0
+    for step in range(1, int(g["nsteps"]) + 1):
+        ctx.step_routed(drv.before_step())
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][step - 1], err_msg=f"{case} scalars step {step}")
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}")
+            checked += 1
+    assert checked >= 20
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ROUTING_CASES)
+def test_routing_entry_points_golden(native, case):
+    """rh_surface_routing and rh_subsurface_runoff + rh_subsurface_routing: state before the reference routine in, state after it out."""
+    import hip_util as H
+
+    g, names, _ = load_case(case)
+    steps = sorted({int(k[1:6]) for k in g.files if k.startswith("r") and k.endswith("_calculate_surface_runoff")})
+    assert len(steps) >= 4
+    for step in steps:
+        for prev, cur, entries in (("calculate_infiltration", "calculate_surface_runoff", ("rh_surface_routing",)),
+                                   ("calculate_surface_runoff", "calculate_subsurface_runoff", ("rh_subsurface_runoff", "rh_subsurface_routing"))):
+            kp = f"r{step:05d}_{prev}"
+            ctx = routed_ctx(native, g, names, key=kp, scal_key=kp + "_scal")
+            for e in entries:
+                ctx.call(e)
+            compare(H.download_snapshot(ctx, names), g[f"r{step:05d}_{cur}"], names, what=f"{case} step {step} {cur}")
+            ctx.close()
+
+
+@pytest.mark.parametrize("case", ROUTING_CASES)
+def test_halo_columns_of_a_cut_domain(native, case):
+    """The grid cut in two along x (as a (2, 1) decomposition cuts it), one context per half, the edge columns handed over by hand
+    (rh_route_get_edges / rh_route_set_halo: what the RCCL exchange of rh_surface_routing does between ranks): both routings give the
+    single-domain result bit for bit -- water crosses the cut straight and diagonally."""
+    import hip_util as H
+
+    g, names, _ = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    cut = nx // 2
+    steps = sorted({int(k[1:6]) for k in g.files if k.startswith("r") and k.endswith("_calculate_surface_runoff")})
+    crossed = 0
+    for step in steps:
+        for which, kp in ((0, f"r{step:05d}_calculate_infiltration"), (1, None)):
+            if which == 0:
+                whole = routed_ctx(native, g, names, key=kp, scal_key=kp + "_scal")
+                halves = [routed_ctx(native, g, names, key=kp, scal_key=kp + "_scal", columns=c) for c in ((0, cut), (cut, nx))]
+            else:   # continue: the lateral flow, then its routing
+                for c in [whole] + halves:
+                    c.call("rh_subsurface_runoff")
+            whole.call("rh_surface_routing" if which == 0 else "rh_subsurface_routing")
+            for h in halves:
+                h.route_out(which)
+            if which == 0:
+                st = [h.route_static_edges() for h in halves]
+                halves[0].route_set_halo(1, flow_dir=st[1][0], mask=st[1][2])   # the right half's x = 0 column is the left half's x = nx halo
+                halves[1].route_set_halo(0, flow_dir=st[0][1], mask=st[0][3])
+            e = [h.route_edges(which) for h in halves]
+            halves[0].route_set_halo(1, q=e[1][0])
+            halves[1].route_set_halo(0, q=e[0][1])
+            crossed += int((e[0][1] != 0).any() or (e[1][0] != 0).any())
+            for h in halves:
+                h.route_in(which)
+            ref = H.download_snapshot(whole, names).reshape(len(names), nx, ny)
+            got = np.concatenate([H.download_snapshot(h, names).reshape(len(names), -1, ny) for h in halves], axis=1)
+            assert np.array_equal(got, ref, equal_nan=True), f"step {step} routing {which}: planes {[names[p] for p in np.unique(np.argwhere(got != ref)[:, 0])][:6]}"
+        for c in [whole] + halves:
+            c.close()
+    assert crossed >= 2, "no water crossed the cut: the test would not see the halo path"
+
+
+def test_routed_steps_with_device_hooks_and_one_rank_communicator(native):
+    """rh_run_steps on a routing context (device-side set_forcing / set_parameters hooks, then rh_step_routed) reproduces the golden
+    trajectory; with a one-rank RCCL communicator attached (the predicate words and the edge columns then take the multi-rank code path
+    up to the exchange itself) the result is bit-identical."""
+    import hip_util as H
+
+    g, names, forcing = load_case(ROUTING_CASES[0])
+    nsteps = int(g["nsteps"])
+    out = []
+    for with_comm in (False, True):
+        ctx = routed_ctx(native, g, names)
+        ctx.set_forcing_series(forcing)
+        if with_comm:
+            ctx.comm_init(native.comm_unique_id(), 1, 0)
+        ctx.run_steps(nsteps)
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][nsteps - 1])
+        out.append(H.download_snapshot(ctx, names))
+        ctx.close()
+    compare(out[0], g[f"s{nsteps:05d}"], names, what="routed run_steps")
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+
+
+def test_fused_step_is_refused_and_lateral_flow_is_required(native):
+    g, names, forcing = load_case(ROUTING_CASES[0])
+    ctx = routed_ctx(native, g, names)
+    ctx.set_forcing_day(*[forcing[v][:144] for v in ("PREC", "TA", "PET")])
+    with pytest.raises(native.NativeError, match="routine by routine"):
+        ctx.step(False)
+    ctx.close()
+    with pytest.raises(native.NativeError, match="enable_lateral_flow"):
+        native.Context(3, 3, enable_routing_1D=1)
