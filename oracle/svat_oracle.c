@@ -1299,12 +1299,26 @@ static double d8_out(double q, int flow_dir, double mk) {
 /* q_in of cell (ix, iy): np.sum over the eight *_in_d8 entries, in_d8[c, d] = where(mask_d[s], out_d8[s, d], 0) * maskCatch[s] with
  * s = c - (dx_d, dy_d) an INTERIOR cell (the slices only read [2:-2, 2:-2]); a sum of 8 contiguous values is numpy's unrolled
  * pairwise block ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)) */
+/* a decomposed run (x split over ranks): the neighbour ranks' edge columns, ny values each, side 0 = the column x = -1, side 1 =
+ * x = nx; NULL where the rank has no neighbour.  Set by the driver before oc_route_in (tests/oracle_context.py). */
+static const double *HALO_Q[2];
+static const int32_t *HALO_FD[2], *HALO_MK[2];
+void oc_route_set_halo(int side, const double *q, const int32_t *flow_dir, const int32_t *mask) {
+    HALO_Q[side] = q;
+    HALO_FD[side] = flow_dir;
+    HALO_MK[side] = mask;
+}
 static double d8_in(const double *q_out, const int32_t *flow_dir, const int32_t *mask, int64_t nx, int64_t ny, int64_t ix, int64_t iy) {
     double a[8];
     for (int d = 0; d < 8; ++d) {
         const int64_t sx = ix - D8_DX[d], sy = iy - D8_DY[d];
         a[d] = 0.0;
-        if (sx < 0 || sx >= nx || sy < 0 || sy >= ny) continue;
+        if (sy < 0 || sy >= ny) continue;
+        if (sx < 0 || sx >= nx) {
+            const int side = sx < 0 ? 0 : 1;
+            if (HALO_Q[side]) a[d] = (HALO_FD[side][sy] == D8_CODE[d] ? HALO_Q[side][sy] : 0.0) * (double)HALO_MK[side][sy];
+            continue;
+        }
         const int64_t s = sx * ny + sy;
         a[d] = (flow_dir[s] == D8_CODE[d] ? q_out[s] : 0.0) * (double)mask[s];
     }
@@ -1729,15 +1743,34 @@ static void route_gather(void *const *planes, const oc_settings *st, const char 
     for (int64_t ix = 0; ix < st->nx; ++ix)
         for (int64_t iy = 0; iy < st->ny; ++iy) q_in[ix * st->ny + iy] = d8_in(q_out, fd, mk, st->nx, st->ny, ix, iy);
 }
+/* which: 0 surface, 1 subsurface.  out: the per-column outflow; in: the gather (with the halo columns of oc_route_set_halo) and the
+ * per-column inflow.  A driver of a decomposed run exchanges the edge columns of q_*_out in between. */
+void oc_route_out(void *const *planes, int64_t n, int which, const oc_scalars *s, const oc_settings *st) {
+    if (which == 0) { FOR_CELLS(route_surface_out_cell(c, st, (double)s->dt_secs)) }
+    else { FOR_CELLS(route_subsurface_out_cell(c)) }
+}
+void oc_route_in(void *const *planes, int64_t n, int which, const oc_settings *st) {
+    if (which == 0) {
+        route_gather(planes, st, "q_sur_out", "q_sur_in");
+        FOR_CELLS(route_surface_in_cell(c))
+    } else {
+        route_gather(planes, st, "q_sub_out", "q_sub_in");
+        FOR_CELLS(route_subsurface_in_cell(c))
+    }
+}
+/* the exchange of a decomposed run, called between out and in (it reads the edge columns of q_*_out and calls oc_route_set_halo) */
+typedef void (*oc_exchange_fn)(int which);
+static oc_exchange_fn EXCHANGE;
+void oc_route_set_exchange(oc_exchange_fn fn) { EXCHANGE = fn; }
 void oc_surface_routing(void *const *planes, int64_t n, const oc_scalars *s, const oc_settings *st) {
-    FOR_CELLS(route_surface_out_cell(c, st, (double)s->dt_secs))
-    route_gather(planes, st, "q_sur_out", "q_sur_in");
-    FOR_CELLS(route_surface_in_cell(c))
+    oc_route_out(planes, n, 0, s, st);
+    if (EXCHANGE) EXCHANGE(0);
+    oc_route_in(planes, n, 0, st);
 }
 void oc_subsurface_routing(void *const *planes, int64_t n, const oc_settings *st) {
-    FOR_CELLS(route_subsurface_out_cell(c))
-    route_gather(planes, st, "q_sub_out", "q_sub_in");
-    FOR_CELLS(route_subsurface_in_cell(c))
+    oc_route_out(planes, n, 1, NULL, st);
+    if (EXCHANGE) EXCHANGE(1);
+    oc_route_in(planes, n, 1, st);
 }
 void oc_capillary_rise(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(capillary_rise_cell(c, s->dt)) }
 void oc_storage(void *const *planes, int64_t n, const oc_scalars *s) { FOR_CELLS(storage_cell(c, s->month[1])) }

@@ -2059,8 +2059,10 @@ int rh_num_error(rh_ctx *ctx) {
 
 // interception ... numerics in one kernel, then itt/time (roger/roger.py:410-457); for drivers that
 // keep the user hooks `set_parameters` and `after_timestep` on the host
+static int routed_core(rh_ctx *ctx);
 int rh_step_core(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
+    if (ctx->cfg.enable_routing_1D) return routed_core(ctx);   // the columns are coupled: routine by routine with the two gathers
     if (ctx->cfg.enable_lateral_flow)
         LAUNCH_CELLS(ctx, k_step_core_lateral);
     else
@@ -2532,6 +2534,23 @@ static int allreduce_word(rh_ctx *ctx, int word) {
     ctx->exch_valid = false;
     return rh_predicates_compress(ctx, word, ctx->exch_buf + 64);
 }
+// interception ... numerics, itt / time (what rh_step_core is for the uncoupled columns)
+static int routed_core(rh_ctx *ctx) {
+    int rc;
+    LAUNCH_CELLS(ctx, k_interception);
+    LAUNCH_CELLS(ctx, k_evapotranspiration);
+    LAUNCH_CELLS(ctx, k_snow);
+    if ((rc = rh_infiltration(ctx)) || (rc = rh_surface_routing(ctx))) return rc;
+    LAUNCH_CELLS(ctx, k_subsurface_runoff_lateral);
+    if ((rc = rh_subsurface_routing(ctx))) return rc;
+    LAUNCH_CELLS(ctx, k_capillary_rise);
+    LAUNCH_CELLS(ctx, k_storage);
+    if ((rc = rh_num_error(ctx))) return rc;
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
 int rh_step_routed(rh_ctx *ctx, int monthly) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->cfg.enable_routing_1D) return fail(ctx, RH_ERR_STATE, "rh_step_routed: the context was created without enable_routing_1D");
@@ -2544,17 +2563,7 @@ int rh_step_routed(rh_ctx *ctx, int monthly) {
         return rc;
     if (monthly < 0) LAUNCH_CELLS(ctx, k_params_surface_if_monthly);
     else if (monthly) LAUNCH_CELLS(ctx, k_params_surface);
-    LAUNCH_CELLS(ctx, k_interception);
-    LAUNCH_CELLS(ctx, k_evapotranspiration);
-    LAUNCH_CELLS(ctx, k_snow);
-    if ((rc = rh_infiltration(ctx)) || (rc = rh_surface_routing(ctx))) return rc;
-    LAUNCH_CELLS(ctx, k_subsurface_runoff_lateral);
-    if ((rc = rh_subsurface_routing(ctx))) return rc;
-    LAUNCH_CELLS(ctx, k_capillary_rise);
-    LAUNCH_CELLS(ctx, k_storage);
-    if ((rc = rh_num_error(ctx))) return rc;
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
-    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    if ((rc = routed_core(ctx))) return rc;
     return rh_after_timestep(ctx);
 }
 
@@ -2646,6 +2655,14 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
+    if (ctx->cfg.enable_routing_1D) {   // the routed step exchanges its predicate words and edge columns itself
+        for (int64_t k = 0; k < nsteps; ++k) {
+            launch_hooks(ctx);
+            int rc = rh_step_routed(ctx, -1);
+            if (rc) return rc;
+        }
+        return RH_OK;
+    }
     if (ctx->per_cell) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: the one-exchange step needs forcing shared by all columns (rh_step_phase1/2/3 otherwise)");
     RcclApi *api = rccl_api();
     if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: " + api->why);

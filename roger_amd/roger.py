@@ -123,6 +123,11 @@ class RogerSetup(metaclass=abc.ABCMeta):
                 raise NotImplementedError("the hip backend splits the grid along x only: num_proc = (N, 1) (BASELINE.json north_star)")
             state.initialize_variables()
             offline = state.settings.enable_offline_transport
+            if rst.proc_num > 1 and state.settings.enable_routing_1D and not offline:
+                # routed water crosses the rank boundaries: the edge columns travel over the context's communicator inside
+                # rh_step_core / rh_step_routed (the reference never exchanges them, core/utilities.py:79 is not on this path)
+                state.backend_context.comm_init_torch()
+                self._comm_ready = True
             self.set_grid(state)
             self.set_topography(state)
             self.set_look_up_tables(state)

@@ -55,7 +55,7 @@ SETTINGS = {name: Setting(default, type_, group) for group, table in _GROUPS.ite
 _UNSUPPORTED_SWITCHES = (
     "enable_film_flow", "enable_crop_phenology",
     "enable_net_irrigation", "enable_soil_compaction", "enable_groundwater_boundary",
-    "enable_groundwater", "enable_routing_1D", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
+    "enable_groundwater", "enable_routing_2D", "enable_macropore_lower_boundary_condition",
     "enable_nitrate",
 )
 
@@ -66,6 +66,9 @@ def check_setting_conflicts(settings):
         if getattr(settings, name):
             raise NotImplementedError(
                 f"settings.{name}=True is outside the hot path of the hip backend (SURVEY.md section 8: out of scope)")
+    if settings.enable_routing_1D and not settings.enable_lateral_flow:
+        raise NotImplementedError("settings.enable_routing_1D routes the lateral subsurface runoff: it needs settings.enable_lateral_flow "
+                                  "(examples/hillslope_scale/oneD_distributed_routing_tutorial/oneD.py:82-83)")
     if settings.enable_offline_transport:
         # the native transport path: oxygen-18, deuterium, bromide or chloride with the deterministic SAS solver
         # 

@@ -356,6 +356,8 @@ class RogerState:
             "end_event", "hpi")}
         consts["enable_lateral_flow"] = int(bool(s.enable_lateral_flow))   # oneD model
         consts["dx"] = float(s.dx)
+        consts["enable_routing_1D"] = int(bool(s.enable_routing_1D))   # D8 routing of surface and subsurface runoff
+        consts["dy"] = float(s.dy)
         self._ctx = _native.Context(s.nx // px, s.ny // py, device=device, **consts)
         self._variables = RogerVariables(self._var_meta, self._manifest_dimensions(), self._ctx)
 

@@ -117,6 +117,9 @@ def build_variables(settings=None):
         V["station_id"] = Variable("station_id", CATCH_GRID, dtype=i64)
         for name in ("PREC_DIST", "TA_DIST", "PET_DIST"):
             V[name] = Variable(name, ("n_stations", "t_forc"))
+    # catchment boundary of the routing setups (oneD_distributed_routing_tutorial/oneD.py:133-197): the user's set_topography derives
+    # outer_boundary (a plane of the arena) from it on the host
+    V["inner_boundary"] = Variable("inner_boundary", CATCH_GRID, dtype=np.int32)
     V.update(_arena_variables())
     return V
 

@@ -56,6 +56,17 @@ def is_routing(g):
     return bool(int(g["routing"])) if "routing" in g.files else False
 
 
+def routing_of(g, names, columns=None):
+    """The `routing` argument of svat_scripts.make_model from a routing golden case (columns = (x0, x1): that slab of the grid)."""
+    nx, ny = (int(v) for v in g["nx_ny"])
+    s0 = np.asarray(g["state0"])
+    sl = slice(*columns) if columns else slice(None)
+    field = lambda k: s0[names.index(k)].reshape(nx, ny)[sl]   # noqa: E731
+    dx, dy = (float(v) for v in g["routing_dx_dy"])
+    return dict(flow_dir_topo=field("flow_dir_topo").astype(np.int32), outer_boundary=field("outer_boundary").astype(np.int32),
+                k_st=field("k_st"), dx=int(dx), dy=int(dy))
+
+
 def configure_settings(settings, g):
     """The model switches of a golden case on an oracle-side settings struct (oracle_binding.OcSettings)."""
     settings.enable_lateral_flow = int(is_lateral(g))

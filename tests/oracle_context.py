@@ -21,6 +21,7 @@ class OracleContext:
         self.st = ob.OracleState(self.n)
         for k, v in settings.items():
             setattr(self.st.settings, k, v)
+        self.st.settings.nx, self.st.settings.ny = self.nx, self.ny   # the routing gathers over the (local) grid
         self.mlms = None
         self.planes = list(zip(self.st.names, self.st.is_int))
         self.index = {nm: i for i, nm in enumerate(self.st.names)}
@@ -36,9 +37,6 @@ class OracleContext:
         self.series = None
         self.monthly = False
         self.words = [0, 0, 0, 0]
-
-    def close(self):
-        pass
 
     def sync(self):
         pass
@@ -119,7 +117,12 @@ class OracleContext:
             st.adaptive_dt(*self.day)
             return
         if entry == "rh_step_core":
-            self._after_adt(monthly=False, core_only=True, word1=self._local_word1())
+            # (several ranks: the word the ranks agreed on in the adaptive time stepping, adaptive_dt_finish)
+            w1 = self.__dict__.pop("_agreed_word1", None)
+            self._after_adt(monthly=False, core_only=True, word1=self._local_word1() if w1 is None else w1)
+            return
+        if entry in ("rh_surface_routing", "rh_subsurface_routing"):
+            (st.surface_routing if entry == "rh_surface_routing" else st.subsurface_routing)()
             return
         if entry == "rh_params_lateral":
             st.params_lateral(self.mlms)
@@ -282,6 +285,62 @@ class OracleContext:
     def adaptive_dt_finish(self):
         ob.lib().oc_adt_finish(self.st._ptrs, C.c_int64(self.n), *self._forc(), C.byref(self.st.scal),
                                C.byref(self.st.settings), C.c_uint64(self.words[0]), C.c_uint64(self.words[1]))
+        self._agreed_word1 = int(self.words[1])
+
+    # -- routing over several ranks: what rh_surface_routing / rh_subsurface_routing do over RCCL, here over the process group ----
+    def comm_init_torch(self, group=None):
+        """The edge columns of q_*_out (and, once, of flow direction and mask) go to the x-neighbours between the out and the in
+        part of a routing (oracle: oc_route_set_exchange / oc_route_set_halo)."""
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        P, nx, ny, L = self.st.planes, self.nx, self.ny, ob.lib()
+        self._halo = {"q": [np.zeros(ny), np.zeros(ny)], "fd": [np.zeros(ny, np.int32), np.zeros(ny, np.int32)],
+                      "mk": [np.zeros(ny, np.int32), np.zeros(ny, np.int32)], "static": False}
+
+        def swap(edges, dtype):
+            """edges = (lo, hi) of this rank -> (halo lo, halo hi) from the neighbours (None where there is none)."""
+            ops, got = [], [None, None]
+            for side, peer in ((0, rank - 1), (1, rank + 1)):
+                if 0 <= peer < world:
+                    got[side] = torch.zeros(ny, dtype=dtype)
+                    ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(edges[side])).to(dtype), peer, group))
+                    ops.append(dist.P2POp(dist.irecv, got[side], peer, group))
+            for r in dist.batch_isend_irecv(ops) if ops else []:
+                r.wait()
+            return got
+
+        def exchange(which):
+            H = self._halo
+            if not H["static"]:
+                fd, mk = P["flow_dir_topo"].reshape(nx, ny), P["maskCatch"].reshape(nx, ny)
+                for key, a in (("fd", fd), ("mk", mk)):
+                    for side, t in enumerate(swap((a[0], a[-1]), torch.int32)):
+                        if t is not None:
+                            H[key][side][:] = t.numpy()
+                H["static"] = True
+            q = P["q_sur_out" if which == 0 else "q_sub_out"].reshape(nx, ny)
+            for side, t in enumerate(swap((q[0], q[-1]), torch.float64)):
+                if t is None:
+                    L.oc_route_set_halo(side, None, None, None)
+                else:
+                    H["q"][side][:] = t.numpy()
+                    L.oc_route_set_halo(side, H["q"][side].ctypes.data_as(C.c_void_p), H["fd"][side].ctypes.data_as(C.c_void_p),
+                                        H["mk"][side].ctypes.data_as(C.c_void_p))
+
+        self._exchange_cb = C.CFUNCTYPE(None, C.c_int)(exchange)
+        L.oc_route_set_halo.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oc_route_set_exchange(self._exchange_cb)
+
+    def close(self):
+        if getattr(self, "_exchange_cb", None) is not None:
+            L = ob.lib()
+            L.oc_route_set_exchange(None)
+            L.oc_route_set_halo.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            for side in (0, 1):
+                L.oc_route_set_halo(side, None, None, None)
+            self._exchange_cb = None
 
 
 class OraclePhases:

@@ -9,7 +9,7 @@ from roger_amd.core.operators import at, numpy as npx, update
 from roger_amd.models.svat import SVATSetup
 
 
-def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights=None, stations=None):
+def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights=None, stations=None, routing=None):
     """global_shape: (nx, ny) of the whole domain when `params` holds this rank's slab only (num_proc = (N, 1))."""
     from roger_amd.models.oned import ONEDSetup
 
@@ -27,6 +27,9 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights
             s.nitt_forc = len(F["PREC"])
             s.dx = 1
             s.dy = 1
+            if routing is not None:   # examples/hillslope_scale/oneD_distributed_routing_tutorial/oneD.py:72-85
+                s.enable_routing_1D = True
+                s.dx, s.dy = routing["dx"], routing["dy"]
             s.x_origin = 0.0
             s.y_origin = 0.0
             s.time_origin = "2018-01-01 00:00:00"
@@ -39,11 +42,23 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights
                 s.nstations = len(stations["station_ids"])
 
         @roger_routine
+        def set_topography(self, state):
+            if routing is None:
+                return
+            vs = state.variables   # oneD_distributed_routing_tutorial/oneD.py:127-203: D8 flow direction, catchment boundary
+            vs.flow_dir_topo = update(vs.flow_dir_topo, at[2:-2, 2:-2], routing["flow_dir_topo"])
+            vs.inner_boundary = update(vs.inner_boundary, at[2:-2, 2:-2], 1)
+            vs.outer_boundary = update(vs.outer_boundary, at[2:-2, 2:-2], routing["outer_boundary"])
+            vs.maskCatch = update(vs.maskCatch, at[2:-2, 2:-2], 1)
+
+        @roger_routine
         def set_parameters_setup(self, state):
             vs = state.variables
             for k in ("lu_id", "z_soil", "dmpv", "lmpv", "theta_ac", "theta_ufc", "theta_pwp", "ks", "kf",
                       "sealing", "S_dep_tot"):
                 setattr(vs, k, update(getattr(vs, k), at[2:-2, 2:-2], params[k]))
+            if routing is not None:   # Strickler coefficient, oneD.py:330-335
+                vs.k_st = update(vs.k_st, at[2:-2, 2:-2], routing["k_st"])
             if lateral:   # benchmarks/oneD_benchmark.py:106-117
                 vs.slope = update(vs.slope, at[2:-2, 2:-2], params["slope"])
                 vs.slope_per = update(vs.slope_per, at[2:-2, 2:-2], vs.slope[2:-2, 2:-2] * 100)

@@ -240,3 +240,64 @@ def _mismatch_worker(rank, world, port):
 
 def test_world_size_must_match_num_proc():
     mp.spawn(_mismatch_worker, args=(2, 29500 + (os.getpid() % 2000) + 17), nprocs=2, join=True)
+
+
+def _routed_worker(rank, world, port, out_dir, device_hooks):
+    """The routed hillslope (settings.enable_routing_1D) on two ranks: every rank holds half of the x range; routed water crosses the cut
+    straight and diagonally, the edge columns travel between the out and the in part of both routings."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from roger_amd import runtime_settings
+
+    runtime_settings.update(num_proc=(world, 1))
+    import oracle_binding as ob
+    import oracle_context
+    import svat_scripts as S
+    from golden_util import load_case, routing_of
+    from roger_amd import _native
+    from roger_amd.distributed import get_chunk_slices
+
+    _native.Context = oracle_context.OracleContext
+    _native.plane_table = lambda: list(zip(ob.plane_names(), ob.plane_is_int()))
+    g, names, forcing = load_case("oned_routing")
+    nx, ny = (int(v) for v in g["nx_ny"])
+    (gx, gy), _ = get_chunk_slices(nx, ny, (world, 1), rank)
+    p = {k: v[gx, gy] for k, v in S.params_from_golden(g, names).items()}
+    ndays = len(forcing["PREC"]) // 144
+    model = S.make_model(p, forcing, ndays, lateral=True, global_shape=(nx, ny), routing=routing_of(g, names, columns=(gx.start, gx.stop)))
+    model.setup()
+    vs = model.state.variables
+    nsteps = int(g["nsteps"])
+    if device_hooks:
+        model.run_device(nsteps)
+    else:
+        for _ in range(nsteps):
+            model.step(model.state)
+    snap = S.snapshot_from_vs(vs, names)
+    sel = np.arange(nx * ny).reshape(nx, ny)[gx, gy].ravel()
+    np.savez(os.path.join(out_dir, f"routed{rank}.npz"), snap=snap, sel=sel,
+             scal=np.array([int(vs.itt), int(vs.time), int(vs.dt_secs), int(vs.itt_day), int(vs.event_id_counter)]))
+    model.state.backend_context.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_hooks", [False, True])
+def test_routing_on_two_ranks(tmp_path, oracle, device_hooks):
+    """settings.enable_routing_1D with num_proc = (2, 1): the two halves of the routed hillslope, exchanging their edge columns in both
+    routings of every step, reproduce the reference's single-domain run (which the reference itself could not: it never exchanges the
+    routed water between processes)."""
+    from golden_util import compare, load_case
+
+    port = 29500 + (os.getpid() % 2000) + 23 + int(device_hooks)
+    mp.spawn(_routed_worker, args=(2, port, str(tmp_path), device_hooks), nprocs=2, join=True)
+    g, names, _ = load_case("oned_routing")
+    nsteps = int(g["nsteps"])
+    ref, gs = g[f"s{nsteps:05d}"], g["scal"][nsteps - 1]
+    got = np.full_like(ref, np.nan)
+    for r in range(2):
+        d = np.load(tmp_path / f"routed{r}.npz")
+        np.testing.assert_array_equal(d["scal"], [gs[0], gs[1], gs[2], gs[3], gs[6]], err_msg=f"rank {r}")
+        got[:, d["sel"]] = d["snap"]
+    compare(got, ref, names, what=f"routing on 2 ranks, step {nsteps}")

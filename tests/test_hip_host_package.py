@@ -223,3 +223,29 @@ def test_output_diagnostics_hourly_on_device(tmp_path):
     finally:
         for f in files:
             f.close()
+
+
+def test_routed_setup_on_device():
+    """settings.enable_routing_1D through the host package on the device: `step()` (hooks on the host, rh_adaptive_dt + rh_step_core,
+    which runs routine by routine with the two gathers for a routing context) and `run_device()` against the reference's routed run."""
+    import svat_scripts as S
+    from golden_util import routing_of
+
+    g, names, forcing = load_case("oned_routing")
+    ndays = len(forcing["PREC"]) // 144
+    nsteps = int(g["nsteps"])
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=True, routing=routing_of(g, names))
+    model.setup()
+    vs = model.state.variables
+    compare(S.snapshot_from_vs(vs, names), g["state0"], names, what="after setup()")
+    for step in range(1, nsteps + 1):
+        model.step(model.state)
+        key = f"s{step:05d}"
+        if key in g.files:
+            for i, k in enumerate(("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")):
+                assert getattr(vs, k) == g["scal"][step - 1][i], (step, k)
+            compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"step {step}")
+    fast = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=True, routing=routing_of(g, names))
+    fast.setup()
+    fast.run_device(nsteps)
+    compare(S.snapshot_from_vs(fast.state.variables, names), g[f"s{nsteps:05d}"], names, what="run_device")

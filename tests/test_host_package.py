@@ -422,3 +422,29 @@ def test_output_diagnostics_hourly(oracle_backend, tmp_path):
     np.testing.assert_allclose(prec[1:], np.stack(want_prec), rtol=1e-13, atol=1e-13)
     steps = np.diff(t) * 24
     assert np.isclose(steps, 1).any() and np.isclose(steps, 24).any()     # hourly records and whole-day records
+
+
+def test_routed_setup_reproduces_reference(oracle_backend):
+    """settings.enable_routing_1D through the host package: the routed hillslope the golden generator ran through the reference
+    (tests/golden/oned_routing.npz), same setup script, `step()` with the user hooks on the host and `run_device()`."""
+    import svat_scripts as S
+    from golden_util import routing_of
+
+    g, names, forcing = load_case("oned_routing")
+    ndays = len(forcing["PREC"]) // 144
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=True, routing=routing_of(g, names))
+    model.setup()
+    vs = model.state.variables
+    compare(S.snapshot_from_vs(vs, names), g["state0"], names, what="after setup()")
+    nsteps = int(g["nsteps"])
+    for step in range(1, nsteps + 1):
+        model.step(model.state)
+        for i, k in enumerate(("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "event_id_counter", "dt")):
+            assert getattr(vs, k) == g["scal"][step - 1][i], (step, k)
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"step {step}")
+    fast = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=True, routing=routing_of(g, names))
+    fast.setup()
+    fast.run_device(nsteps)
+    compare(S.snapshot_from_vs(fast.state.variables, names), g[f"s{nsteps:05d}"], names, what="run_device")
