@@ -31,6 +31,11 @@
 #include "roger_hip.h"
 
 #define RH_BLOCK 256
+// unused slots appended to every tile of the arena (the tile stride in units of 512 bytes decides how the tiles spread over the HBM
+// channels; experiments)
+#ifndef RH_STRIDE_PAD
+#define RH_STRIDE_PAD 0
+#endif
 #define RH_PRED_BLOCKS 1024  // grid of the grid-stride predicate kernels
 #define RH_DONE_GROUPS 1024  // completion counters of the fused kernel (two levels: workgroup -> group -> grid)
 #define RH_DEVERR_FORCING 1u // a step began a day beyond the end of the resident forcing series
@@ -1673,7 +1678,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->per_cell = false;
 #if RH_TILED
     const size_t n_tiles = ((size_t)ctx->n + RH_TILE_CELLS - 1) / RH_TILE_CELLS;
-    const size_t stride = (size_t)RH_NPLANES * RH_SLOT_BYTES, arena_bytes = n_tiles * stride;
+    const size_t stride = (size_t)(RH_NPLANES + RH_STRIDE_PAD) * RH_SLOT_BYTES, arena_bytes = n_tiles * stride;
 #else
     const size_t stride = (((size_t)ctx->n * sizeof(double)) + 255) / 256 * 256, arena_bytes = stride * RH_NPLANES;
 #endif
