@@ -11,6 +11,12 @@
 #include "roger_hip_sas.h"
 
 #define SAS_DEV __device__ __forceinline__
+// the workgroup barrier of the cross-wave reductions (-DRH_SAS_NO_BARRIER: timing experiments only, the results are then wrong)
+#ifdef RH_SAS_NO_BARRIER
+#define SAS_SYNC() ((void)0)
+#else
+#define SAS_SYNC() __syncthreads()
+#endif
 
 // (SA / S) ** k of the power-law SAS function, the hot spot of the kernel: 5 * substeps * (ages + 1)
 // evaluations per column and day.  The device library's general pow() costs ~230 VALU instructions
@@ -232,7 +238,7 @@ SAS_DEV void blk_prev2(Blk<W> &B, double a, double b, double a0, double b0, doub
             B.xch[buf][B.wave][0] = a;
             B.xch[buf][B.wave][1] = b;
         }
-        __syncthreads();
+        SAS_SYNC();
         if (B.lane == 0 && B.wave > 0) {
             pa = B.xch[buf][B.wave - 1][0];
             pb = B.xch[buf][B.wave - 1][1];
@@ -255,7 +261,7 @@ SAS_DEV void blk_sum(Blk<W> &B, double (&v)[N]) {
 #pragma unroll
             for (int i = 0; i < N; ++i) B.red[buf][B.wave][i] = v[i];
         }
-        __syncthreads();
+        SAS_SYNC();
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double s = B.red[buf][0][i];
@@ -270,7 +276,7 @@ SAS_DEV double blk_max(Blk<W> &B, double v) {
     if (W > 1) {
         const int buf = B.phase++ & 1;
         if (B.lane == 0) B.red[buf][B.wave][0] = v;
-        __syncthreads();
+        SAS_SYNC();
         v = B.red[buf][0][0];
         for (int w = 1; w < W; ++w) v = fmax(v, B.red[buf][w][0]);
     }
@@ -340,7 +346,7 @@ SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double
         B.red[buf][B.wave][1] = ktop;
         B.red[buf][B.wave][2] = utop;
     }
-    __syncthreads();
+    SAS_SYNC();
     double pw = 0.0, mine = 0.0, S = 0.0, kglob = -1.0;
     for (int w = 0; w < W; ++w) {
         if (w == B.wave) mine = pw;
@@ -560,7 +566,7 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
 #pragma unroll
             for (int q = 0; q < 5; ++q) B.red[buf][B.wave][q] = (double)cnt5[q];
         }
-        __syncthreads();
+        SAS_SYNC();
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             double c = B.red[buf][0][q];
