@@ -111,8 +111,11 @@ int rh_upload(rh_ctx *ctx, int plane, const void *host, size_t bytes);
 int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes);
 /* Device address of cell 0 of a plane.  The arena is tiled (64 cells per tile, a 512-byte slot per plane and tile,
  * roger_amd/csrc/rh_col.h): cell i of the plane is at
- *     ptr + (i / 64) * (rh_num_planes() * 512) + (i % 64) * sizeof(element). */
+ *     ptr + (i / 64) * (rh_planes_held(ctx) * 512) + (i % 64) * sizeof(element).
+ * rh_planes_held: the planes the context's arena has slots for -- all of rh_num_planes() for a routing context, otherwise all but the
+ * routing's planes (flow_dir_topo ... q_sub_in_ss, the last ones of rh_fields.def), which rh_upload / rh_download then refuse. */
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane);
+int rh_planes_held(const rh_ctx *ctx);
 
 /* How the last fused step ran (measurement, tests): RH_STEP_MODE_LAZY = it deferred the tau -> taum1 copies of after_timestep
  * (models/svat/svat.py:187-384; materialised on demand), RH_STEP_MODE_TAIL = its last wavefront formed the control part of the next

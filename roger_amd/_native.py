@@ -45,6 +45,26 @@ _ENTRY_POINTS = (
 )
 
 
+class _Missing:
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, *a, **k):
+        raise NativeError(f"{self.name} is not exported by {LIB_PATH}")
+
+
+class _Tolerant:
+    def __init__(self, lib):
+        self.__dict__["_lib"] = lib
+        self.__dict__["_missing"] = {}
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._lib, name)
+        except AttributeError:
+            return self._missing.setdefault(name, _Missing(name))
+
+
 def load():
     """Load the shared library and declare every symbol of roger_hip.h."""
     global _lib
@@ -61,6 +81,8 @@ def load():
     except ImportError:
         pass
     lib = C.CDLL(LIB_PATH)
+    if os.environ.get("RH_OLD_VARIANT"):   # A/B against a library built from an older commit (tools/ab_variants.sh): entry points
+        lib = _Tolerant(lib)               # it lacks are declared on a stand-in that raises when called
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     lib.rh_abi_version.restype = i32
     lib.rh_default_config.argtypes = [C.POINTER(RhConfig)]
@@ -101,6 +123,7 @@ def load():
     lib.rh_set_comm.argtypes = [vp, vp]
     lib.rh_run_steps_dist.argtypes = [vp, i64]
     lib.rh_step_routed.argtypes = [vp, i32]
+    lib.rh_planes_held.argtypes = [vp]
     lib.rh_route_out.argtypes = [vp, i32]
     lib.rh_route_in.argtypes = [vp, i32]
     lib.rh_route_get_edges.argtypes = [vp, i32, vp, vp]
@@ -138,6 +161,9 @@ class RhSasConfig(C.Structure):
                 ("vsmow", C.c_double), ("d18O_min", C.c_double), ("d18O_max", C.c_double),
                 ("tracer", C.c_int32), ("solver", C.c_int32)]
 
+
+# the planes of the routing (settings.enable_routing_1D): the last ones of include/rh_fields.def, held by routing contexts only
+ROUTING_PLANES = ("flow_dir_topo", "outer_boundary", "k_st", "q_sur_out", "q_sur_in", "q_sub_out", "q_sub_in", "q_sub_in_rz", "q_sub_in_ss")
 
 # RH_SAS_TRACER_*.  Deuterium runs the isotope kernels of oxygen-18 with its own constants in the vsmow / d18O_min /
 # d18O_max fields of rh_sas_config (roger/core/transport.py:315-340, roger/settings.py:79-81)
@@ -357,7 +383,7 @@ DECLARED_SYMBOLS = (
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
-    "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
+    "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_planes_held", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
 
 
@@ -397,6 +423,7 @@ class Context:
         self.nx, self.ny, self.n = int(nx), int(ny), int(nx) * int(ny)
         self.planes = plane_table()
         self.index = {nm: i for i, (nm, _) in enumerate(self.planes)}
+        self.planes_held = int(lib.rh_planes_held(h))   # (the routing's planes exist in routing contexts only)
 
     def close(self):
         if getattr(self, "_h", None):

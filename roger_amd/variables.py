@@ -67,12 +67,14 @@ _INITIAL = {"maskCatch": True, "ta": 15, "z_gw": 1000, "c_int": 1.0, "c_root": 1
 _BOOL = {"maskCatch", "maskRiver", "maskLake"}
 
 
-def _arena_variables():
+def _arena_variables(routing=True):
     out = {}
     table = _native.plane_table()
     names = [n for n, _ in table]
     for name, is_int in table:
         if name.endswith("_m1") and name[:-3] in names:
+            continue
+        if not routing and name in _native.ROUTING_PLANES:   # active with settings.enable_routing_1D only, as in roger/variables.py
             continue
         two = (name + "_m1") in names
         dims = CATCH_GRID + TIMESTEPS if two else CATCH_GRID
@@ -119,8 +121,10 @@ def build_variables(settings=None):
             V[name] = Variable(name, ("n_stations", "t_forc"))
     # catchment boundary of the routing setups (oneD_distributed_routing_tutorial/oneD.py:133-197): the user's set_topography derives
     # outer_boundary (a plane of the arena) from it on the host
-    V["inner_boundary"] = Variable("inner_boundary", CATCH_GRID, dtype=np.int32)
-    V.update(_arena_variables())
+    routing = settings is None or bool(settings.enable_routing_1D)
+    if routing:
+        V["inner_boundary"] = Variable("inner_boundary", CATCH_GRID, dtype=np.int32)
+    V.update(_arena_variables(routing))
     return V
 
 

@@ -7,14 +7,19 @@ SCALARS = ("itt", "time", "dt_secs", "itt_day", "itt_forc", "time_event0", "even
 SCALARS2 = ("event_id", "year", "month", "doy")
 
 
+def _held(ctx, nm):
+    """The routing's planes exist in routing contexts only (rh_planes_held); the oracle double holds every plane."""
+    return nm in ctx.index and ctx.index[nm] < getattr(ctx, "planes_held", len(ctx.index))
+
+
 def upload_snapshot(ctx, snap, names):
     for row, nm in zip(snap, names):
-        if nm in ctx.index:
+        if _held(ctx, nm):
             ctx.upload(nm, row)
 
 
 def download_snapshot(ctx, names):
-    return np.stack([ctx.download(nm).astype(np.float64) for nm in names])
+    return np.stack([ctx.download(nm).astype(np.float64) if _held(ctx, nm) else np.zeros(ctx.n) for nm in names])
 
 
 def scalars_from_row(row):

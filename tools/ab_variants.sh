@@ -6,7 +6,7 @@ mkdir -p gpurun_out/ab
 for r in $(seq 1 "$rounds"); do
   for v in base "$@"; do
     if [ "$v" = base ]; then lib=roger_amd/libroger_hip.so; else lib=roger_amd/variants/libroger_hip_$v.so; fi
-    ROGER_HIP_LIB=$lib python bench.py $args --no-cpu-baseline > gpurun_out/ab/${v}_$r.json 2> gpurun_out/ab/${v}_$r.err || echo "$v failed"
+    RH_OLD_VARIANT=1 ROGER_HIP_LIB=$lib python bench.py $args --no-cpu-baseline > gpurun_out/ab/${v}_$r.json 2> gpurun_out/ab/${v}_$r.err || echo "$v failed"
   done
 done
 python - "$@" <<'PY'
