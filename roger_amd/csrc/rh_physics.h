@@ -1288,6 +1288,30 @@ RH_DEV bool rt_step_core_lateral(Col &c, const Consts &K, const StepCtx &X) {   
     rt_storage(c, X);
     return rt_num_error_lateral(c, K);
 }
+// settings.enable_routing_1D: the step core in the three passes the two gathers of the routing cut it into (roger/roger.py:410-447)
+RH_DEV void rt_routed_a(Col &c, const Consts &K, const StepCtx &X, double dt_secs) {
+    rt_interception(c, K);
+    rt_evapotranspiration(c, K);
+    rt_snow(c, K, X);
+    rt_infiltration_routed(c, K, X);
+    rt_route_surface_out(c, K, X, dt_secs);
+}
+RH_DEV void rt_routed_b(Col &c, const Consts &K, const StepCtx &X) {
+    rt_route_surface_in(c);
+    rt_subsurface_runoff_lateral(c, K, X);
+    rt_route_subsurface_out(c);
+}
+RH_DEV bool rt_routed_c(Col &c, const Consts &K, const StepCtx &X) {
+    rt_route_subsurface_in(c);
+    rt_capillary_rise(c, X);
+    rt_storage(c, X);
+    return rt_num_error_routed(c, K);
+}
+RH_DEV bool rt_routed_c_after(Col &c, const Consts &K, const StepCtx &X) {   // ... with after_timestep (rh_step_routed)
+    const bool bad = rt_routed_c(c, K, X);
+    rt_after_timestep_oned(c);
+    return bad;
+}
 RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
     rt_select_prec(c, X);
     rt_select_pet(c, X, pet_v, ta_v);

@@ -1284,6 +1284,12 @@ RH_CELL_KERNEL(k_route_surface_in, rt_route_surface_in, rt_route_surface_in(c))
 RH_CELL_KERNEL(k_route_subsurface_out, rt_route_subsurface_out, rt_route_subsurface_out(c))
 RH_CELL_KERNEL(k_route_subsurface_in, rt_route_subsurface_in, rt_route_subsurface_in(c))
 RH_CELL_KERNEL(k_num_error_routed, rt_num_error_routed, if (rt_num_error_routed(c, K)) atomicOr(&D->words[2], 1ull))
+// the step core in three passes, one kernel each (the infiltration's branch conditions come from the adaptive time stepping's
+// predicate word, as in k_step_core: global over the ranks)
+RH_CELL_KERNEL(k_routed_a, rt_routed_a, rt_routed_a(c, K, X, (double)D->S.dt_secs))
+RH_CELL_KERNEL(k_routed_b, rt_routed_b, rt_routed_b(c, K, X))
+RH_CELL_KERNEL(k_routed_c, rt_routed_c, if (rt_routed_c(c, K, X)) atomicOr(&D->words[2], 1ull))
+RH_CELL_KERNEL(k_routed_c_after, rt_routed_c_after, if (rt_routed_c_after(c, K, X)) atomicOr(&D->words[2], 1ull))
 // set_parameters' month-change test was evaluated on the device by the set_forcing hook (D->monthly)
 __global__ __launch_bounds__(RH_BLOCK) void k_params_surface_if_monthly(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -2073,10 +2079,10 @@ int rh_num_error(rh_ctx *ctx) {
 
 // interception ... numerics in one kernel, then itt/time (roger/roger.py:410-457); for drivers that
 // keep the user hooks `set_parameters` and `after_timestep` on the host
-static int routed_core(rh_ctx *ctx);
+static int routed_core(rh_ctx *ctx, bool with_after);
 int rh_step_core(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
-    if (ctx->cfg.enable_routing_1D) return routed_core(ctx);   // the columns are coupled: routine by routine with the two gathers
+    if (ctx->cfg.enable_routing_1D) return routed_core(ctx, false);   // the columns are coupled: routine by routine with the two gathers
     if (ctx->cfg.enable_lateral_flow)
         LAUNCH_CELLS(ctx, k_step_core_lateral);
     else
@@ -2174,7 +2180,7 @@ int rh_route_set_halo(rh_ctx *ctx, int side, const double *q, const int32_t *flo
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RH_OK;
 }
-int rh_route_in(rh_ctx *ctx, int which) {
+static int rh_route_gather_only(rh_ctx *ctx, int which) {
     int rc = route_check(ctx, which, "rh_route_in");
     if (rc) return rc;
     const size_t ny = (size_t)ctx->cfg.ny;
@@ -2188,6 +2194,12 @@ int rh_route_in(rh_ctx *ctx, int which) {
     planes_touched(ctx);
     hipLaunchKernelGGL(k_route_gather, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, (int)ctx->cfg.nx, (int)ctx->cfg.ny,
                        which == 0 ? (int)RH_P_q_sur_out : (int)RH_P_q_sub_out, which == 0 ? (int)RH_P_q_sur_in : (int)RH_P_q_sub_in, H);
+    CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+int rh_route_in(rh_ctx *ctx, int which) {
+    int rc = rh_route_gather_only(ctx, which);
+    if (rc) return rc;
     if (which == 0) LAUNCH_CELLS(ctx, k_route_surface_in);
     else LAUNCH_CELLS(ctx, k_route_subsurface_in);
     CHECK_LAUNCH(ctx);
@@ -2549,19 +2561,28 @@ static int allreduce_word(rh_ctx *ctx, int word) {
     return rh_predicates_compress(ctx, word, ctx->exch_buf + 64);
 }
 // interception ... numerics, itt / time (what rh_step_core is for the uncoupled columns)
-static int routed_core(rh_ctx *ctx) {
+static int routed_core(rh_ctx *ctx, bool with_after) {
     int rc;
-    LAUNCH_CELLS(ctx, k_interception);
-    LAUNCH_CELLS(ctx, k_evapotranspiration);
-    LAUNCH_CELLS(ctx, k_snow);
-    if ((rc = rh_infiltration(ctx)) || (rc = rh_surface_routing(ctx))) return rc;
-    LAUNCH_CELLS(ctx, k_subsurface_runoff_lateral);
-    if ((rc = rh_subsurface_routing(ctx))) return rc;
-    LAUNCH_CELLS(ctx, k_capillary_rise);
-    LAUNCH_CELLS(ctx, k_storage);
-    if ((rc = rh_num_error(ctx))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->dev->sanity_last, 0, sizeof(unsigned long long), ctx->stream));
+    LAUNCH_CELLS(ctx, k_routed_a);                    // interception ... infiltration, the surface outflow
+    if (ctx->comm && ctx->comm_nranks > 1 && (rc = route_exchange(ctx, 0))) return rc;
+    if ((rc = rh_route_gather_only(ctx, 0))) return rc;
+    LAUNCH_CELLS(ctx, k_routed_b);                    // the surface inflow, the lateral subsurface runoff, its outflow
+    if (ctx->comm && ctx->comm_nranks > 1 && (rc = route_exchange(ctx, 1))) return rc;
+    if ((rc = rh_route_gather_only(ctx, 1))) return rc;
+    // the subsurface inflow, capillary rise, storages, numerics [, after_timestep: the output accumulators then read the taum1 planes
+    // only for variables the rotation has just made equal to tau -- they accumulate tau values, kept by a separate pass otherwise]
+    const bool fuse_after = with_after && !ctx->diag_n;
+    if (fuse_after) LAUNCH_CELLS(ctx, k_routed_c_after);
+    else LAUNCH_CELLS(ctx, k_routed_c);
+    LAUNCH_ONE(ctx, k_sanity_to_scalars, ctx->dev);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    if (with_after) {
+        if (fuse_after) LAUNCH_ONE(ctx, k_rotate_scalars, ctx->dev);
+        else if ((rc = rh_after_timestep(ctx))) return rc;
+    }
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
@@ -2577,8 +2598,7 @@ int rh_step_routed(rh_ctx *ctx, int monthly) {
         return rc;
     if (monthly < 0) LAUNCH_CELLS(ctx, k_params_surface_if_monthly);
     else if (monthly) LAUNCH_CELLS(ctx, k_params_surface);
-    if ((rc = routed_core(ctx))) return rc;
-    return rh_after_timestep(ctx);
+    return routed_core(ctx, true);
 }
 
 int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double *ta_offset, const double *pet_weight) {
