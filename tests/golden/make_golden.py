@@ -531,6 +531,23 @@ def main():
         run_case(roger, "oned_routing", p, toy_forcing("heavyrain", ndays=4), 4, 100000, 25, {1, 2, 30, 31, 60}, args.out,
                  lateral=True, pair_every=10, routing=routing)
 
+    # the reference's own routing example (examples/hillslope_scale/oneD_distributed_routing_tutorial: config.yml, oneD.py:127-335,
+    # 455-483): a 1 x 20 hillslope, dx = dy = 1 m, every cell draining towards +y, uniform soil, Strickler coefficient 50, soil at field
+    # capacity, the station's series (the same files as Eberbaechle's: the first 40 days, 2019-11-01 ...) with the example's weights
+    # (prec x 1, ta + 1, pet x 1)
+    if not args.only or args.only == "oned_routing_tutorial":
+        from roger_amd.forcing import forcing_from_txt
+
+        nx, ny, nd = 1, 20, 25
+        f = lambda v: np.full((nx, ny), v)  # noqa: E731
+        p = dict(lu_id=np.full((nx, ny), 8, dtype=np.int32), sealing=f(0.0), S_dep_tot=f(0.0), z_soil=f(900.0), slope=f(0.05), dmpv=f(50.0),
+                 dmph=f(50.0), lmpv=f(600.0), theta_ac=f(0.1), theta_ufc=f(0.1), theta_pwp=f(0.2), ks=f(20.0), kf=f(1.0),
+                 theta_rz0=f(0.3), theta_ss0=f(0.3))
+        routing = dict(flow_dir_topo=np.full((nx, ny), 4), outer_boundary=np.zeros((nx, ny), dtype=int), k_st=f(50.0), dx=1, dy=1)
+        weights = dict(prec_weight=f(1.0), ta_offset=f(1.0), pet_weight=f(1.0))
+        run_case(roger, "oned_routing_tutorial", p, forcing_from_txt(EBERBAECHLE_INPUT, ndays=nd), nd, 100000, 40, {1, 2, 200, 201}, args.out,
+                 lateral=True, pair_every=25, routing=routing, weights=weights)
+
 
 if __name__ == "__main__":
     main()

@@ -9,7 +9,8 @@ SVAT_CASES = ("svat_uniform_rain", "svat_hetero_snowrain", "svat_hetero_heavyrai
 # oneD model: lateral subsurface flow; the last: BASELINE configs[3]'s own uniform parameter set (benchmarks/oneD_benchmark.py:99-135)
 ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo", "oned_uniform_benchmark")
 # settings.enable_routing_1D: surface and subsurface runoff routed to the D8 neighbour (oneD_distributed_routing_tutorial)
-ROUTING_CASES = ("oned_routing",)
+# ... and the reference's own routing example (1 x 20 hillslope, the station's measured series, uniform weights)
+ROUTING_CASES = ("oned_routing", "oned_routing_tutorial")
 CASES = SVAT_CASES + ONED_CASES
 # BASELINE configs[4] (Eberbaechle, svat_distributed): the station's measured series x per-cell prec_weight / ta_offset / pet_weight
 WEIGHTED_CASES = ("svat_eberbaechle_weights",)
@@ -29,12 +30,19 @@ def load_case(name):
     g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     names = [str(x) for x in g["plane_names"]]
     forcing = {k[5:]: g[k] for k in g.files if k.startswith("forc_")}
+    if name in ROUTING_CASES and "weight_prec_weight" in g.files:
+        # the routing example weighs the station's series with maps that are uniform (prec x 1, ta + 1, pet x 1): one shared series
+        w = {k: np.asarray(g[f"weight_{k}"], dtype=np.float64) for k in ("prec_weight", "ta_offset", "pet_weight")}
+        assert all(np.all(v == v.flat[0]) for v in w.values())
+        forcing = dict(forcing, PREC=forcing["PREC"] * w["prec_weight"].flat[0], TA=forcing["TA"] + w["ta_offset"].flat[0],
+                       PET=forcing["PET"] * w["pet_weight"].flat[0])
     return g, names, forcing
 
 
 def load_weights(g):
-    """Per-cell forcing weights of a golden case (None for the cases whose columns share one series)."""
-    if "weight_prec_weight" not in g.files:
+    """Per-cell forcing weights of a golden case (None for the cases whose columns share one series, and for the routing example, whose
+    uniform weights load_case has applied to the series)."""
+    if "weight_prec_weight" not in g.files or is_routing(g):
         return None
     return {k: np.asarray(g[f"weight_{k}"], dtype=np.float64) for k in ("prec_weight", "ta_offset", "pet_weight")}
 

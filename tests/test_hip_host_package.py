@@ -249,3 +249,37 @@ def test_routed_setup_on_device():
     fast.setup()
     fast.run_device(nsteps)
     compare(S.snapshot_from_vs(fast.state.variables, names), g[f"s{nsteps:05d}"], names, what="run_device")
+
+
+def test_routing_example_from_text_inputs(tmp_path):
+    """examples/oned_routing_tutorial.py end to end on the first 25 days of the example's measured inputs (the Eberbaechle fixture: the
+    reference ships the same three files with both setups): text files -> device hooks with the example's station weights -> routed steps
+    -> ONED.rate.nc / ONED.collect.nc; the final state equals the reference's run of the same hillslope (golden oned_routing_tutorial),
+    and the routed fluxes of the files chain down the slope (what leaves a cell arrives in the next)."""
+    import importlib.util
+    import os
+
+    import svat_scripts as S
+    from golden_util import GOLDEN_DIR
+    from roger_amd import runtime_settings as rs
+    from scipy.io import netcdf_file
+
+    spec = importlib.util.spec_from_file_location("oned_routing_example", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "oned_routing_tutorial.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        model = ex.main([os.path.join(GOLDEN_DIR, "eberbaechle_input"), "--days", "25", "--out", str(tmp_path)])
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    g, names, _ = load_case("oned_routing_tutorial")
+    nsteps = int(g["nsteps"])
+    vs = model.state.variables
+    assert vs.itt == nsteps and vs.time == 25 * 86400
+    compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what="routing example, day 25")
+    with netcdf_file(str(tmp_path / "ONED.rate.nc"), "r", mmap=False) as f:
+        out, inn = f.variables["q_sub_out"][:, :, 0].copy(), f.variables["q_sub_in"][:, :, 0].copy()   # (Time, y, x)
+        assert f.variables["Time"].shape == (26,)
+    assert out[1:].sum() > 0
+    np.testing.assert_allclose(inn[1:, 1:], out[1:, :-1], rtol=1e-9, atol=1e-12)   # every cell drains into the next one along y

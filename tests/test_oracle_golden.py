@@ -42,7 +42,7 @@ def test_single_steps_from_reference_states(oracle, case):
     ways at such ties; see DESIGN.md.  Single steps from identical states do not.)"""
     g, names, forcing = load_case(case)
     pairs = single_step_pairs(g)
-    assert len(pairs) >= 20
+    assert len(pairs) >= 12
     for k in pairs:
         st = _start(oracle, g, names, key=f"s{k - 1:05d}")
         st.load_scalars(g["scal"][k - 2])
