@@ -157,3 +157,26 @@ def forcing_from_txt(input_dir, float_type="float32", ndays=None):
     out["MONTH"] = table.index.month.to_numpy().astype(np.int64)
     out["DOY"] = table.index.dayofyear.to_numpy().astype(np.int64)
     return out
+
+
+def forcing_from_nc(path, ndays=None, cell=(0, 0)):
+    """The same dict from a `forcing.nc` as the reference's `write_forcing` stores it (roger/tools/setup.py:565-626: netCDF-4 with
+    PREC / TA / PET (x, y, Time) -- one station broadcast over the grid --, YEAR / MONTH / DOY (Time)) and its setup scripts read it
+    back (`_read_var_from_nc(...)[0, 0, :]`, e.g. examples/hillslope_scale/oneD_distributed_routing_tutorial/oneD.py:500-504).  Read with
+    h5py where it is installed, otherwise with `roger_amd.h5lite`."""
+    try:
+        import h5py
+
+        with h5py.File(path, "r") as f:
+            v = {k: np.asarray(f[k]) for k in ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY")}
+    except ImportError:
+        from . import h5lite
+
+        v = h5lite.read_root(path)
+    missing = [k for k in ("PREC", "TA", "PET", "YEAR", "MONTH", "DOY") if k not in v]
+    if missing:
+        raise KeyError(f"{path} lacks the variables {missing}")
+    n = v["PREC"].shape[-1] if ndays is None else min(int(ndays) * SLOTS_PER_DAY, v["PREC"].shape[-1])
+    out = {k: np.asarray(v[k][cell[0], cell[1], :n], dtype=np.float64) for k in ("PREC", "TA", "PET")}
+    out.update({k: np.asarray(v[k][:n], dtype=np.int64) for k in ("YEAR", "MONTH", "DOY")})
+    return out

@@ -152,9 +152,11 @@ class _Reader:
     # -- object headers ---------------------------------------------------------------------------------------------------------
     def messages(self, addr):
         d = self.d
+        if d[addr:addr + 4] == b"OHDR":
+            return self._messages_v2(addr)
         ver, nmsg, _, size = struct.unpack_from("<BxHII", d, addr)
         if ver != 1:
-            raise ValueError("h5lite: version-2 object header (the file was written with libver='latest'): read it with h5py")
+            raise ValueError("h5lite: unknown object header version")
         blocks = [(addr + 16, size)]
         out = []
         while blocks and len(out) < nmsg:
@@ -168,6 +170,39 @@ class _Reader:
                     caddr, clen = struct.unpack_from("<QQ", body, 0)
                     blocks.append((caddr, clen))
                 out.append((mtype, body))
+        return out
+
+    def _messages_v2(self, addr):
+        """Version-2 object header ("OHDR", continuation chunks "OCHK"): what libhdf5 writes for objects of files that track the creation
+        order of links and attributes -- every netCDF-4 file (h5netcdf / netCDF4 create their groups with track_order)."""
+        d = self.d
+        if d[addr + 4] != 2:
+            raise ValueError("h5lite: unknown object header version")
+        flags = d[addr + 5]
+        pos = addr + 6
+        if flags & 0x20:
+            pos += 16            # access, modification, change, birth time
+        if flags & 0x10:
+            pos += 4             # max compact / min dense attributes
+        nb = 1 << (flags & 3)
+        size = int.from_bytes(d[pos:pos + nb], "little")
+        pos += nb
+        corder = 2 if flags & 0x04 else 0
+        blocks = [(pos, pos + size)]
+        out = []
+        while blocks:
+            pos, end = blocks.pop(0)
+            while pos + 4 + corder <= end:
+                mtype, msize, _ = struct.unpack_from("<BHB", d, pos)
+                body = d[pos + 4 + corder:pos + 4 + corder + msize]
+                pos += 4 + corder + msize
+                if mtype == 0x10:
+                    caddr, clen = struct.unpack_from("<QQ", body, 0)
+                    if d[caddr:caddr + 4] != b"OCHK":
+                        raise ValueError("h5lite: object header continuation chunk expected")
+                    blocks.append((caddr + 4, caddr + clen - 4))   # between the signature and the checksum
+                elif mtype != 0:
+                    out.append((mtype, body))
         return out
 
     # -- groups -----------------------------------------------------------------------------------------------------------------
@@ -195,22 +230,114 @@ class _Reader:
                 yield c
 
     def group(self, hdr_addr):
-        """{name: object header address} of a symbol-table group."""
-        st = [b for t, b in self.messages(hdr_addr) if t == 0x0011]
-        if not st:
-            raise ValueError("h5lite: not a symbol-table group")
-        tree, heap = struct.unpack_from("<QQ", st[0], 0)
+        """{name: object header address} of a group: symbol table (classic) or link messages / a fractal heap of them (new style)."""
+        msgs = self.messages(hdr_addr)
+        st = [b for t, b in msgs if t == 0x0011]
+        if st:
+            tree, heap = struct.unpack_from("<QQ", st[0], 0)
+            out = {}
+            for snod in self._tree_leaves(tree):
+                assert self.d[snod:snod + 4] == b"SNOD"
+                n = struct.unpack_from("<H", self.d, snod + 6)[0]
+                for i in range(n):
+                    name_off, obj = struct.unpack_from("<QQ", self.d, snod + 8 + 40 * i)
+                    out[self._heap_name(heap, name_off)] = obj
+            return out
         out = {}
-        for snod in self._tree_leaves(tree):
-            assert self.d[snod:snod + 4] == b"SNOD"
-            n = struct.unpack_from("<H", self.d, snod + 6)[0]
-            for i in range(n):
-                name_off, obj = struct.unpack_from("<QQ", self.d, snod + 8 + 40 * i)
-                out[self._heap_name(heap, name_off)] = obj
+        for t, b in msgs:
+            if t == 0x06:        # compact storage: the links are messages of the header
+                name, obj, _ = self._link(b, 0)
+                if obj is not None:
+                    out[name] = obj
+            elif t == 0x02:      # link info: dense storage in a fractal heap
+                pos = 2 + (8 if b[1] & 1 else 0)
+                heap = struct.unpack_from("<Q", b, pos)[0]
+                if heap != UNDEF:
+                    out.update(self._heap_links(heap))
+        if not any(t in (0x02, 0x06) for t, _ in msgs):
+            raise ValueError("h5lite: not a group")
+        return out
+
+    def _link(self, b, pos):
+        """A link message at b[pos:]: (name, object header address or None for a soft / external link, position after it)."""
+        if b[pos] != 1:
+            raise ValueError("h5lite: link message version")
+        flags = b[pos + 1]
+        pos += 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = b[pos]
+            pos += 1
+        if flags & 0x04:
+            pos += 8
+        if flags & 0x10:
+            pos += 1
+        nb = 1 << (flags & 3)
+        nlen = int.from_bytes(b[pos:pos + nb], "little")
+        pos += nb
+        name = bytes(b[pos:pos + nlen]).decode()
+        pos += nlen
+        if ltype == 0:
+            return name, struct.unpack_from("<Q", b, pos)[0], pos + 8
+        if ltype == 1:           # soft link: length + path
+            n = struct.unpack_from("<H", b, pos)[0]
+            return name, None, pos + 2 + n
+        n = struct.unpack_from("<H", b, pos)[0]
+        return name, None, pos + 2 + n
+
+    def _heap_links(self, addr):
+        """The link messages held as managed objects of a fractal heap ("FRHP").  Files written once hold them back to back from the
+        start of every direct block, so the blocks are read through instead of going by the name index (a version-2 B-tree)."""
+        d = self.d
+        if d[addr:addr + 4] != b"FRHP":
+            raise ValueError("h5lite: fractal heap expected")
+        flags = d[addr + 9]
+        (width,) = struct.unpack_from("<H", d, addr + 110)
+        start_size, max_direct = struct.unpack_from("<QQ", d, addr + 112)
+        max_bits, _, root, cur_rows = struct.unpack_from("<HHQH", d, addr + 128)
+        if struct.unpack_from("<H", d, addr + 7)[0]:
+            raise ValueError("h5lite: filtered fractal heap")
+        off_bytes = (max_bits + 7) // 8
+        dhdr = 5 + 8 + off_bytes + (4 if flags & 2 else 0)
+        max_direct_rows = (max_direct.bit_length() - 1) - (start_size.bit_length() - 1) + 2
+        out = {}
+
+        def direct(baddr, size):
+            if baddr == UNDEF:
+                return
+            if d[baddr:baddr + 4] != b"FHDB":
+                raise ValueError("h5lite: fractal heap direct block expected")
+            pos, end = baddr + dhdr, baddr + size
+            while pos < end and d[pos] == 1:
+                name, obj, nxt = self._link(d, pos)
+                if obj is not None:
+                    out[name] = obj
+                pos = nxt
+
+        def indirect(baddr, rows):
+            if baddr == UNDEF:
+                return
+            if d[baddr:baddr + 4] != b"FHIB":
+                raise ValueError("h5lite: fractal heap indirect block expected")
+            pos = baddr + 5 + 8 + off_bytes
+            for r in range(rows):
+                size = start_size * (1 if r < 2 else 2 ** (r - 1))
+                for _ in range(width):
+                    child = struct.unpack_from("<Q", d, pos)[0]
+                    pos += 8
+                    if r < max_direct_rows:
+                        direct(child, size)
+                    else:
+                        indirect(child, (size.bit_length() - 1) - (start_size * width).bit_length() + 2)
+
+        if cur_rows == 0:
+            direct(root, start_size)
+        else:
+            indirect(root, cur_rows)
         return out
 
     def is_group(self, hdr_addr):
-        return any(t == 0x0011 for t, _ in self.messages(hdr_addr))
+        return any(t in (0x0011, 0x02, 0x06) for t, _ in self.messages(hdr_addr))
 
     # -- datasets ---------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -306,6 +433,18 @@ class _Reader:
                 yield from self._chunks(child, rank1)
             else:
                 yield offs, d[child:child + csize], mask
+
+
+def read_root(path):
+    """{dataset name: array} of the datasets directly under the root -- the variables of a netCDF-4 file (forcing.nc, parameters.nc,
+    <identifier>.rate.nc ... as the reference writes them through h5netcdf: version-2 object headers, links in a fractal heap,
+    chunked + gzip data; the dimension scales come back as datasets like any other)."""
+    return read(path).get("", {})
+
+
+def is_hdf5(path):
+    with open(path, "rb") as f:
+        return f.read(8) == SIG
 
 
 def read(path):

@@ -28,12 +28,25 @@ SVAT_STORAGES = ("S_rz", "S_ss", "S_snow", "S_pwp_rz", "S_pwp_ss", "S_sat_rz", "
 def read_svat_output(rate_nc, collect_nc):
     """The daily flux sums and end-of-day storages a SVAT run wrote through `state.diagnostics` (roger_amd/diagnostics.py:
     `<identifier>.rate.nc`, `<identifier>.collect.nc`) as the `svat` dict of `make_transport_model`: arrays (nx, ny, days + 1),
-    record 0 = initial values -- the variables the reference's transport models read from SVAT.nc
+    record 0 = initial values; the reference's own netCDF-4 output files are read as well -- the variables the reference's transport models read from SVAT.nc
     (roger/models/svat_oxygen18/svat_oxygen18.py:148-163, 231-241, 452-473)."""
     from scipy.io import netcdf_file
 
+    from .. import h5lite
+
     out = {}
     for path, names in ((rate_nc, SVAT_RATES), (collect_nc, SVAT_STORAGES)):
+        if h5lite.is_hdf5(str(path)):   # netCDF-4, as the reference itself writes its output (h5netcdf): same variables, same (Time, y, x)
+            try:
+                import h5py
+
+                with h5py.File(str(path), "r") as f:
+                    have = {k: np.asarray(f[k]) for k in names if k in f}
+            except ImportError:
+                have = {k: v for k, v in h5lite.read_root(str(path)).items() if k in names}
+            for k, v in have.items():
+                out[k] = np.ascontiguousarray(np.asarray(v, dtype=np.float64).transpose(2, 1, 0))
+            continue
         with netcdf_file(str(path), "r", mmap=False) as f:
             for k in names:
                 if k in f.variables:
