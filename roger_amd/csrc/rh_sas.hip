@@ -397,6 +397,14 @@ template <int W, bool ANION>
 __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY_E8 void k_sas8(const SasArgs P) {
     sas_body<W, 8, ANION>(P);
 }
+// Sixteen age classes per thread, ONE wavefront per column (ages <= 1023): no workgroup barrier and no exchange through LDS at all, the
+// scans are the wave's DPP scan plus a running sum over the thread's own classes; the state of a column then takes the register file of
+// a whole SIMD (1 wave/SIMD, 512 registers: VGPRs + AGPRs).  -DRH_SAS_EXPERIMENT_E16 builds ONLY this shape (experiments).
+#define SAS_OCCUPANCY_E16 __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <bool ANION>
+__global__ __launch_bounds__(64) SAS_OCCUPANCY_E16 void k_sas16(const SasArgs P) {
+    sas_body<1, 16, ANION>(P);
+}
 template <int W, int E, bool ANION>
 __device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
@@ -969,6 +977,14 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     const int nages = c.ages + 1;
     // eight classes per thread from 257 age classes on (9.63 against 10.17 ms per day at 10^5 columns x 1000 ages); RH_SAS_E4=1: the
     // four-class shapes for comparison
+#ifdef RH_SAS_EXPERIMENT_E16
+    if (nages > 1024) return sfail(ctx, RH_ERR_ARG, "RH_SAS_EXPERIMENT_E16: ages <= 1023 only");
+    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18) hipLaunchKernelGGL((k_sas16<true>), dim3((unsigned)ctx->cfg.n_cells), dim3(64), 0, ctx->stream, args);
+    else hipLaunchKernelGGL((k_sas16<false>), dim3((unsigned)ctx->cfg.n_cells), dim3(64), 0, ctx->stream, args);
+    SHIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
+    return RH_OK;
+#else
     static const bool e4 = std::getenv("RH_SAS_E4") != nullptr;
     if (!e4 && nages > 256 && nages <= 4096) {
         if (nages <= 512) launch_sas8<1>(ctx, args);
@@ -986,6 +1002,7 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     SHIPCHK(ctx, hipGetLastError());
     if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     return RH_OK;
+#endif
 }
 
 int rh_sas_step(rh_sas_ctx *ctx, int64_t day) { return rh_sas_stages(ctx, day, RH_SAS_ALL); }
