@@ -626,14 +626,17 @@ RH_DEV void rt_infiltration(Col &c, const Consts &K, const StepCtx &X) {
     rt_inf_finish(c, K, X);
 }
 // ... with settings.enable_routing_1D: calc_surface_runoff is skipped (:2189-2190)
+RH_DEV void rt_inf_finish_routed(Col &c, const Consts &K, const StepCtx &X) {
+    const double mk = (double)c.maskCatch;
+    h_inf_rz_hof_sof(c, mk);
+    if (X.cond4) h_event_end(c, mk);
+}
 RH_DEV void rt_infiltration_routed(Col &c, const Consts &K, const StepCtx &X) {
     rt_inf_events(c, K, X);
     rt_inf_matrix(c, K, X);
     rt_inf_macropores(c, K, X);
     rt_inf_cracks(c, K, X);
-    const double mk = (double)c.maskCatch;
-    h_inf_rz_hof_sof(c, mk);
-    if (X.cond4) h_event_end(c, mk);
+    rt_inf_finish_routed(c, K, X);
 }
 
 // ---------------------------------------------------------------------------------------------

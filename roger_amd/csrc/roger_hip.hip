@@ -1286,10 +1286,45 @@ RH_CELL_KERNEL(k_route_subsurface_in, rt_route_subsurface_in, rt_route_subsurfac
 RH_CELL_KERNEL(k_num_error_routed, rt_num_error_routed, if (rt_num_error_routed(c, K)) atomicOr(&D->words[2], 1ull))
 // the step core in three passes, one kernel each (the infiltration's branch conditions come from the adaptive time stepping's
 // predicate word, as in k_step_core: global over the ranks)
-RH_CELL_KERNEL(k_routed_a, rt_routed_a, rt_routed_a(c, K, X, (double)D->S.dt_secs))
-RH_CELL_KERNEL(k_routed_b, rt_routed_b, rt_routed_b(c, K, X))
-RH_CELL_KERNEL(k_routed_c, rt_routed_c, if (rt_routed_c(c, K, X)) atomicOr(&D->words[2], 1ull))
-RH_CELL_KERNEL(k_routed_c_after, rt_routed_c_after, if (rt_routed_c_after(c, K, X)) atomicOr(&D->words[2], 1ull))
+// ... staged like the fused step (tools/gen_sets.py PLAIN_SEQUENCES): every plane is loaded right before the first stage that mentions it
+// and stored right after the last one that assigns it (short live ranges instead of all loads up front)
+#define RH_PSTAGE(seq, rt, call) RH_SEQ_##seq##_LOAD_##rt(LD) call; RH_SEQ_##seq##_STORE_##rt(ST)
+#define RH_PASS_KERNEL(kname, body)                                                                        \
+    __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void kname(Arena a, DevState *D) {               \
+        const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;                                    \
+        if (i >= a.n) return;                                                                              \
+        const Consts K = D->K;                                                                             \
+        const StepCtx X = D->X;                                                                            \
+        Col c;                                                                                             \
+        bool bad = false;                                                                                  \
+        body                                                                                               \
+        if (bad) atomicOr(&D->words[2], 1ull);                                                             \
+    }
+RH_PASS_KERNEL(k_routed_a,
+               RH_PSTAGE(routed_a, rt_interception, rt_interception(c, K))
+               RH_PSTAGE(routed_a, rt_evapotranspiration, rt_evapotranspiration(c, K))
+               RH_PSTAGE(routed_a, rt_snow, rt_snow(c, K, X))
+               RH_PSTAGE(routed_a, rt_inf_events, rt_inf_events(c, K, X))
+               RH_PSTAGE(routed_a, rt_inf_matrix, rt_inf_matrix(c, K, X))
+               RH_PSTAGE(routed_a, rt_inf_macropores, rt_inf_macropores(c, K, X))
+               RH_PSTAGE(routed_a, rt_inf_cracks, rt_inf_cracks(c, K, X))
+               RH_PSTAGE(routed_a, rt_inf_finish_routed, rt_inf_finish_routed(c, K, X))
+               RH_PSTAGE(routed_a, rt_route_surface_out, rt_route_surface_out(c, K, X, (double)D->S.dt_secs)))
+RH_PASS_KERNEL(k_routed_b,
+               RH_PSTAGE(routed_b, rt_route_surface_in, rt_route_surface_in(c))
+               RH_PSTAGE(routed_b, rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X))
+               RH_PSTAGE(routed_b, rt_route_subsurface_out, rt_route_subsurface_out(c)))
+RH_PASS_KERNEL(k_routed_c,
+               RH_PSTAGE(routed_c, rt_route_subsurface_in, rt_route_subsurface_in(c))
+               RH_PSTAGE(routed_c, rt_capillary_rise, rt_capillary_rise(c, X))
+               RH_PSTAGE(routed_c, rt_storage, rt_storage(c, X))
+               RH_PSTAGE(routed_c, rt_num_error_routed, bad = rt_num_error_routed(c, K)))
+RH_PASS_KERNEL(k_routed_c_after,
+               RH_PSTAGE(routed_c_after, rt_route_subsurface_in, rt_route_subsurface_in(c))
+               RH_PSTAGE(routed_c_after, rt_capillary_rise, rt_capillary_rise(c, X))
+               RH_PSTAGE(routed_c_after, rt_storage, rt_storage(c, X))
+               RH_PSTAGE(routed_c_after, rt_num_error_routed, bad = rt_num_error_routed(c, K))
+               RH_PSTAGE(routed_c_after, rt_after_timestep_oned, rt_after_timestep_oned(c)))
 // set_parameters' month-change test was evaluated on the device by the set_forcing hook (D->monthly)
 __global__ __launch_bounds__(RH_BLOCK) void k_params_surface_if_monthly(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;

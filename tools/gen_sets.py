@@ -147,6 +147,17 @@ SEQUENCES = {
         "rt_subsurface_runoff_lateral", "rt_capillary_rise", "rt_storage", "rt_num_error_lateral",
         "rt_after_timestep_oned"],
 }
+# The three passes of the routed step (settings.enable_routing_1D, roger_hip.hip k_routed_a / _b / _c): staged like the fused step -- a
+# plane is loaded right before the first stage that mentions it and stored right after the last stage that assigns it -- without the
+# rotation and summary machinery of the fused kernel.
+PLAIN_SEQUENCES = {
+    "routed_a": ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_inf_events", "rt_inf_matrix", "rt_inf_macropores",
+                 "rt_inf_cracks", "rt_inf_finish_routed", "rt_route_surface_out"],
+    "routed_b": ["rt_route_surface_in", "rt_subsurface_runoff_lateral", "rt_route_subsurface_out"],
+    "routed_c": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed"],
+    "routed_c_after": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed", "rt_after_timestep_oned"],
+}
+PLAIN_CHECK = {"routed_a": "rt_routed_a", "routed_b": "rt_routed_b", "routed_c": "rt_routed_c", "routed_c_after": "rt_routed_c_after"}
 # stages before which long-lived, momentarily unused planes are evicted from registers (see main())
 EVICT_BEFORE = set(filter(None, os.environ.get("RH_EVICT", "").split(",")))
 # each sequence must cover exactly what the corresponding single-function routine does
@@ -257,6 +268,22 @@ def main():
         ref_m, ref_w = sets[SEQUENCE_CHECK[seq]]
         if all_m != ref_m or all_w != ref_w:
             sys.exit(f"sequence {seq} does not match {SEQUENCE_CHECK[seq]}")
+        lines.append("")
+    for seq, stages in PLAIN_SEQUENCES.items():
+        lines.append(f"// sequence {seq}: " + " -> ".join(stages))
+        resident, all_m, all_w = set(), set(), set()
+        for i, rt in enumerate(stages):
+            mention, write = sets[rt]
+            later_w = set().union(*[sets[r][1] for r in stages[i + 1:]]) if i + 1 < len(stages) else set()
+            ld, st = mention - resident, write - later_w
+            resident |= mention
+            all_m |= mention
+            all_w |= write
+            lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in sorted(ld, key=order.get)))
+            lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in sorted(st, key=order.get)))
+        ref_m, ref_w = sets[PLAIN_CHECK[seq]]
+        if all_m != ref_m or all_w != ref_w:
+            sys.exit(f"sequence {seq} does not match {PLAIN_CHECK[seq]}")
         lines.append("")
     # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x
     lines.append("// tau -> taum1 rotation of after_timestep (h_rotate): " + str(len(pairs)) + " pairs")
