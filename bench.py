@@ -268,6 +268,102 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
     ctx.close()
 
 
+def bench_routed(args, torch, dist, rank, local_rank, world, device):
+    """The oneD benchmark's columns with settings.enable_routing_1D (surface and subsurface runoff routed to the D8 neighbour, every cell
+    draining towards +y): the routed step, three per-column passes around the two gathers (rh_run_steps on a routing context); several
+    ranks exchange the predicate words and the edge columns over RCCL from C."""
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.svat import create_svat, hetero_params
+
+    nx, ny = args.size
+    n_local = nx * ny
+    params = dict(hetero_params(n_local, seed=42 + rank)) if args.params == "hetero" else {}
+    for k, v in dict(z_soil=1000.0, lmpv=600.0, slope=0.05, slope_per=5, dmph=50.0, flow_dir_topo=4, k_st=15.0).items():
+        params.setdefault(k, v)
+    ctx = create_svat(nx, ny, params=params, device=local_rank, lateral=True, enable_routing_1D=1, dx=5.0, dy=5.0)
+    total_steps = args.steps + args.warmup
+    ctx.set_forcing_series(combo_forcing(ndays=max(30, total_steps + 5)))
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    run, stepping = ctx.run_steps, "rh_run_steps (routed: rh_step_routed per step)"
+    if world > 1:
+        ctx.comm_init_torch()
+        run, stepping = ctx.run_steps_dist, "rh_run_steps_dist (routed; predicate words and edge columns over RCCL from C)"
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(args.warmup)
+    s0 = ctx.get_scalars()
+    ctx.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.timing_summary()
+    ctx.enable_timing(False)
+    s1 = ctx.get_scalars()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if s1.itt - s0.itt != args.steps:   # (the reference's water balance check fails on routed runs: sanity_ok is not asserted)
+        raise SystemExit(f"bench: step bookkeeping failed (itt {s0.itt}->{s1.itt})")
+    if rank == 0:
+        census = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))   # bytes per column from the ISA (tools/isa_census.py)
+        passes = {seq: (census[seq]["load_bytes"], census[seq]["store_bytes"]) for seq in ("routed_a", "routed_b", "routed_c_after")}
+        ld_b, st_b = passes["routed_a"]
+        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = (ld_b + st_b) * n_local / k_avg_s / 1e9
+        step_bytes = sum(sum(v) for v in passes.values())
+        out = {
+            "metric": "cell-timesteps/sec on SVAT_benchmark grid",
+            "value": world * n_local * args.steps / elapsed,
+            "unit": "cell-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"oneD_benchmark synthetic grid nx*ny={n_local} per GPU ({nx}x{ny}) with enable_routing_1D (every cell drains "
+                            f"towards +y, Strickler coefficient 15, dx = dy = 5 m), {args.params} benchmark parameters, combo forcing (seed 42), adaptive dt",
+                "cells_per_gpu": n_local,
+                "simulated_seconds": int(s1.time - s0.time),
+                "decomposition": f"({world},1) along x, " + ("two predicate all-reduces and two edge-column exchanges per step" if world > 1
+                                                              else "single GPU: no exchange"),
+                "stepping": stepping,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_routed_a (interception ... infiltration + the surface outflow: the longest of the step's three passes)",
+                "note": f"achieved = the bytes this pass loads + stores per column ({ld_b} + {st_b} B, roger_amd/csrc/rh_step_bytes.json from "
+                        "the ISA) / its average duration by HIP events; the whole routed step moves "
+                        f"{step_bytes} B per column in its three passes (fused oneD step: 2040 B), plus the gathers and the adaptive time stepping",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": (ld_b + st_b) * n_local,
+                "algorithmic_bytes_per_cell": {p: {"load": v[0], "store": v[1]} for p, v in passes.items()},
+                "whole_step": {"bytes_per_cell": step_bytes, "achieved": step_bytes * n_local / (elapsed / args.steps) / 1e9,
+                               "frac": step_bytes * n_local / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                "avg_kernel_ms": k_avg_s * 1e3,
+                "launches_timed": launches,
+            },
+        }
+        print(json.dumps(out))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +376,8 @@ def main():
                          "sas: SVATOXYGEN18_benchmark (configs[2]: offline oxygen-18 transport, one step = one day)")
     ap.add_argument("--ages", type=int, default=1000, help="sas: age classes (benchmark: 1000)")
     ap.add_argument("--substeps", type=int, default=6, help="sas: sas_solver_substeps (benchmark: 6)")
+    ap.add_argument("--routing", action="store_true",
+                    help="oned: settings.enable_routing_1D -- surface and subsurface runoff routed to the D8 neighbour (the routed step)")
     ap.add_argument("--sas-solver", choices=("deterministic", "Euler", "RK4"), default="deterministic",
                     help="sas: settings.sas_solver (benchmark: deterministic; Euler / RK4 = the explicit schemes, transport.py:2064-2414, 1139-2047)")
     ap.add_argument("--station-weights", action="store_true",
@@ -318,6 +416,14 @@ def main():
 
     if args.model == "sas":
         bench_sas(args, torch, dist, rank, local_rank, world, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    if args.routing:
+        if args.model != "oned":
+            raise SystemExit("--routing goes with --model oned (the routed subsurface runoff is the lateral flow)")
+        bench_routed(args, torch, dist, rank, local_rank, world, device)
         if world > 1:
             dist.destroy_process_group()
         return

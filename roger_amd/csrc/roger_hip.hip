@@ -2299,6 +2299,20 @@ int rh_subsurface_routing(rh_ctx *ctx) { return route_all(ctx, 1); }
         hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
     } while (0)
 
+// the next pair of timing events (rh_enable_timing): they ride on a kernel's own dispatch (hipExtLaunchKernelGGL)
+static int timing_pair(rh_ctx *ctx, hipEvent_t *ev0, hipEvent_t *ev1) {
+    if (ctx->ev_used + 2 > 2 * (size_t)RH_DT_LOG_CAP)
+        return fail(ctx, RH_ERR_STATE, "timing: more than 65536 timed steps since rh_enable_timing(1); read the timings and enable again");
+    while (ctx->events.size() < ctx->ev_used + 2) {
+        hipEvent_t ev;
+        HIPCHK(ctx, hipEventCreate(&ev));
+        ctx->events.push_back(ev);
+    }
+    *ev0 = ctx->events[ctx->ev_used];
+    *ev1 = ctx->events[ctx->ev_used + 1];
+    return RH_OK;
+}
+
 static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst64 = nullptr) {
     // Timing: the event pair rides on the kernel's own dispatch (hipExtLaunchKernelGGL: start / stop are taken from the
     // dispatch's completion signal) instead of two hipEventRecord packets around it, which cost 5 us per step at 10^6
@@ -2600,7 +2614,13 @@ static int routed_core(rh_ctx *ctx, bool with_after) {
     int rc;
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->words[2], 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->sanity_last, 0, sizeof(unsigned long long), ctx->stream));
-    LAUNCH_CELLS(ctx, k_routed_a);                    // interception ... infiltration, the surface outflow
+    {   // interception ... infiltration, the surface outflow: the longest of the three passes, the one rh_enable_timing times
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (ctx->timing && (rc = timing_pair(ctx, &ev0, &ev1))) return rc;
+        planes_touched(ctx);
+        hipExtLaunchKernelGGL(k_routed_a, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
+        if (ctx->timing) ctx->ev_used += 2;
+    }
     if (ctx->comm && ctx->comm_nranks > 1 && (rc = route_exchange(ctx, 0))) return rc;
     if ((rc = rh_route_gather_only(ctx, 0))) return rc;
     LAUNCH_CELLS(ctx, k_routed_b);                    // the surface inflow, the lateral subsurface runoff, its outflow

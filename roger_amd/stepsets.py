@@ -38,6 +38,16 @@ def step_plane_bytes(lateral=False, lazy=True, monthly=False):
     return sum(size[p] for p in ld), sum(size[p] for p in st)
 
 
+def pass_plane_bytes(seq):
+    """(bytes loaded, bytes stored) per column by one of the staged passes of the routed step: seq = "routed_a", "routed_b", "routed_c",
+    "routed_c_after" (tools/gen_sets.py PLAIN_SEQUENCES; roger_hip.hip k_routed_*)."""
+    txt, size = open(_SETS).read(), _plane_bytes()
+    ld, st = _planes(txt, seq, "LOAD"), _planes(txt, seq, "STORE")
+    if not ld:
+        raise KeyError(f"no sequence {seq} in rh_sets.inc")
+    return sum(size[p] for p in ld), sum(size[p] for p in st)
+
+
 def routine_union_bytes(lateral=False):
     """(bytes read, bytes written) per column by the union of the distinct variables the step's routines read / assign, X_m1
     levels included -- the method of SURVEY.md section 8(d) (2 779 B for the SVAT step from the reference's own read / write
@@ -54,3 +64,5 @@ if __name__ == "__main__":
         for lazy in (True, False):
             print("oneD" if lat else "SVAT", "lazy" if lazy else "eager", step_plane_bytes(lat, lazy), sum(step_plane_bytes(lat, lazy)))
         print("  routine union", routine_union_bytes(lat), sum(routine_union_bytes(lat)))
+    for seq in ("routed_a", "routed_b", "routed_c", "routed_c_after"):
+        print(seq, pass_plane_bytes(seq), sum(pass_plane_bytes(seq)))
