@@ -319,6 +319,7 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = (ld_b + st_b) * n_local / k_avg_s / 1e9
         step_bytes = sum(sum(v) for v in passes.values())
+        traffic, _ = measured_traffic("k_routed_a", n_local)
         out = {
             "metric": "cell-timesteps/sec on SVAT_benchmark grid",
             "value": world * n_local * args.steps / elapsed,
@@ -351,7 +352,7 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": (ld_b + st_b) * n_local,
                 "algorithmic_bytes_per_cell": {p: {"load": v[0], "store": v[1]} for p, v in passes.items()},
                 "whole_step": {"bytes_per_cell": step_bytes, "achieved": step_bytes * n_local / (elapsed / args.steps) / 1e9,

@@ -52,15 +52,23 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   bench svat_80x53 --size 80 53 --params hetero --steps 2000 --warmup 50 --no-cpu-baseline
   bench svat_80x53_station_weights --size 80 53 --params hetero --station-weights --steps 2000 --warmup 50 --no-cpu-baseline
   RH_BENCH_FORCE_DIST=1 bench svat_1e6_rccl_one_rank --steps 200 --warmup 10 --no-cpu-baseline
-  bench oned_1e6_routing --model oned --routing --steps 200 --warmup 10 --no-cpu-baseline
-  rm -rf $scratch/stats_routed
-  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_routed -- python3 bench.py --model oned --routing --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_routed.out 2> $scratch/stats_routed.err \
-    && cp "$(find $scratch/stats_routed -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_oned_1e6_routing.csv && echo "kernel stats routed ok"
   # the default bench command under rocprofv3 --kernel-trace --stats: the kernel's average duration there must agree with the HIP events
   rm -rf $scratch/stats_svat
   rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_svat -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_svat.out 2> $scratch/stats_svat.err \
     && last $scratch/stats_svat.out > $out/${tag}_bench_svat_1e6_under_rocprof.json \
     && cp "$(find $scratch/stats_svat -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_svat_1e6.csv && echo "kernel stats svat ok"
+fi
+if [ "$what" = all ] || [ "$what" = routing ]; then
+  # the routed step (settings.enable_routing_1D): traffic of its longest pass, the bench line, the per-kernel times of one step
+  export RH_PMC_MODEL=routed RH_PMC_SIZE=1000x1000
+  pmc_pair k_routed_a "k_routed_a" 1000000 1000000 python3 tools/pmc_workload.py
+  unset RH_PMC_MODEL RH_PMC_SIZE
+  cp $out/traffic.json profiles/
+  bench oned_1e6_routing --model oned --routing --steps 200 --warmup 10 --no-cpu-baseline
+  rm -rf $scratch/stats_routed
+  rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_routed -- python3 bench.py --model oned --routing --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_routed.out 2> $scratch/stats_routed.err \
+    && last $scratch/stats_routed.out > $out/${tag}_bench_oned_1e6_routing_under_rocprof.json \
+    && cp "$(find $scratch/stats_routed -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_oned_1e6_routing.csv && echo "kernel stats routed ok"
 fi
 if [ "$what" = all ] || [ "$what" = sas ]; then
   export RH_PMC_CALIB=1
