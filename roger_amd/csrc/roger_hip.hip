@@ -2769,7 +2769,11 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
             LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, 0, send, src);
             CHECK_LAUNCH(ctx);
         }
-        NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+        static const bool copy_only = std::getenv("RH_DIST_COPY_ONLY") != nullptr;   // timing experiment (one rank): the exchange as a plain copy
+        if (copy_only && ctx->comm_nranks == 1)
+            HIPCHK(ctx, hipMemcpyAsync(recv, send, 64 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
         LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv);
         CHECK_LAUNCH(ctx);
         int rc = launch_fused_kernel(ctx, -1, 0, send);   // the tail spreads the next step's summary word into `send`
