@@ -171,3 +171,120 @@ def test_fused_step_is_refused_and_lateral_flow_is_required(native):
     ctx.close()
     with pytest.raises(native.NativeError, match="enable_lateral_flow"):
         native.Context(3, 3, enable_routing_1D=1)
+
+
+def _tiled_case(native, oracle, g, names, nx, ny, rng, flow=None):
+    """A grid of nx x ny cells drawn from the golden hillslope's cells (every per-cell plane of a cell travels together), with new
+    routing parameters: an oracle state and a device context holding the same start state."""
+    import hip_util as H
+    from golden_util import configure_settings
+
+    src = np.asarray(g["state0"])
+    pick = rng.integers(0, src.shape[1], nx * ny)
+    snap = src[:, pick].copy()
+    if flow is None:
+        flow = rng.choice([0, 1, 2, 4, 8, 16, 32, 64, 128], nx * ny, p=[0.04] + [0.12] * 8)
+    snap[names.index("flow_dir_topo")] = flow
+    snap[names.index("outer_boundary")] = rng.random(nx * ny) < 0.03
+    snap[names.index("k_st")] = rng.uniform(8, 30, nx * ny)
+    dx, dy = (float(v) for v in g["routing_dx_dy"])
+    st = oracle.OracleState(nx * ny)
+    st.load_snapshot(snap, names)
+    st.load_scalars(g["scal0"])
+    st.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    configure_settings(st.settings, g)
+    st.settings.nx, st.settings.ny = nx, ny
+    ctx = native.Context(nx, ny, enable_lateral_flow=1, enable_routing_1D=1, dx=dx, dy=dy)
+    H.upload_snapshot(ctx, snap, names)
+    ctx.set_scalars(H.scalars_from_row(g["scal0"]))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    ctx.set_lut_mlms(g["lut_mlms"])
+    return st, ctx
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle_binding as ob
+
+    ob.lib()
+    return ob
+
+
+def test_random_flow_directions_over_many_tiles_against_oracle(native, oracle):
+    """70 x 45 cells (50 arena tiles, so the D8 gather reads across tiles), every flow direction and pits at random, outlets sprinkled
+    in: the routed step tracks the oracle on every plane -- free-running over the first 100 steps, then step by step from the oracle's
+    state (the oneD columns have no snap-to-zero of emptied stores: from step 123 on a residue of 3e-18 mm in a saturated root zone
+    decides a branch, as in the oneD goldens, and routing would carry such a tie downstream) -- and water does move between cells."""
+    import hip_util as H
+    from golden_util import compare_bulk
+
+    g, names, forcing = load_case(ROUTING_CASES[0])
+    nx, ny = 70, 45
+    st, ctx = _tiled_case(native, oracle, g, names, nx, ny, np.random.default_rng(8))
+    odrv, hdrv = oracle.ForcingDriver(forcing), H.HipForcingDriver(ctx, forcing)
+    moved = 0.0
+    for step in range(1, 161):
+        if step > 100:
+            H.upload_snapshot(ctx, st.snapshot(names), names)
+        pd, td, ed, monthly = odrv.before_step(st)
+        st.step(pd, td, ed, monthly)
+        assert hdrv.before_step() == monthly
+        ctx.step_routed(monthly)
+        if step <= 3 or step % 20 == 0 or step > 100:
+            np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row(), err_msg=f"step {step}")
+            compare_bulk(H.download_snapshot(ctx, names), st.snapshot(names), names, what=f"step {step}", frac_bulk=0.9999 if step > 100 else 0.999)
+            moved += float(ctx.download("q_sur_in").sum() + ctx.download("q_sub_in").sum())
+    assert moved > 1.0, "no water was routed: the test would not see the gather"
+    ctx.close()
+
+
+def test_full_size_routed_columns_equal_a_strip(native, oracle):
+    """10^6 cells all draining towards +y: every x-row of the grid is the same hillslope, so the state does not depend on x, and it
+    equals the oracle's run of one 1 x 1000 strip."""
+    import hip_util as H
+    from golden_util import ATOL, RTOL
+
+    g, names, forcing = load_case(ROUTING_CASES[0])
+    nx, ny = 1000, 1000
+    rng = np.random.default_rng(3)
+    strip_pick = rng.integers(0, np.asarray(g["state0"]).shape[1], ny)
+    src = np.asarray(g["state0"])[:, strip_pick].copy()
+    src[names.index("flow_dir_topo")] = 4
+    src[names.index("outer_boundary")] = 0
+    src[names.index("k_st")] = rng.uniform(8, 30, ny)
+    dx, dy = (float(v) for v in g["routing_dx_dy"])
+    from golden_util import configure_settings
+
+    st = oracle.OracleState(ny)
+    st.load_snapshot(src, names)
+    st.load_scalars(g["scal0"])
+    st.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    configure_settings(st.settings, g)
+    st.settings.nx, st.settings.ny = 1, ny
+    ctx = native.Context(nx, ny, enable_lateral_flow=1, enable_routing_1D=1, dx=dx, dy=dy)
+    for row, nm in zip(src, names):
+        if nm in ctx.index:
+            ctx.upload(nm, np.tile(row, nx))
+    ctx.set_scalars(H.scalars_from_row(g["scal0"]))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    ctx.set_lut_mlms(g["lut_mlms"])
+    odrv, hdrv = oracle.ForcingDriver(forcing), H.HipForcingDriver(ctx, forcing)
+    for step in range(60):
+        pd, td, ed, monthly = odrv.before_step(st)
+        st.step(pd, td, ed, monthly)
+        assert hdrv.before_step() == monthly
+        ctx.step_routed(monthly)
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row())
+    ref = st.snapshot(names)
+    routed = 0.0
+    for nm in ("S", "S_rz", "S_ss", "theta_rz", "theta_ss", "z0", "z_sat", "q_sur_out", "q_sur_in", "q_sub_out", "q_sub_in", "q_sub", "q_ss", "aet"):
+        got = ctx.download(nm).reshape(nx, ny)
+        assert np.array_equal(got.min(axis=0), got.max(axis=0), equal_nan=True), nm   # the same hillslope in every row
+        r = ref[names.index(nm)]
+        with np.errstate(invalid="ignore"):
+            bad = ~((np.abs(got[0] - r) <= ATOL + 1e-8 * np.abs(r)) | (np.isnan(got[0]) & np.isnan(r)))
+        assert bad.mean() <= 0.002, (nm, int(bad.sum()), got[0][bad][:3], r[bad][:3])
+        if nm in ("q_sur_in", "q_sub_in"):
+            routed += float(np.nansum(np.abs(r)))
+    assert routed > 0.1
+    ctx.close()
