@@ -284,10 +284,13 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
     total_steps = args.steps + args.warmup
     ctx.set_forcing_series(combo_forcing(ndays=max(30, total_steps + 5)))
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-    run, stepping = ctx.run_steps, "rh_run_steps (routed: rh_step_routed per step)"
+    by_routine = bool(os.environ.get("RH_ROUTED_BY_ROUTINE"))   # A/B: the routine-by-routine control part (17 launches per step)
+    first = "routed_a" if by_routine else "routed_a2"
+    run, stepping = ctx.run_steps, ("rh_run_steps (routed, rh_step_routed per step: 17 launches)" if by_routine else
+                                    "rh_run_steps (routed: control kernel on the posted summary bits, three passes, two gathers: 6 launches per step)")
     if world > 1:
         ctx.comm_init_torch()
-        run, stepping = ctx.run_steps_dist, "rh_run_steps_dist (routed; predicate words and edge columns over RCCL from C)"
+        run, stepping = ctx.run_steps_dist, "rh_run_steps_dist (routed; summary word and edge columns over RCCL from C)"
 
     def fence():
         torch.cuda.synchronize(device)
@@ -314,12 +317,12 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
         raise SystemExit(f"bench: step bookkeeping failed (itt {s0.itt}->{s1.itt})")
     if rank == 0:
         census = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))   # bytes per column from the ISA (tools/isa_census.py)
-        passes = {seq: (census[seq]["load_bytes"], census[seq]["store_bytes"]) for seq in ("routed_a", "routed_b", "routed_c_after")}
-        ld_b, st_b = passes["routed_a"]
+        passes = {seq: (census[seq]["load_bytes"], census[seq]["store_bytes"]) for seq in (first, "routed_b", "routed_c_after")}
+        ld_b, st_b = passes[first]
         k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = (ld_b + st_b) * n_local / k_avg_s / 1e9
         step_bytes = sum(sum(v) for v in passes.values())
-        traffic, _ = measured_traffic("k_routed_a", n_local)
+        traffic, _ = measured_traffic("k_" + first, n_local)
         out = {
             "metric": "cell-timesteps/sec on SVAT_benchmark grid",
             "value": world * n_local * args.steps / elapsed,
@@ -338,13 +341,13 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
                             f"towards +y, Strickler coefficient 15, dx = dy = 5 m), {args.params} benchmark parameters, combo forcing (seed 42), adaptive dt",
                 "cells_per_gpu": n_local,
                 "simulated_seconds": int(s1.time - s0.time),
-                "decomposition": f"({world},1) along x, " + ("two predicate all-reduces and two edge-column exchanges per step" if world > 1
+                "decomposition": f"({world},1) along x, " + ("one summary all-reduce and two edge-column exchanges per step" if world > 1
                                                               else "single GPU: no exchange"),
                 "stepping": stepping,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_routed_a (interception ... infiltration + the surface outflow: the longest of the step's three passes)",
+                "kernel": f"k_{first} (" + ("" if by_routine else "forcing selection, ") + "interception ... infiltration + the surface outflow: the longest of the step's three passes)",
                 "note": f"achieved = the bytes this pass loads + stores per column ({ld_b} + {st_b} B, roger_amd/csrc/rh_step_bytes.json from "
                         "the ISA) / its average duration by HIP events; the whole routed step moves "
                         f"{step_bytes} B per column in its three passes (fused oneD step: 2040 B), plus the gathers and the adaptive time stepping",

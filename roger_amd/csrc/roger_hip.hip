@@ -128,6 +128,8 @@ struct rh_ctx {
     double *mlms_buf;
     bool per_cell;
     bool summary_valid;   // the summary word (words[3]) describes the columns as they are in the arena now
+    bool routed_summary = false;     // routing: sumw holds the summary bits of the arena's state (posted by k_routed_a2)
+    bool routed_device_ok = true;    // RH_ROUTED_BY_ROUTINE: rh_run_steps takes rh_step_routed per step (A/B, tests)
     bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
     int pending_hooks;    // ... formed with / without the device-side hooks
     bool tail_ok;         // RH_NO_TAIL_CTRL unset
@@ -1325,6 +1327,51 @@ RH_PASS_KERNEL(k_routed_c_after,
                RH_PSTAGE(routed_c_after, rt_storage, rt_storage(c, X))
                RH_PSTAGE(routed_c_after, rt_num_error_routed, bad = rt_num_error_routed(c, K))
                RH_PSTAGE(routed_c_after, rt_after_timestep_oned, rt_after_timestep_oned(c)))
+// Device-driven stepping (rh_run_steps / rh_run_steps_dist on a routing context): the first pass with the step's forcing selection [and
+// the monthly surface parameters, D->monthly] in front, as the fused kernel has them, and the columns' summary bits for the NEXT step's
+// control kernel posted as soon as they are final (k_ctrl reads them from sumw: no predicate passes over the arena between two steps).
+#define RH_ROUTED_A2_TAIL(seq)                                                                                  \
+    RH_PSTAGE(seq, rt_interception, rt_interception(c, K))                                                      \
+    RH_PSTAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                          \
+    RH_PSTAGE(seq, rt_snow, rt_snow(c, K, X))                                                                   \
+    q = summary_bits_sw(q, c.swe, c.swe_top);                                                                   \
+    post_summary(D, q, dep);                                                                                    \
+    RH_PSTAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                       \
+    RH_PSTAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                       \
+    RH_PSTAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                               \
+    RH_PSTAGE(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                                       \
+    RH_PSTAGE(seq, rt_inf_finish_routed, rt_inf_finish_routed(c, K, X))                                         \
+    RH_PSTAGE(seq, rt_route_surface_out, rt_route_surface_out(c, K, X, (double)D->S.dt_secs))
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_a2(Arena a, DevState *D) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const Consts K = D->K;
+    const StepCtx X = D->X;
+    Col c;
+    unsigned long long q = 0;
+    unsigned dep = 1;
+    double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
+    if (D->per_cell && X.sel_w >= 0) {
+        pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
+        ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
+    }
+#ifdef RH_CENSUS   // tools/isa_census.py counts the pipeline a step runs unless the month changes
+    if (false) {
+#else
+    if (D->monthly != 0) {
+#endif
+        RH_PSTAGE(routed_a2_monthly, rt_select_prec, rt_select_prec(c, X))
+        RH_PSTAGE(routed_a2_monthly, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
+        q = summary_bits_pt(c.prec, c.ta, K);
+        RH_PSTAGE(routed_a2_monthly, rt_params_surface, rt_params_surface(c, D->L, X))
+        RH_ROUTED_A2_TAIL(routed_a2_monthly)
+    } else {
+        RH_PSTAGE(routed_a2, rt_select_prec, rt_select_prec(c, X))
+        RH_PSTAGE(routed_a2, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
+        q = summary_bits_pt(c.prec, c.ta, K);
+        RH_ROUTED_A2_TAIL(routed_a2)
+    }
+}
 // set_parameters' month-change test was evaluated on the device by the set_forcing hook (D->monthly)
 __global__ __launch_bounds__(RH_BLOCK) void k_params_surface_if_monthly(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -1558,6 +1605,7 @@ static void planes_touched(rh_ctx *ctx) {
     materialise_m1(ctx);
     ctx->rot_consistent = false;
     ctx->summary_valid = false;
+    ctx->routed_summary = false;
     ctx->pending_valid = false;
     ctx->exch_valid = false;
 }
@@ -1849,6 +1897,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->pending_valid = false;
     ctx->pending_hooks = 0;
     ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
+    ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
     ctx->grp_shift = 6;
     while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
     ctx->summary_valid = false;
@@ -2641,6 +2690,52 @@ static int routed_core(rh_ctx *ctx, bool with_after) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
+// One routed step of rh_run_steps / rh_run_steps_dist (forcing shared by all columns): control kernel on the summary word (all-reduced
+// between the ranks), three passes around the two gathers -- 6 launches instead of 17.
+static int routed_step_device(rh_ctx *ctx) {
+    int rc;
+    RcclApi *api = nullptr;
+    const bool ranks = ctx->comm && ctx->comm_nranks > 1;
+    if (ctx->comm) {
+        api = rccl_api();
+        if (!api->ok) return fail(ctx, RH_ERR_STATE, "routed step: " + api->why);
+    }
+    if (!ctx->routed_summary) {   // first step, or somebody else touched the planes: the summary bits from the arena
+        HIPCHK(ctx, hipMemsetAsync(ctx->dev->sumw, 0, sizeof(ctx->dev->sumw), ctx->stream));
+        LAUNCH_CELLS(ctx, k_summary);
+    }
+    if (ctx->comm) {   // (a one-rank communicator takes the same path: tests)
+        if (!ctx->exch_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->exch_buf, 128 * sizeof(int)));
+        int *send = ctx->exch_buf, *recv = ctx->exch_buf + 64;
+        LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, 0, send, RH_SRC_SUMW);
+        NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+        LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv);
+    } else
+        LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_SUMW, (const int *)nullptr);
+    planes_touched(ctx);
+    {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (ctx->timing && (rc = timing_pair(ctx, &ev0, &ev1))) return rc;
+        hipExtLaunchKernelGGL(k_routed_a2, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
+        if (ctx->timing) ctx->ev_used += 2;
+    }
+    if (ranks && (rc = route_exchange(ctx, 0))) return rc;
+    if ((rc = rh_route_gather_only(ctx, 0))) return rc;
+    LAUNCH_CELLS(ctx, k_routed_b);
+    if (ranks && (rc = route_exchange(ctx, 1))) return rc;
+    if ((rc = rh_route_gather_only(ctx, 1))) return rc;
+    // (the control kernel has advanced itt / time and rotated the scalars, scalars_update; the sanity word stays in words[2], where
+    // rh_get_scalars reads it)
+    if (ctx->diag_n) {   // the accumulators read the planes between the numerics and the rotation
+        LAUNCH_CELLS(ctx, k_routed_c);
+        hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+        LAUNCH_CELLS(ctx, k_after_timestep_oned);
+    } else
+        LAUNCH_CELLS(ctx, k_routed_c_after);
+    CHECK_LAUNCH(ctx);
+    ctx->routed_summary = true;   // k_routed_a2 left the summary bits of the state the step ends in
+    return RH_OK;
+}
 int rh_step_routed(rh_ctx *ctx, int monthly) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->cfg.enable_routing_1D) return fail(ctx, RH_ERR_STATE, "rh_step_routed: the context was created without enable_routing_1D");
@@ -2695,9 +2790,13 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     for (int64_t k = 0; k < nsteps; ++k) {
         int rc;
-        if (ctx->cfg.enable_routing_1D) {   // the hooks, then the step routine by routine (rh_step_routed)
-            launch_hooks(ctx);
-            rc = rh_step_routed(ctx, -1);
+        if (ctx->cfg.enable_routing_1D) {
+            if (!ctx->per_cell && ctx->routed_device_ok)
+                rc = routed_step_device(ctx);
+            else {   // the hooks, then the step routine by routine (rh_step_routed)
+                launch_hooks(ctx);
+                rc = rh_step_routed(ctx, -1);
+            }
         } else
             rc = step_fused_launches(ctx, -1, 1);
         if (rc) return rc;
@@ -2746,8 +2845,13 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
     if (ctx->cfg.enable_routing_1D) {   // the routed step exchanges its predicate words and edge columns itself
         for (int64_t k = 0; k < nsteps; ++k) {
-            launch_hooks(ctx);
-            int rc = rh_step_routed(ctx, -1);
+            int rc;
+            if (!ctx->per_cell && ctx->routed_device_ok)
+                rc = routed_step_device(ctx);
+            else {
+                launch_hooks(ctx);
+                rc = rh_step_routed(ctx, -1);
+            }
             if (rc) return rc;
         }
         return RH_OK;

@@ -162,6 +162,36 @@ def test_routed_steps_with_device_hooks_and_one_rank_communicator(native):
     assert np.array_equal(out[0], out[1], equal_nan=True)
 
 
+def test_device_driven_routed_steps_equal_the_routine_by_routine_step(native, monkeypatch):
+    """rh_run_steps on a routing context forms the control part in one kernel from the summary bits the first pass posted and selects
+    the step's forcing inside that pass (6 launches per step); RH_ROUTED_BY_ROUTINE=1 keeps rh_step_routed per step (predicate passes
+    over the arena, 17 launches): the same bits, also when the run is split and the host touches a plane in between."""
+    import hip_util as H
+
+    g, names, forcing = load_case(ROUTING_CASES[0])
+    nsteps = int(g["nsteps"])
+    out = {}
+    for mode in ("device", "routine", "split"):
+        if mode == "routine":
+            monkeypatch.setenv("RH_ROUTED_BY_ROUTINE", "1")
+        else:
+            monkeypatch.delenv("RH_ROUTED_BY_ROUTINE", raising=False)
+        ctx = routed_ctx(native, g, names)
+        ctx.set_forcing_series(forcing)
+        if mode == "split":
+            ctx.run_steps(37)
+            ctx.upload("z0", ctx.download("z0"))   # the host touches a plane: the summary bits are rebuilt from the arena
+            ctx.run_steps(1)
+            ctx.run_steps(nsteps - 38)
+        else:
+            ctx.run_steps(nsteps)
+        out[mode] = (H.scalars_to_row(ctx.get_scalars()), H.download_snapshot(ctx, names))
+        ctx.close()
+    for mode in ("routine", "split"):
+        np.testing.assert_array_equal(out["device"][0], out[mode][0])
+        assert np.array_equal(out["device"][1], out[mode][1], equal_nan=True), mode
+
+
 def test_fused_step_is_refused_and_lateral_flow_is_required(native):
     g, names, forcing = load_case(ROUTING_CASES[0])
     ctx = routed_ctx(native, g, names)

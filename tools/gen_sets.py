@@ -153,6 +153,12 @@ SEQUENCES = {
 PLAIN_SEQUENCES = {
     "routed_a": ["rt_interception", "rt_evapotranspiration", "rt_snow", "rt_inf_events", "rt_inf_matrix", "rt_inf_macropores",
                  "rt_inf_cracks", "rt_inf_finish_routed", "rt_route_surface_out"],
+    # device-driven stepping (rh_run_steps): the selection of the step's forcing [and the monthly surface parameters] in front
+    "routed_a2": ["rt_select_prec", "rt_select_pet", "rt_interception", "rt_evapotranspiration", "rt_snow", "rt_inf_events", "rt_inf_matrix",
+                  "rt_inf_macropores", "rt_inf_cracks", "rt_inf_finish_routed", "rt_route_surface_out"],
+    "routed_a2_monthly": ["rt_select_prec", "rt_select_pet", "rt_params_surface", "rt_interception", "rt_evapotranspiration", "rt_snow",
+                          "rt_inf_events", "rt_inf_matrix", "rt_inf_macropores", "rt_inf_cracks", "rt_inf_finish_routed",
+                          "rt_route_surface_out"],
     "routed_b": ["rt_route_surface_in", "rt_subsurface_runoff_lateral", "rt_route_subsurface_out"],
     "routed_c": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed"],
     "routed_c_after": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed", "rt_after_timestep_oned"],
@@ -281,9 +287,10 @@ def main():
             all_w |= write
             lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in sorted(ld, key=order.get)))
             lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in sorted(st, key=order.get)))
-        ref_m, ref_w = sets[PLAIN_CHECK[seq]]
-        if all_m != ref_m or all_w != ref_w:
-            sys.exit(f"sequence {seq} does not match {PLAIN_CHECK[seq]}")
+        if seq in PLAIN_CHECK:
+            ref_m, ref_w = sets[PLAIN_CHECK[seq]]
+            if all_m != ref_m or all_w != ref_w:
+                sys.exit(f"sequence {seq} does not match {PLAIN_CHECK[seq]}")
         lines.append("")
     # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x
     lines.append("// tau -> taum1 rotation of after_timestep (h_rotate): " + str(len(pairs)) + " pairs")

@@ -61,7 +61,7 @@ fi
 if [ "$what" = all ] || [ "$what" = routing ]; then
   # the routed step (settings.enable_routing_1D): traffic of its longest pass, the bench line, the per-kernel times of one step
   export RH_PMC_MODEL=routed RH_PMC_SIZE=1000x1000
-  pmc_pair k_routed_a "k_routed_a" 1000000 1000000 python3 tools/pmc_workload.py
+  pmc_pair k_routed_a2 "k_routed_a2" 1000000 1000000 python3 tools/pmc_workload.py
   unset RH_PMC_MODEL RH_PMC_SIZE
   cp $out/traffic.json profiles/
   bench oned_1e6_routing --model oned --routing --steps 200 --warmup 10 --no-cpu-baseline
