@@ -63,6 +63,21 @@ def measured_traffic(key, n_cells):
     return rec["hbm_bytes_per_launch"], rec
 
 
+def prewarm(torch, device, ms):
+    """A device-to-device copy of 256 MB repeated for `ms` milliseconds: untimed work that brings the device to the clock state it
+    holds under load (not steps of the model; before the timed region)."""
+    if ms <= 0:
+        return
+    a = torch.empty(1 << 25, dtype=torch.float64, device=device)
+    b = torch.empty_like(a)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            b.copy_(a)
+        torch.cuda.synchronize(device)
+    del a, b
+
+
 def device_clocks():
     """Clock levels rocm-smi reports (a child process; nothing here touches the GPU): the fused kernel's speed follows the
     memory-side clocks of the moment."""
@@ -390,6 +405,9 @@ def main():
     ap.add_argument("--placement-probes", type=int, default=4,
                     help="svat / oned: candidate arenas rh_create times a streaming copy on before keeping the fastest (DESIGN.md section 5; "
                          "the library's default is 1 = take the first)")
+    ap.add_argument("--prewarm-ms", type=float, default=0.0,
+                    help="keep the device busy with a plain copy for this long right before the timed region (untimed; the memory-side "
+                         "clocks fall back while the host reads rocm-smi between warm-up and timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
@@ -478,6 +496,7 @@ def main():
     run(args.warmup)
     s0 = ctx.get_scalars()
     clocks0 = device_clocks() if rank == 0 else None
+    prewarm(torch, device, args.prewarm_ms)
     ctx.enable_timing(True)
     fence()
     t0 = time.perf_counter()

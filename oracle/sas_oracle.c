@@ -358,6 +358,7 @@ static void ageing_anion(double *sa, double *msa, int64_t A) {
     msa[A - 1] += msa_last;
 }
 
+static void storages_anion(const oc_sas *P, int64_t i, double *work);
 /* one day of svat_transport_model_deterministic for one column, bromide */
 static void step_anion(const oc_sas *P, int64_t i, double *work) {
     const int64_t A = P->ages;
@@ -391,7 +392,14 @@ static void step_anion(const oc_sas *P, int64_t i, double *work) {
     }
     outflux_anion(P, i, 3, P->q_ss[i], P->alpha_q[i], 0, sa_ss, msa_ss, NULL, NULL, mk, work);
     outflux_anion(P, i, 4, P->cpr_rz[i], P->alpha_q[i], 0, sa_ss, msa_ss, sa_rz, msa_rz, mk, work);
-    /* storages: root_zone.py:221-258, subsoil.py:186-223, soil.py:1094-1142 */
+    storages_anion(P, i, work);
+}
+
+/* storages of the anion kernels: root_zone.py:221-258, subsoil.py:186-223, soil.py:1094-1142 */
+static void storages_anion(const oc_sas *P, int64_t i, double *work) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
     for (int64_t k = 0; k < A; ++k) sa_rz[k] = (sa_rz[k] < 1e-8 ? 0 : sa_rz[k]);
     for (int64_t k = 0; k < A; ++k) msa_rz[k] = (sa_rz[k] <= 0 ? 0 : msa_rz[k]);
     P->M_rz[i] = np_nansum(msa_rz, A, work) * mk;
@@ -631,6 +639,71 @@ static void euler_inflow(const oc_sas *P, int64_t i, double h) {
         msa_ss[k] = (sa_ss[k] <= 0) ? 0 : msa_ss[k];
     }
 }
+/* ... of the anion kernels, transport.py:2150-2170 (Euler), 1225-1245 (RK4): water as above; the solute arrays of the three
+ * infiltration fluxes hold C_in in age class 0 whatever infiltrates (:2100-2112), and each adds it times h */
+static void euler_inflow_anion(const oc_sas *P, int64_t i, double h) {
+    const double mk = (double)P->maskCatch[i];
+    double *sa_rz = P->sa_rz + i * P->ages, *msa_rz = P->msa_rz + i * P->ages, *sa_ss = P->sa_ss + i * P->ages, *msa_ss = P->msa_ss + i * P->ages;
+    const double im = P->inf_mat_rz[i], ip = P->inf_pf_rz[i], is = P->inf_pf_ss[i];
+    const double t0 = (im > 0 ? 1 : 0) * mk, t1 = (ip > 0 ? 1 : 0) * mk, t2 = (is > 0 ? 1 : 0) * mk;
+    const double m = P->C_in[i] * mk, mm = isnan(m) ? 0 : m;
+    sa_rz[0] += (im * t0 + ip * t1) * h;
+    sa_ss[0] += (is * t2) * h;
+    msa_rz[0] += mm * h + mm * h;
+    msa_ss[0] += mm * h;
+}
+/* calc_mtt, anion branch (:583-596): msa / sa * alpha * tt * flux clipped to [0, msa]; flux_h = flux * h */
+static void anion_mtt(double *mtt, const double *sa, const double *msa, const double *tt, double alpha, double flux_h, int64_t A) {
+    for (int64_t k = 0; k < A; ++k) {
+        double m = (sa[k] > 0 ? msa[k] / sa[k] : 0) * alpha * tt[k] * flux_h;
+        m = (m <= 0 ? 0 : m);
+        mtt[k] = (m > msa[k] ? msa[k] : m);
+    }
+}
+/* the solute leaving with the four fluxes that carry it (the soil evaporation's is never assigned for the anions, :2196-2200) from the
+ * state as it stands and the distributions in P->tt */
+static void anion_mtt_fluxes(const oc_sas *P, int64_t i, double h) {
+    const int64_t A = P->ages;
+    const double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    anion_mtt(P->mtt[1] + i * A, sa_rz, msa_rz, P->tt[1] + i * A, P->alpha_transp[i], P->transp[i] * h, A);
+    anion_mtt(P->mtt[2] + i * A, sa_rz, msa_rz, P->tt[2] + i * A, P->alpha_q[i], P->q_rz[i] * h, A);
+    anion_mtt(P->mtt[3] + i * A, sa_ss, msa_ss, P->tt[3] + i * A, P->alpha_q[i], P->q_ss[i] * h, A);
+    anion_mtt(P->mtt[4] + i * A, sa_ss, msa_ss, P->tt[4] + i * A, P->alpha_q[i], P->cpr_rz[i] * h, A);
+}
+/* the update of a sub-step, anion kernels: transport.py:2308-2332 (Euler) and 1941-1966 (RK4, whose root zone -- as written -- GAINS the
+ * soil evaporation and does not receive the capillary rise) */
+static void explicit_update_anion(const oc_sas *P, int64_t i, double h, int rk4) {
+    const int64_t A = P->ages;
+    double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
+    const double ev = P->evap_soil[i], tr = P->transp[i], qrz = P->q_rz[i], qss = P->q_ss[i], cpr = P->cpr_rz[i];
+    const double *tt_ev = P->tt[0] + i * A, *tt_tr = P->tt[1] + i * A, *tt_qrz = P->tt[2] + i * A, *tt_qss = P->tt[3] + i * A, *tt_cpr = P->tt[4] + i * A;
+    const double *mtt_tr = P->mtt[1] + i * A, *mtt_qrz = P->mtt[2] + i * A, *mtt_qss = P->mtt[3] + i * A, *mtt_cpr = P->mtt[4] + i * A;
+#define NZ(x) (isnan(x) ? 0 : (x))
+    for (int64_t k = 0; k < A; ++k) {
+        double dsa_rz = rk4 ? (ev * tt_ev[k] - tr * tt_tr[k] - qrz * tt_qrz[k]) * h : (cpr * tt_cpr[k] - ev * tt_ev[k] - tr * tt_tr[k] - qrz * tt_qrz[k]) * h;
+        dsa_rz = (sa_rz[k] + dsa_rz < 0) ? -sa_rz[k] : dsa_rz;
+        double dsa_ss = (qrz * tt_qrz[k] - cpr * tt_cpr[k] - qss * tt_qss[k]) * h;
+        dsa_ss = (sa_ss[k] + dsa_ss < 0) ? -sa_ss[k] : dsa_ss;
+        double dmsa_rz = NZ(mtt_cpr[k]) - NZ(mtt_tr[k]) - NZ(mtt_qrz[k]);
+        double dmsa_ss = NZ(mtt_qrz[k]) - NZ(mtt_cpr[k]) - NZ(mtt_qss[k]);
+        dmsa_rz = (msa_rz[k] + dmsa_rz < 0) ? 0 : dmsa_rz;
+        dmsa_ss = (msa_ss[k] + dmsa_ss < 0) ? 0 : dmsa_ss;
+        sa_rz[k] += dsa_rz;
+        sa_ss[k] += dsa_ss;
+        msa_rz[k] += dmsa_rz;
+        msa_ss[k] += dmsa_ss;
+    }
+#undef NZ
+}
+/* concentrations of a sub-step, anion kernels: transport.py:2379-2407, 2012-2040 */
+static void explicit_concentrations_anion(const oc_sas *P, int64_t i, double h) {
+    const int64_t A = P->ages;
+    const double mk = (double)P->maskCatch[i];
+    const double inf[3] = {P->inf_mat_rz[i], P->inf_pf_rz[i], P->inf_pf_ss[i]};
+    const double flux[5] = {P->evap_soil[i], P->transp[i], P->q_rz[i], P->q_ss[i], P->cpr_rz[i]};
+    for (int w = 0; w < 3; ++w) P->C_inf[w][i] = (inf[w] * h > 0 ? P->C_in[i] : 0) * mk;
+    for (int f = 1; f < 5; ++f) P->C[f][i] = (flux[f] > 0 ? np_sum(P->mtt[f] + i * A, A) / (flux[f] * h) : 0) * mk;
+}
 /* order of the five outgoing fluxes in the arrays: evap_soil, transp, q_rz (root zone), q_ss, cpr_rz (subsoil) */
 static const int EULER_SRC_SS[5] = {0, 0, 0, 1, 1};
 /* the distributions of the five fluxes from the state as it stands; SA_rz / SA_ss: NA doubles each, work: 3 * NA */
@@ -649,8 +722,10 @@ static void euler_distributions(const oc_sas *P, int64_t i, double h, double *SA
         double *tt = P->tt[f] + i * A, *mtt = P->mtt[f] + i * A, *TT = P->TT[f] + i * NA;
         const double *msa = EULER_SRC_SS[f] ? msa_ss : msa_rz;
         euler_tt(P, TT, tt, EULER_SRC_SS[f] ? SA_ss : SA_rz, P->sas_params[f] + i * 8, flux[f] * h, mk, work);
-        for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0;   /* calc_mtt :565-596, isotopes */
+        if (P->tracer == 0)
+            for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0;   /* calc_mtt :565-596, isotopes */
     }
+    if (P->tracer != 0) anion_mtt_fluxes(P, i, h);
 }
 /* the StorAge update of a sub-step from the distributions in P->tt / P->mtt, transport.py:2266-2310 */
 static void euler_update(const oc_sas *P, int64_t i, double h) {
@@ -693,6 +768,13 @@ static void euler_concentrations(const oc_sas *P, int64_t i, double *work) {
 /* svat_transport_model_euler, transport.py:2064-2414 (oxygen-18 / deuterium): one sub-step of length h */
 static void euler_substep(const oc_sas *P, int64_t i, double h, double *work) {
     const int64_t NA = P->ages + 1;
+    if (P->tracer != 0) {
+        euler_inflow_anion(P, i, h);
+        euler_distributions(P, i, h, work, work + NA, work + 2 * NA);
+        explicit_update_anion(P, i, h, 0);
+        explicit_concentrations_anion(P, i, h);
+        return;
+    }
     euler_inflow(P, i, h);
     euler_distributions(P, i, h, work, work + NA, work + 2 * NA);
     euler_update(P, i, h);
@@ -715,7 +797,9 @@ static void rk4_substep(const oc_sas *P, int64_t i, double h, double *work) {
     const double flux[5] = {P->evap_soil[i], P->transp[i], P->q_rz[i], P->q_ss[i], P->cpr_rz[i]};
     double *tw = work, *SA_rz = work + 3 * NA, *SA_ss = SA_rz + NA, *s_rz = SA_ss + NA, *s_ss = s_rz + A, *tts = s_ss + A;
     double *TT = P->TT[0] + i * NA; /* scratch for the stages' cumulative distributions (overwritten at the end) */
-    euler_inflow(P, i, h);
+    const int anion = P->tracer != 0;
+    if (anion) euler_inflow_anion(P, i, h);
+    else euler_inflow(P, i, h);
     calc_SA(SA_rz, sa_rz, A);
     calc_SA(SA_ss, sa_ss, A);
     for (int64_t k = 0; k < NA; ++k) {
@@ -738,11 +822,14 @@ static void rk4_substep(const oc_sas *P, int64_t i, double h, double *work) {
             for (int64_t k = 0; k < A; ++k) acc[k] = (stage == 0) ? t[k] : acc[k] + w * t[k];
         }
         if (stage == 3) break;
+        /* the anion kernels move the trial StorAge by h / 2 after the first AND the second evaluation and not at all after the third
+         * (:1432-1446, 1581-1595, 1729-1751: only the trial solute, which never reaches the result, changes there) */
+        if (anion && stage == 2) continue;
         const double *t_ev = tts, *t_tr = tts + A, *t_qrz = tts + 2 * A, *t_qss = tts + 3 * A, *t_cpr = tts + 4 * A;
         for (int64_t k = 0; k < A; ++k) {
             double d_rz = (flux[4] * t_cpr[k] - flux[0] * t_ev[k] - flux[1] * t_tr[k] - flux[2] * t_qrz[k]) * h;
             double d_ss = (flux[2] * t_qrz[k] - flux[4] * t_cpr[k] - flux[3] * t_qss[k]) * h;
-            if (stage > 0) {
+            if (stage > 0 || anion) {
                 d_rz = d_rz / 2;
                 d_ss = d_ss / 2;
             }
@@ -769,7 +856,14 @@ static void rk4_substep(const oc_sas *P, int64_t i, double h, double *work) {
             acc = (k == 0) ? tt[0] : acc + tt[k];
             TTf[k + 1] = acc;
         }
-        for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0; /* calc_mtt :565-596, isotopes */
+        if (!anion)
+            for (int64_t k = 0; k < A; ++k) mtt[k] = (tt[k] > 0) ? msa[k] : 0; /* calc_mtt :565-596, isotopes */
+    }
+    if (anion) {
+        anion_mtt_fluxes(P, i, h);   /* :1881-1896: on the state after the infiltration */
+        explicit_update_anion(P, i, h, 1);
+        explicit_concentrations_anion(P, i, h);
+        return;
     }
     euler_update(P, i, h);
     euler_concentrations(P, i, work);
@@ -787,7 +881,7 @@ void oc_sas_step(const oc_sas *P) {
         const double mk = (double)P->maskCatch[i];
         double *sa_rz = P->sa_rz + i * A, *msa_rz = P->msa_rz + i * A, *sa_ss = P->sa_ss + i * A, *msa_ss = P->msa_ss + i * A;
         double *sa_s = P->sa_s + i * A;
-        if (P->tracer != 0) {
+        if (P->tracer != 0 && P->solver == 0) {
             step_anion(P, i, work);
             goto statistics;
         }
@@ -797,7 +891,8 @@ void oc_sas_step(const oc_sas *P) {
             for (int64_t it = 0; it < P->substeps; ++it) {
                 if (P->solver == 1) euler_substep(P, i, h, work);
                 else rk4_substep(P, i, h, work);
-                storages_iso(P, i, work);
+                if (P->tracer != 0) storages_anion(P, i, work);
+                else storages_iso(P, i, work);
             }
             goto statistics;
         }

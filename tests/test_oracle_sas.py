@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from sas_binding import FIRST_TIE, ORACLE_TIES, check_day_loose, FLUXES, INFS, SAS_CASES, SOLVER_CASES, STAT_Q, STAT_TARGETS, GOLDEN, SasGolden, compare_sas
+from sas_binding import ANION_SOLVER_CASES, FIRST_TIE, ORACLE_TIES, check_day_loose, FLUXES, INFS, SAS_CASES, SOLVER_CASES, STAT_Q, STAT_TARGETS, GOLDEN, SasGolden, compare_sas
 
 CASES = [c for c in SAS_CASES + SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))]
 
@@ -158,6 +158,35 @@ def test_bromide_trajectory():
     # (not exact: an age class emptied of water drops what solute it still held, `msa = where(sa <= 0, 0, msa)`)
     np.testing.assert_allclose(st.out["M_s"], m_in - m_out, rtol=1e-4, atol=1e-9)
     assert (st.out["M_s"] <= (m_in - m_out) * (1 + 1e-12) + 1e-9).all()
+
+
+def explicit_anion_names(stats):
+    """What svat_transport_model_euler / _rk4 and the storages assign for the anions: no solute masses of the fluxes (M_*), nothing for
+    the soil evaporation's solute."""
+    return [k for k in bromide_names(stats) if not (k.startswith("M_") and k not in ("M_rz", "M_ss", "M_s"))]
+
+
+@pytest.mark.parametrize("case", ANION_SOLVER_CASES)
+def test_explicit_solvers_with_the_anion_kernels(case):
+    """settings.sas_solver = "Euler" / "RK4" with bromide (the reference's bromide tutorial runs RK4): day by day from the reference's
+    states, then free-running."""
+    g = SasGolden(case)
+    assert g.tracer == "bromide" and g.solver in ("Euler", "RK4")
+    names = explicit_anion_names(bool(g.stats))
+    st = g.new_state()
+    for d in range(1, g.ndays + 1):
+        g.load_state(st, d - 1)
+        g.load_inputs(st, d)
+        st.step_oracle()
+        for k in names:
+            compare_sas(st.state[k] if k in st.state else st.out[k], g.day(d, k), f"{case} day {d} {k}", rtol=1e-10, atol=1e-11)
+    g.load_state(st, 0)
+    for d in range(1, g.ndays + 1):
+        g.load_inputs(st, d)
+        st.step_oracle()
+        for k in names:
+            compare_sas(st.state[k] if k in st.state else st.out[k], g.day(d, k), f"{case} trajectory day {d} {k}", rtol=1e-9, atol=1e-11)
+    assert max(g.day(d, "C_q_ss").max() for d in range(1, g.ndays + 1)) > 0   # solute reaches the percolation
 
 
 def test_bromide_rescale_after_warmup():
