@@ -332,33 +332,6 @@ SAS_DEV void inflow_anion(Blk<W> &B, const SasArgs &P, int64_t cell, bool subsoi
         }
 }
 
-// calc_ageing_sa (core/transport.py:623-652) and calc_ageing_msa (:655-680): shift by one class, merge the oldest
-template <int W, int E>
-SAS_DEV void ageing_anion(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E]) {
-    double p_sa, p_msa;
-    blk_prev2<W>(B, sa[E - 1], msa[E - 1], 0.0, 0.0, p_sa, p_msa);
-    double n_sa[E], n_msa[E];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int k = base + j;
-        n_sa[j] = (j == 0 ? p_sa : sa[j > 0 ? j - 1 : 0]);
-        n_msa[j] = (j == 0 ? p_msa : msa[j > 0 ? j - 1 : 0]);
-        if (k == 0) {
-            n_sa[j] = 0;
-            n_msa[j] = 0;
-        }
-        if (k == A - 1) {
-            n_sa[j] += sa[j];
-            n_sa[j] = (n_sa[j] < 1e-8 ? 0 : n_sa[j]);
-            n_msa[j] += msa[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        sa[j] = n_sa[j];
-        msa[j] = n_msa[j];
-    }
-}
 
 // tt / TT of one flux back from the diagnostics arrays (age statistics in a launch of their own)
 template <int E>
@@ -775,8 +748,6 @@ int rh_sas_create(const rh_sas_config *cfg, rh_sas_ctx **out) {
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: tracer must be RH_SAS_TRACER_OXYGEN18, _BROMIDE, _CHLORIDE or _VIRTUAL");
     if (cfg->solver < RH_SAS_SOLVER_DETERMINISTIC || cfg->solver > RH_SAS_SOLVER_RK4)
         return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: solver must be RH_SAS_SOLVER_DETERMINISTIC, _EULER or _RK4");
-    if (cfg->solver != RH_SAS_SOLVER_DETERMINISTIC && cfg->tracer != RH_SAS_TRACER_OXYGEN18)
-        return sfail(nullptr, RH_ERR_ARG, "rh_sas_create: the explicit solvers are implemented for the isotope tracers (oxygen-18, deuterium) only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sfail(nullptr, RH_ERR_NODEVICE, "rh_sas_create: no HIP device visible (this backend has no CPU fallback)");

@@ -619,6 +619,34 @@ SAS_DEV void residence_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base
     age_stats<W, E>(B, P, cell, base, RT_hi, RT_lo, rt, first_arr, skip10_90);
 }
 
+// calc_ageing_sa (core/transport.py:623-652) and calc_ageing_msa (:655-680): shift by one class, merge the oldest
+template <int W, int E>
+SAS_DEV void ageing_anion(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E]) {
+    double p_sa, p_msa;
+    blk_prev2<W>(B, sa[E - 1], msa[E - 1], 0.0, 0.0, p_sa, p_msa);
+    double n_sa[E], n_msa[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = base + j;
+        n_sa[j] = (j == 0 ? p_sa : sa[j > 0 ? j - 1 : 0]);
+        n_msa[j] = (j == 0 ? p_msa : msa[j > 0 ? j - 1 : 0]);
+        if (k == 0) {
+            n_sa[j] = 0;
+            n_msa[j] = 0;
+        }
+        if (k == A - 1) {
+            n_sa[j] += sa[j];
+            n_sa[j] = (n_sa[j] < 1e-8 ? 0 : n_sa[j]);
+            n_msa[j] += msa[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        sa[j] = n_sa[j];
+        msa[j] = n_msa[j];
+    }
+}
+
 // Ageing by one day: calc_ageing_sa_msa_iso_kernel :780-805 -> calc_ageing_msa_iso :682-739.
 template <int W, int E>
 SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E]) {

@@ -174,27 +174,93 @@ SAS_DEV void storages_iso(Blk<W> &B, const SasArgs &P, int64_t cell, int base, d
     }
 }
 
+// ... of the anion kernels (core/root_zone.py:221-258, subsoil.py:186-223, soil.py:1094-1142): classes without water drop their solute,
+// M = nansum(msa), C = M / sum(sa)
+template <int W, int E>
+SAS_DEV void storages_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int base, double (&sa_rz)[E], double (&msa_rz)[E], double (&sa_ss)[E],
+                            double (&msa_ss)[E], double mk, bool outputs) {
+    const int A = P.ages;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        sa_rz[j] = (sa_rz[j] < 1e-8 ? 0 : sa_rz[j]);
+        sa_ss[j] = (sa_ss[j] < 1e-8 ? 0 : sa_ss[j]);
+        msa_rz[j] = (sa_rz[j] <= 0 ? 0 : msa_rz[j]);
+        msa_ss[j] = (sa_ss[j] <= 0 ? 0 : msa_ss[j]);
+    }
+    if (!outputs) return;
+    double sa_s[E], msa_s[E];
+    double s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        sa_s[j] = sa_rz[j] + sa_ss[j] * mk;
+        msa_s[j] = msa_rz[j] + msa_ss[j] * mk;
+        s[0] += (msa_rz[j] != msa_rz[j]) ? 0 : msa_rz[j];
+        s[1] += sa_rz[j];
+        s[2] += (msa_ss[j] != msa_ss[j]) ? 0 : msa_ss[j];
+        s[3] += sa_ss[j];
+        s[4] += (msa_s[j] != msa_s[j]) ? 0 : msa_s[j];
+        s[5] += sa_s[j];
+    }
+    blk_sum<W, 6>(B, s);
+    if (B.tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double M = s[2 * k] * mk;
+            ((double *)P.a[SA_M_rz + k])[cell] = M;
+            ((double *)P.a[SA_C_rz + k])[cell] = (s[2 * k + 1] > 0 ? M / s[2 * k + 1] : 0);
+        }
+    }
+    if (P.diag) {
+        double *o0 = (double *)P.a[SA_sa_s] + cell * A, *o1 = (double *)P.a[SA_msa_s] + cell * A;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (base + j < A) {
+                o0[base + j] = sa_s[j];
+                o1[base + j] = msa_s[j];
+            }
+    }
+    if (P.stats) {
+        residence_stats<W, E>(B, P, cell, base, sa_rz, mk, SA_rt10_rz, true);
+        residence_stats<W, E>(B, P, cell, base, sa_ss, mk, SA_rt10_ss, true);
+        residence_stats<W, E>(B, P, cell, base, sa_s, mk, SA_rt10_s, false);
+    }
+}
+
 // What the reference overwrites in every sub-step and the day keeps from the last one, for one flux: its concentration (:2336-2357,
 // calc_conc_iso_flux :512-535, delta_fluxes_svat :3660-3697), the age statistics of transpiration and percolation, the diagnostics arrays
-template <int W, int E>
+//   ANION: the solute the flux takes along (anion_mtt) comes in as mtt_in, its concentration is sum(mtt) / (flux * h) (:2391-2406); the soil
+//   evaporation's solute and concentration are never assigned
+template <int W, int E, bool ANION>
 SAS_DEV void flux_outputs(Blk<W> &B, const SasArgs &P, int64_t cell, int base, int f, const double (&tt)[E], const double (&msa_rz)[E],
-                          const double (&msa_ss)[E], double mk) {
+                          const double (&msa_ss)[E], double mk, const double (&mtt_in)[E], double flux_h) {
     const int A = P.ages;
     const bool from_ss = f >= 3;
     double mtt[E], s[2] = {0.0, 0.0};
+    if constexpr (ANION) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        mtt[j] = (tt[j] > 0 ? (from_ss ? msa_ss[j] : msa_rz[j]) : 0);   // calc_mtt :565-596, isotopes
-        s[0] += mtt[j] * tt[j];
-        s[1] += tt[j];
-    }
-    blk_sum<W, 2>(B, s);
-    if (B.tid == 0) {
-        double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
-        conc = (conc != 0 ? conc : NAN);
-        const double Cf = conc * mk;
-        ((double *)arr5(P, SA_C_evap_soil, f))[cell] = Cf;
-        ((double *)arr5(P, SA_C_iso_evap_soil, f))[cell] = conc_to_delta(P, Cf) * mk;
+        for (int j = 0; j < E; ++j) {
+            mtt[j] = mtt_in[j];
+            s[0] += mtt[j];
+        }
+        if (f > 0) {
+            blk_sum<W, 2>(B, s);
+            if (B.tid == 0) ((double *)arr5(P, SA_C_evap_soil, f))[cell] = (flux_h > 0 ? s[0] / flux_h : 0) * mk;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            mtt[j] = (tt[j] > 0 ? (from_ss ? msa_ss[j] : msa_rz[j]) : 0);   // calc_mtt :565-596, isotopes
+            s[0] += mtt[j] * tt[j];
+            s[1] += tt[j];
+        }
+        blk_sum<W, 2>(B, s);
+        if (B.tid == 0) {
+            double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
+            conc = (conc != 0 ? conc : NAN);
+            const double Cf = conc * mk;
+            ((double *)arr5(P, SA_C_evap_soil, f))[cell] = Cf;
+            ((double *)arr5(P, SA_C_iso_evap_soil, f))[cell] = conc_to_delta(P, Cf) * mk;
+        }
     }
     const bool want_stats = P.stats && (f == 1 || f == 3);
     if (P.diag || want_stats) {
@@ -210,7 +276,7 @@ SAS_DEV void flux_outputs(Blk<W> &B, const SasArgs &P, int64_t cell, int base, i
             for (int j = 0; j < E; ++j)
                 if (base + j < A) {
                     o_tt[base + j] = tt[j];
-                    o_mtt[base + j] = mtt[j];
+                    if (!ANION || f > 0) o_mtt[base + j] = mtt[j];
                     o_TT[base + j + 1] = TT_hi[j];
                 }
         }
@@ -240,6 +306,24 @@ SAS_DEV double get5(int f, int j, const double (&ev)[E], const double (&tr)[E], 
     v = (f == 3) ? qss[j] : v;
     v = (f == 4) ? cpr[j] : v;
     return v;
+}
+
+// calc_mtt, anion branch (:583-596): the solute flux f takes from the classes of its source, msa / sa * alpha * tt * (flux * h) clipped to
+// [0, msa]; the soil evaporation (f = 0) takes none
+template <int E>
+SAS_DEV void anion_mtt(const SasArgs &P, int64_t cell, int f, double flux_h, const double (&tt)[E], const double (&sa_rz)[E], const double (&msa_rz)[E],
+                       const double (&sa_ss)[E], const double (&msa_ss)[E], double (&mtt)[E]) {
+    const bool from_ss = f >= 3;
+    const double *pa = (f == 1) ? (const double *)P.a[SA_alpha_transp] : (const double *)P.a[SA_alpha_q];   // (constant indices: arr5)
+    const double alpha = pa[cell];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const double sa = from_ss ? sa_ss[j] : sa_rz[j], msa = from_ss ? msa_ss[j] : msa_rz[j];
+        double m = (sa > 0 ? msa / sa : 0) * alpha * tt[j] * flux_h;
+        m = (m <= 0 ? 0 : m);
+        m = (m > msa ? msa : m);
+        mtt[j] = (f == 0) ? 0.0 : m;
+    }
 }
 
 // tt of flux f (0..4: evap_soil, transp, q_rz from the root zone; q_ss, cpr_rz from the subsoil; called with f ascending) on the StorAges
@@ -302,13 +386,31 @@ SAS_DEV double one_flux(Blk<W> &B, const SasArgs &P, int64_t cell, int base, int
 //   stage 2 on that,      fluxes * h / 2;  it moves by (net outflow) * h / 2                  (:1552-1580)
 //   stage 3 on that,      fluxes * h / 2;  it moves by (net outflow) * h / 2, limited by `sarkn - dsarkn < 0` as written (:1700-1728)
 //   stage 4 on that,      fluxes * h;      tt = (tt1 + 2 tt2 + 2 tt3 + tt4) / 6 (:1835-1855), then Euler's update with it (:1898-1941)
-template <int W, int E, bool LAST, bool RK4>
+//
+// ANION (bromide, chloride, virtual tracer: msa is solute mass by age): the water side is the same up to the trial StorAges of RK4, which
+// move by h / 2 after the first AND the second evaluation and not at all after the third (:1432-1446, 1581-1595, 1729-1751 -- the trial
+// solute that changes there never reaches the result either); the infiltration adds C_in * h per infiltration flux to age class 0
+// whatever infiltrates (:2100-2112, 2150-2170); the fluxes take msa / sa * alpha * tt * flux * h (calc_mtt's anion branch) and the update
+// adds the differences unmixed, refused where they would turn a class negative (:2308-2332); RK4's root zone -- as written -- GAINS the
+// soil evaporation and does not receive the capillary rise (:1941-1946).
+template <int W, int E, bool LAST, bool RK4, bool ANION>
 SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int base, double h, double mk, double im, double ip, double is,
                               double C_in, double (&sa_rz)[E], double (&msa_rz)[E], double (&sa_ss)[E], double (&msa_ss)[E]) {
     // 1. upper boundary condition :2071-2145 (:1146-1220).  tt_inf is 1 in age class 0 and 0 elsewhere: for the other classes the mixing
     //    reduces to msa * (sa / sa) where the class holds water (and, in the root zone, a positive signal), 0 otherwise
 #pragma unroll
     for (int j = 0; j < E; ++j) {
+        if constexpr (ANION) {
+            if (base + j == 0) {
+                const double t0 = (im > 0 ? 1 : 0) * mk, t1 = (ip > 0 ? 1 : 0) * mk, t2 = (is > 0 ? 1 : 0) * mk;
+                const double m = C_in * mk, mm = (m != m) ? 0 : m;
+                sa_rz[j] += (im * t0 + ip * t1) * h;
+                sa_ss[j] += (is * t2) * h;
+                msa_rz[j] += mm * h + mm * h;
+                msa_ss[j] += mm * h;
+            }
+            continue;
+        }
         if (base + j == 0) {
             const double t0 = (im > 0 ? 1 : 0) * mk, t1 = (ip > 0 ? 1 : 0) * mk, t2 = (is > 0 ? 1 : 0) * mk;
             const double m0 = (im > 0 ? C_in : 0) * mk, m1 = (ip > 0 ? C_in : 0) * mk, m2 = (is > 0 ? C_in : 0) * mk;
@@ -327,24 +429,34 @@ SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int bas
             msa_ss[j] = (sa_ss[j] > 0) ? msa_ss[j] : 0;
         }
     }
-    if (LAST && B.tid == 0) {   // :2324-2335, delta_fluxes_svat :3660-3697
+    if (LAST && B.tid == 0) {   // :2324-2335, delta_fluxes_svat :3660-3697; anions :2379-2390
         const double inf[3] = {im, ip, is};
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-            const double Ci = (inf[w] > 0 ? C_in : NAN) * mk;
-            ((double *)P.a[SA_C_inf_mat_rz + w])[cell] = Ci;
-            ((double *)P.a[SA_C_iso_inf_mat_rz + w])[cell] = conc_to_delta(P, Ci) * mk;
+            if constexpr (ANION) {
+                ((double *)P.a[SA_C_inf_mat_rz + w])[cell] = (inf[w] * h > 0 ? C_in : 0) * mk;
+            } else {
+                const double Ci = (inf[w] > 0 ? C_in : NAN) * mk;
+                ((double *)P.a[SA_C_inf_mat_rz + w])[cell] = Ci;
+                ((double *)P.a[SA_C_iso_inf_mat_rz + w])[cell] = conc_to_delta(P, Ci) * mk;
+            }
         }
     }
-    // 2. + 3. flux * tt per class of the five fluxes
+    // 2. + 3. flux * tt per class of the five fluxes [, the solute they take]
     FIVE(e);
+    FIVE(m);   // (ANION only; m_ev stays unused)
     double SA[E], sa_src[E], S_top = 0.0;
     if constexpr (!RK4) {
 #pragma unroll 1
         for (int f = 0; f < 5; ++f) {
-            double tt[E];
+            double tt[E], mtt[E];
             const double flux = one_flux<W, E>(B, P, cell, base, f, h, false, mk, true, sa_rz, sa_ss, SA, sa_src, S_top, tt);
-            if constexpr (LAST) flux_outputs<W, E>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk);
+            if constexpr (ANION) {
+                anion_mtt<E>(P, cell, f, flux * h, tt, sa_rz, msa_rz, sa_ss, msa_ss, mtt);
+#pragma unroll
+                for (int j = 0; j < E; ++j) SET5(m, f, j, mtt[j]);
+            }
+            if constexpr (LAST) flux_outputs<W, E, ANION>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk, mtt, flux * h);
 #pragma unroll
             for (int j = 0; j < E; ++j) SET5(e, f, j, flux * tt[j]);
         }
@@ -370,12 +482,12 @@ SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int bas
                     SET5(e, f, j, flux * tt[j]);
                 }
             }
-            if (stage < 3) {
+            if (stage < (ANION ? 2 : 3)) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     double d_rz = (e_cpr[j] - e_ev[j] - e_tr[j] - e_qrz[j]) * h;
                     double d_ss = (e_qrz[j] - e_cpr[j] - e_qss[j]) * h;
-                    if (stage > 0) {
+                    if (stage > 0 || ANION) {
                         d_rz = d_rz / 2;
                         d_ss = d_ss / 2;
                     }
@@ -391,16 +503,42 @@ SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int bas
 #pragma unroll 1
         for (int f = 0; f < 5; ++f) {
             const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
-            double tt[E];
+            double tt[E], mtt[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) tt[j] = get5<E>(f, j, FIVE_ARGS(acc)) / 6.;
-            if constexpr (LAST) flux_outputs<W, E>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk);
+            if constexpr (ANION) {   // :1881-1896: on the state after the infiltration
+                anion_mtt<E>(P, cell, f, flux * h, tt, sa_rz, msa_rz, sa_ss, msa_ss, mtt);
+#pragma unroll
+                for (int j = 0; j < E; ++j) SET5(m, f, j, mtt[j]);
+            }
+            if constexpr (LAST) flux_outputs<W, E, ANION>(B, P, cell, base, f, tt, msa_rz, msa_ss, mk, mtt, flux * h);
 #pragma unroll
             for (int j = 0; j < E; ++j) SET5(e, f, j, flux * tt[j]);
         }
     }
 
-    // 4. update of both StorAges :2266-2310 (:1898-1941)
+    // 4. update of both StorAges :2266-2310 (:1898-1941); anions :2308-2332 (:1941-1966)
+    if constexpr (ANION) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            double dsa_rz = RK4 ? (e_ev[j] - e_tr[j] - e_qrz[j]) * h : (e_cpr[j] - e_ev[j] - e_tr[j] - e_qrz[j]) * h;
+            dsa_rz = (sa_rz[j] + dsa_rz < 0) ? -sa_rz[j] : dsa_rz;
+            double dsa_ss = (e_qrz[j] - e_cpr[j] - e_qss[j]) * h;
+            dsa_ss = (sa_ss[j] + dsa_ss < 0) ? -sa_ss[j] : dsa_ss;
+#define RH_NZ(x) (((x) != (x)) ? 0 : (x))
+            double dmsa_rz = RH_NZ(m_cpr[j]) - RH_NZ(m_tr[j]) - RH_NZ(m_qrz[j]);
+            double dmsa_ss = RH_NZ(m_qrz[j]) - RH_NZ(m_cpr[j]) - RH_NZ(m_qss[j]);
+#undef RH_NZ
+            dmsa_rz = (msa_rz[j] + dmsa_rz < 0) ? 0 : dmsa_rz;
+            dmsa_ss = (msa_ss[j] + dmsa_ss < 0) ? 0 : dmsa_ss;
+            sa_rz[j] += dsa_rz;
+            sa_ss[j] += dsa_ss;
+            msa_rz[j] += dmsa_rz;
+            msa_ss[j] += dmsa_ss;
+        }
+        storages_anion<W, E>(B, P, cell, base, sa_rz, msa_rz, sa_ss, msa_ss, mk, LAST);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         double dsa_rz = (e_cpr[j] - e_ev[j] - e_tr[j] - e_qrz[j]) * h;
@@ -429,17 +567,17 @@ SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int bas
 #ifndef RH_EULER_WAVES
 #define RH_EULER_WAVES 2
 #endif
-template <int W, int E, bool RK4>
+template <int W, int E, bool RK4, bool ANION>
 __device__ __forceinline__ void explicit_body(const SasArgs &P);
-template <int W, int E>
+template <int W, int E, bool ANION>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER_WAVES, RH_EULER_WAVES))) void k_sas_euler(const SasArgs P) {
-    explicit_body<W, E, false>(P);
+    explicit_body<W, E, false, ANION>(P);
 }
-template <int W, int E>
+template <int W, int E, bool ANION>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(RH_EULER_WAVES, RH_EULER_WAVES))) void k_sas_rk4(const SasArgs P) {
-    explicit_body<W, E, true>(P);
+    explicit_body<W, E, true, ANION>(P);
 }
-template <int W, int E, bool RK4>
+template <int W, int E, bool RK4, bool ANION>
 __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
@@ -477,11 +615,16 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     const double is = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell], C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
 
     for (int it = 0; it + 1 < P.substeps; ++it)
-        explicit_substep<W, E, false, RK4>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
-    explicit_substep<W, E, true, RK4>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
+        explicit_substep<W, E, false, RK4, ANION>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
+    explicit_substep<W, E, true, RK4, ANION>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
 
-    ageing<W, E>(B, A, base, sa_rz, msa_rz);
-    ageing<W, E>(B, A, base, sa_ss, msa_ss);
+    if constexpr (ANION) {
+        ageing_anion<W, E>(B, A, base, sa_rz, msa_rz);
+        ageing_anion<W, E>(B, A, base, sa_ss, msa_ss);
+    } else {
+        ageing<W, E>(B, A, base, sa_rz, msa_rz);
+        ageing<W, E>(B, A, base, sa_ss, msa_ss);
+    }
     {
         double *g0 = (double *)P.a[SA_sa_rz] + cell * A, *g1 = (double *)P.a[SA_msa_rz] + cell * A;
         double *g2 = (double *)P.a[SA_sa_ss] + cell * A, *g3 = (double *)P.a[SA_msa_ss] + cell * A;
@@ -498,8 +641,15 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
 
 template <int W, int E>
 static void launch_explicit(int solver, hipStream_t stream, const SasArgs &args) {
-    if (solver == RH_SAS_SOLVER_RK4) hipLaunchKernelGGL((k_sas_rk4<W, E>), dim3((unsigned)args.n), dim3(W * 64), 0, stream, args);
-    else hipLaunchKernelGGL((k_sas_euler<W, E>), dim3((unsigned)args.n), dim3(W * 64), 0, stream, args);
+    const bool anion = args.tracer != RH_SAS_TRACER_OXYGEN18;
+    const dim3 grid((unsigned)args.n), block(W * 64);
+    if (solver == RH_SAS_SOLVER_RK4) {
+        if (anion) hipLaunchKernelGGL((k_sas_rk4<W, E, true>), grid, block, 0, stream, args);
+        else hipLaunchKernelGGL((k_sas_rk4<W, E, false>), grid, block, 0, stream, args);
+    } else {
+        if (anion) hipLaunchKernelGGL((k_sas_euler<W, E, true>), grid, block, 0, stream, args);
+        else hipLaunchKernelGGL((k_sas_euler<W, E, false>), grid, block, 0, stream, args);
+    }
 }
 
 // The whole day of an explicit solver in one launch; the smallest workgroup whose blocked layout covers the age classes.

@@ -70,7 +70,7 @@ def check_setting_conflicts(settings):
         raise NotImplementedError("settings.enable_routing_1D routes the lateral subsurface runoff: it needs settings.enable_lateral_flow "
                                   "(examples/hillslope_scale/oneD_distributed_routing_tutorial/oneD.py:82-83)")
     if settings.enable_offline_transport:
-        # the native transport path: oxygen-18, deuterium, bromide or chloride with the deterministic SAS solver
+        # the native transport path: oxygen-18, deuterium, bromide, chloride or the virtual tracer with any of the three SAS solvers
         # 
         if sum(int(getattr(settings, k)) for k in ("enable_oxygen18", "enable_deuterium", "enable_bromide", "enable_chloride",
                                                    "enable_virtualtracer")) != 1:
@@ -81,8 +81,6 @@ def check_setting_conflicts(settings):
             raise NotImplementedError(f'settings.sas_solver={settings.sas_solver!r}: the SAS solvers are "deterministic" and the '
                                       'explicit "Euler" and "RK4" (roger/settings.py:119)')
         if settings.sas_solver in ("Euler", "RK4"):
-            if not (settings.enable_oxygen18 or settings.enable_deuterium):
-                raise NotImplementedError(f'settings.sas_solver="{settings.sas_solver}" is implemented for the isotope tracers (oxygen-18, deuterium)')
             # benchmarks/SVATOXYGEN18_benchmark.py:30-31: the increment of the numerical solver is the length of a sub-step
             if abs(settings.h * settings.sas_solver_substeps - 1) > 1e-12:
                 raise ValueError("settings.h must be 1 / settings.sas_solver_substeps for the explicit solvers")

@@ -79,6 +79,16 @@ def test_bromide_setup_on_device():
     model.state.sas_context.close()
 
 
+@pytest.mark.parametrize("case", sb.ANION_SOLVER_CASES)
+def test_bromide_with_explicit_solvers_on_device(case):
+    """settings.sas_solver = "Euler" / "RK4" with settings.enable_bromide (examples/plot_scale/svat_bromide_tutorial runs RK4)."""
+    g = sb.SasGolden(case)
+    model = bromide_model(g)
+    run_and_compare_bromide(g, model)
+    assert model.state.sas_context.solver == g.solver
+    model.state.sas_context.close()
+
+
 def test_bromide_warmup_on_device():
     g = sb.SasGolden("sas_bromide_warmup_a30")
     model = bromide_model(g, warmup_days=g.ndays)

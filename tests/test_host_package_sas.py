@@ -113,7 +113,7 @@ def bromide_model(g, pkg="roger_amd", warmup_days=0):
     if g.tracer in ("chloride", "virtualtracer"):   # the background concentrations tests/golden/make_golden_sas.py starts from
         extra.update(C_init_rz=4.0, C_init_ss=9.0)
     return make_transport_model(pkg, svat, sas, g.ages, g.substeps, g.ndays, bool(g.stats), warmup_days=warmup_days,
-                                tracer=g.tracer, extra=extra)
+                                tracer=g.tracer, extra=extra, solver=g.solver)
 
 
 TWO_LEVELS = ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_ss", "C_s", "M_rz", "M_ss", "M_s")   # (x, y, timesteps, ...)
@@ -122,7 +122,10 @@ TWO_LEVELS = ("sa_rz", "sa_ss", "msa_rz", "msa_ss", "sa_s", "msa_s", "C_rz", "C_
 def run_and_compare_bromide(g, model, rtol=1e-9, warmup=0):
     """The setup class that produced sas_bromide_a40 through the reference (settings.enable_bromide, the anion kernels),
     run free through roger_amd: every day of the trajectory."""
-    from test_oracle_sas import bromide_names
+    from test_oracle_sas import bromide_names, explicit_anion_names
+
+    if g.solver != "deterministic":   # the explicit models never assign the solute masses of the fluxes
+        bromide_names = explicit_anion_names
 
     model.setup()
     model.warmup(repeat=warmup)
@@ -144,6 +147,13 @@ def run_and_compare_bromide(g, model, rtol=1e-9, warmup=0):
 
 def test_bromide_setup_through_host_package(oracle_sas):
     g = sb.SasGolden("sas_bromide_a40")
+    run_and_compare_bromide(g, bromide_model(g))
+
+
+@pytest.mark.parametrize("case", sb.ANION_SOLVER_CASES)
+def test_bromide_with_explicit_solvers_through_host_package(oracle_sas, case):
+    """settings.sas_solver = "Euler" / "RK4" with settings.enable_bromide (examples/plot_scale/svat_bromide_tutorial runs RK4)."""
+    g = sb.SasGolden(case)
     run_and_compare_bromide(g, bromide_model(g))
 
 
