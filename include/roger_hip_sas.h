@@ -62,8 +62,8 @@ extern "C" {
 #define RH_SAS_TRACER_VIRTUAL 3  /* settings.enable_virtualtracer: as chloride, and the soil evaporation takes the tracer along
                                     (calc_evaporation_transport_virtualtracer_kernel, core/evapotranspiration.py:722-791) */
 /* settings.sas_solver (roger/settings.py:119): "deterministic" (svat_transport_model_deterministic, core/transport.py:949-991) or the
- * explicit "Euler" scheme (svat_transport_model_euler :2064-2414, isotopes only): every sub-step of length settings.h = 1 / substeps
- * evaluates all five fluxes on the StorAge as it stands; "RK4" (svat_transport_model_rk4 :1139-2047, isotopes only) evaluates them
+ * explicit "Euler" scheme (svat_transport_model_euler :2064-2414, isotope and anion branches): every sub-step of length settings.h = 1 / substeps
+ * evaluates all five fluxes on the StorAge as it stands; "RK4" (svat_transport_model_rk4 :1139-2047, both branches) evaluates them
  * four times per sub-step on trial StorAges and updates with the weighted mean of the four travel time distributions. */
 #define RH_SAS_SOLVER_DETERMINISTIC 0
 #define RH_SAS_SOLVER_EULER 1

@@ -58,7 +58,7 @@ def calculate_storage_selection(state):
     set_forcing hook assigned (vs.inf_mat_rz, ..., vs.C_in) is uploaded first; results stay on the device until a
     `vs.<name>` is read.
 
-    `sas_solver == "Euler"` / `"RK4"` (:3220-3304, isotopes): the loop over the sub-steps -- svat_transport_model_euler / _rk4, the storages, the age
+    `sas_solver == "Euler"` / `"RK4"` (:3220-3304, isotopes and anions): the loop over the sub-steps -- svat_transport_model_euler / _rk4, the storages, the age
     statistics, the ageing at the end of the day -- is one native launch as well; the model time advances here, by the sub-steps'
     `int(dt_secs / substeps)` (the reference ages the water when that reaches a full day, so the sub-steps must divide the day).
     The variables hold the values after the last sub-step (the reference's per-sub-step `write_output` is not reproduced)."""

@@ -499,7 +499,7 @@ def test_explicit_solver_random_columns_against_oracle(n, ages, substeps, stats,
 
 
 def test_explicit_solver_runs_the_day_in_one_launch():
-    """The explicit solvers evaluate all fluxes on one state: single stages are refused, the Euler solver with an anion tracer too."""
+    """The explicit solvers evaluate all fluxes on one state: single stages are refused; an unknown solver too."""
     from roger_amd import _native
 
     st = random_problem(8, 30, 2, seed=3, solver="Euler")
@@ -508,5 +508,5 @@ def test_explicit_solver_runs_the_day_in_one_launch():
     with pytest.raises(_native.NativeError, match="one launch"):
         ctx.stages(0, _native.SAS_STAGES["TRANSP"])
     ctx.close()
-    with pytest.raises(_native.NativeError, match="isotope"):
-        _native.SasContext(8, 30, 2, tracer="bromide", solver="Euler")
+    with pytest.raises(ValueError, match="solver"):
+        _native.SasContext(8, 30, 2, tracer="bromide", solver="Heun")
