@@ -96,8 +96,9 @@ def test_bromide_warmup_on_device():
     model.state.sas_context.close()
 
 
-def test_chloride_warmup_on_device():
-    g = sb.SasGolden("sas_chloride_warmup_a30")
+@pytest.mark.parametrize("case", ["sas_chloride_warmup_a30", "sas_chloride_rk4_warmup_a30"])
+def test_chloride_warmup_on_device(case):
+    g = sb.SasGolden(case)
     model = bromide_model(g, warmup_days=g.ndays)
     run_and_compare_bromide(g, model, warmup=1)
     assert model.state.sas_context.tracer == "chloride"
