@@ -477,9 +477,15 @@ def main():
         # multi-GPU: per step ncclAllReduce (64 x int32) -> control kernel -> fused kernel, enqueued from C (rh_run_steps_dist);
         # RH_BENCH_FORCE_DIST=1 rehearses it on one GPU with a one-rank communicator
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        ctx.comm_init_torch()
-        run = ctx.run_steps_dist
-        stepping = "rh_run_steps_dist (RCCL from C)"
+        try:
+            ctx.comm_init_torch()
+            run = ctx.run_steps_dist
+            stepping = "rh_run_steps_dist (RCCL from C)"
+        except Exception as exc:   # noqa: BLE001  (no librccl the library can open, or its communicator cannot be formed)
+            # every rank fails or succeeds alike (same image, same node); the exchange then goes through torch.distributed
+            print(f"bench: rank {rank}: RCCL communicator from C not available ({exc}); stepping through torch.distributed", file=sys.stderr)
+            run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run
+            stepping = "PhasedStepper (torch.distributed; the C-side communicator could not be formed)"
     elif world > 1 or os.environ.get("RH_BENCH_FORCE_PHASED"):   # rehearsals: the Python orchestration (gloo between CPU-side ranks)
         run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run   # one summary all-reduce per step
         stepping = "PhasedStepper (torch.distributed)"
