@@ -318,3 +318,48 @@ def test_full_size_routed_columns_equal_a_strip(native, oracle):
             routed += float(np.nansum(np.abs(r)))
     assert routed > 0.1
     ctx.close()
+
+
+def test_month_change_inside_device_driven_routed_steps(native, oracle, monkeypatch):
+    """The month changes on the third day of the run: set_parameters' surface parameters are then recomputed inside the first pass
+    (device-driven stepping, D->monthly) or by a kernel of their own (routine by routine) -- both track the oracle, whose driver decides
+    on the host, and agree bit for bit."""
+    import hip_util as H
+    from golden_util import compare_bulk
+    from roger_amd.forcing import combo_forcing
+
+    g, names, _ = load_case(ROUTING_CASES[0])
+    F = {k: np.array(v) for k, v in combo_forcing(ndays=8).items()}
+    F["MONTH"] = np.where(np.arange(F["MONTH"].size) < 2 * 144, 4, 5).astype(F["MONTH"].dtype)   # April -> May: the vegetation tables differ
+    F["DOY"] = (119 + np.arange(F["DOY"].size) // 144).astype(F["DOY"].dtype)
+    nx, ny = 20, 16
+    out = {}
+    for mode in ("device", "routine"):
+        if mode == "routine":
+            monkeypatch.setenv("RH_ROUTED_BY_ROUTINE", "1")
+        else:
+            monkeypatch.delenv("RH_ROUTED_BY_ROUTINE", raising=False)
+        st, ctx = _tiled_case(native, oracle, g, names, nx, ny, np.random.default_rng(21))
+        for s_ in (st.scal,):   # the golden's start state sits in January: move the calendar of both sides to the series' April
+            s_.month[0] = s_.month[1] = 4
+            s_.doy[0] = s_.doy[1] = 119
+        ctx.set_scalars(H.scalars_from_row(st.scalars_row()))
+        ctx.set_forcing_series(F)
+        odrv = oracle.ForcingDriver(F)
+        months, changed = set(), 0
+        gc0 = st.planes["ground_cover"].copy()
+        for step in range(1, 91):
+            if step > 12:   # from here on step by step from the oracle's state (residue ties of the oneD columns, see above)
+                H.upload_snapshot(ctx, st.snapshot(names), names)
+            pd, td, ed, monthly = odrv.before_step(st)
+            changed += int(monthly)
+            st.step(pd, td, ed, monthly)
+            months.add(int(st.scal.month[1]))
+            ctx.run_steps(1)
+            if step % 10 == 0 or monthly or step > 12:
+                np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row(), err_msg=f"{mode} step {step}")
+                compare_bulk(H.download_snapshot(ctx, names), st.snapshot(names), names, what=f"{mode} step {step}")
+        assert months == {4, 5} and changed == 1 and not np.array_equal(gc0, st.planes["ground_cover"])
+        out[mode] = H.download_snapshot(ctx, names)
+        ctx.close()
+    assert np.array_equal(out["device"], out["routine"], equal_nan=True)
