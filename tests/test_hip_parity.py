@@ -602,3 +602,51 @@ def test_lazy_rotation_equals_eager(native):
         np.testing.assert_array_equal(x, y, err_msg=f"snapshot {k}")
     for xm1 in ("S_rz_m1", "swe_m1", "theta_m1"):     # after a complete step the rotation holds in what the host sees
         np.testing.assert_array_equal(a[2][names.index(xm1)], a[2][names.index(xm1[:-3])], err_msg=xm1)
+
+
+@pytest.mark.parametrize("case", ["oned_hetero_combo", "svat_hetero_heavyrain"])
+def test_month_change_inside_device_driven_steps(native, oracle, case):
+    """The month changes on the third day: the fused kernel takes its pipeline with the monthly surface parameters in front (decided on
+    the device, `k_step<2, LATERAL, .>`), also for the oneD model, whose goldens never cross a month.  Against the oracle, whose driver
+    decides on the host: step by step from the oracle's state (residue ties of the oneD columns)."""
+    import hip_util as H
+    from golden_util import configure_settings
+    from roger_amd.forcing import combo_forcing
+
+    g, names, _ = load_case(case)
+    F = {k: np.array(v) for k, v in combo_forcing(ndays=8).items()}
+    F["MONTH"] = np.where(np.arange(F["MONTH"].size) < 2 * 144, 4, 5).astype(F["MONTH"].dtype)   # April -> May: the vegetation tables differ
+    F["DOY"] = (119 + np.arange(F["DOY"].size) // 144).astype(F["DOY"].dtype)
+    rng = np.random.default_rng(4)
+    src = np.asarray(g["state0"])
+    nx, ny = 24, 20
+    snap = src[:, rng.integers(0, src.shape[1], nx * ny)].copy()
+    st = oracle.OracleState(nx * ny)
+    st.load_snapshot(snap, names)
+    st.load_scalars(g["scal0"])
+    st.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    configure_settings(st.settings, g)
+    st.settings.nx, st.settings.ny = nx, ny
+    st.scal.month[0] = st.scal.month[1] = 4
+    st.scal.doy[0] = st.scal.doy[1] = 119
+    ctx = native.Context(nx, ny, enable_lateral_flow=int(is_lateral(g)))
+    H.upload_snapshot(ctx, snap, names)
+    ctx.set_scalars(H.scalars_from_row(st.scalars_row()))
+    ctx.set_luts(g["lut_ilu"], g["lut_gc"], g["lut_gcm"], g["lut_rdlu"])
+    if is_lateral(g):
+        ctx.set_lut_mlms(g["lut_mlms"])
+    ctx.set_forcing_series(F)
+    odrv = oracle.ForcingDriver(F)
+    gc0 = st.planes["ground_cover"].copy()
+    changed = 0
+    for step in range(1, 81):
+        if step > 2:   # (the second dry day leaves a residue of -4e-16 mm in a subsoil's large pores whose sign decides the percolation)
+            H.upload_snapshot(ctx, st.snapshot(names), names)
+        pd, td, ed, monthly = odrv.before_step(st)
+        changed += int(monthly)
+        st.step(pd, td, ed, monthly)
+        ctx.run_steps(1)
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), st.scalars_row(), err_msg=f"step {step}")
+        compare_bulk(H.download_snapshot(ctx, names), st.snapshot(names), names, what=f"{case} step {step}")
+    assert changed == 1 and not np.array_equal(gc0, st.planes["ground_cover"])
+    ctx.close()
