@@ -190,6 +190,22 @@ def test_device_driven_routed_steps_equal_the_routine_by_routine_step(native, mo
     for mode in ("routine", "split"):
         np.testing.assert_array_equal(out["device"][0], out[mode][0])
         assert np.array_equal(out["device"][1], out[mode][1], equal_nan=True), mode
+    # with the output accumulators configured (the accumulator kernel then runs between the numerics and the rotation): the same state,
+    # and daily sums equal to those of the routine-by-routine step
+    sums = {}
+    for mode in ("device", "routine"):
+        if mode == "routine":
+            monkeypatch.setenv("RH_ROUTED_BY_ROUTINE", "1")
+        else:
+            monkeypatch.delenv("RH_ROUTED_BY_ROUTINE", raising=False)
+        ctx = routed_ctx(native, g, names)
+        ctx.set_forcing_series(forcing)
+        ctx.diag_configure(rate=("q_sur_out", "q_sub_in", "aet", "prec"), collect=("S", "z0"), n_slots=8)
+        ctx.run_steps(nsteps)
+        assert np.array_equal(H.download_snapshot(ctx, names), out["device"][1], equal_nan=True), mode
+        sums[mode] = np.stack([ctx.diag_download(k, slot) for slot in range(4) for k in ("q_sur_out", "q_sub_in", "aet", "prec", "S", "z0")])
+        ctx.close()
+    assert np.array_equal(sums["device"], sums["routine"]) and sums["device"][0].sum() + sums["device"][1].sum() > 0
 
 
 def test_fused_step_is_refused_and_lateral_flow_is_required(native):
