@@ -23,8 +23,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 _SAS_DEPS = ("rh_sas_dev.h", "rh_sas_tables.inc", "include/roger_hip_sas.h", "include/rh_sas_arrays.def", "include/roger_hip.h")
 UNITS = {
     "roger_hip": ("rh_physics.h", "rh_col.h", "rh_sets.inc", "include/roger_hip.h", "include/rh_fields.def"),
-    "rh_sas": _SAS_DEPS,            # the deterministic SAS kernels + the SAS C ABI (about four minutes)
-    "rh_sas_solvers": _SAS_DEPS,    # the explicit solvers
+    "rh_sas": _SAS_DEPS,                                            # the SAS C ABI
+    "rh_sas_det_iso": _SAS_DEPS + ("rh_sas_kernels.h",),            # the deterministic SAS kernels: isotopes ...
+    "rh_sas_det_anion": _SAS_DEPS + ("rh_sas_kernels.h",),          # ... and anions
+    "rh_sas_euler_iso": _SAS_DEPS + ("rh_sas_solvers_impl.h",),     # the explicit solvers
+    "rh_sas_euler_anion": _SAS_DEPS + ("rh_sas_solvers_impl.h",),
+    "rh_sas_rk4_iso": _SAS_DEPS + ("rh_sas_solvers_impl.h",),
+    "rh_sas_rk4_anion": _SAS_DEPS + ("rh_sas_solvers_impl.h",),
 }
 OBJ = os.path.join(PKG, "_obj")
 

@@ -1,4 +1,4 @@
-// rh_sas.hip -- SAS / oxygen-18 transport step (deterministic solver) for gfx950, and its C ABI
+// rh_sas.hip -- the C ABI of the SAS / oxygen-18 transport step for gfx950 (kernels: rh_sas_kernels.h, rh_sas_solvers_impl.h)
 // (include/roger_hip_sas.h).
 //
 // One workgroup per soil column.  The age axis is laid out blocked over the workgroup: thread t
@@ -44,596 +44,6 @@ static const unsigned char SAS_WHEN[] = {
 #include "rh_sas_arrays.def"
 #undef RH_SAS_ARRAY
 };
-
-// One instantiation per family, selected per column (uniform over the workgroup) by calc_tt below: the benchmark's
-// power law keeps its register budget (3 waves/SIMD without spills) whatever the other families need.
-template <int W, int E, int FAM>
-SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
-                            double (&tt)[E]) {
-    const int A = P.ages;
-    const double h = 1 / (double)P.substeps;
-    const double fh = flux * h;
-    if (!(fh > 0)) {
-        // :440-443: tti = where(flux * h > 0, ., 0) in every sub-step -> TT = 0 -> tt = 0 (:496-499);
-        // the SAS evaluation cannot change that, skip it
-#pragma unroll
-        for (int j = 0; j < E; ++j) tt[j] = 0.0;
-        return;
-    }
-    const double pr[7] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};  // read once: the loop below stores nothing, but the compiler cannot know
-    const PowConsts C = load_pow_consts(B.logt);
-    const UDiv by_fh = udiv_prepare(fh);
-    double Om_edge0 = 0.0;  // Omega at SA[0] = 0: 0 for every family but a dirac with a negative threshold
-    double san[E], ttn[E];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        san[j] = sa[j];
-        ttn[j] = 0.0;
-    }
-    for (int it = 0; it < P.substeps; ++it) {
-        double SA_hi[E], SA_lo, Smax;
-        blk_cumsum<W, E, (FAM == FAM_KUMARASWAMI || FAM == FAM_EXPONENTIAL || FAM == FAM_GAMMA)>(B, san, SA_hi, SA_lo, &Smax, base, A - 1);
-        if (it == 0) {  // the first sub-step sees SA = calc_SA(sa) * maskCatch, the later ones cumsum(san) (:456-459)
-#pragma unroll
-            for (int j = 0; j < E; ++j) SA_hi[j] *= mk;
-            Smax *= mk;
-        }
-        double Om[E];
-        sas_omega<W, E, FAM>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
-        double Om_lo, unused;
-        blk_prev2<W>(B, Om[E - 1], 0.0, Om_edge0, 0.0, Om_lo, unused);
-        double tti[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const double d = Om[j] - (j == 0 ? Om_lo : Om[j - 1]);
-            double t = fmax(d, 0.0);                                            // :430-433  where(d >= 0, d, 0)
-            const double q = fmin(flux * t * h, san[j]);                        // :435-438  where(flux t h > san, san, flux t h)
-            t = udiv(q, by_fh);                                                 // :440-443: q / (flux * h), fh > 0 here
-            san[j] = san[j] + -t * flux * h;                                    // :445-448
-            tti[j] = t;
-        }
-        // :461-468.  The reference accumulates TTn += cumsum(tti) and takes diff(TTn / N) afterwards (:482-490);
-        // diff(cumsum(.)) is the identity, so the sub-step distributions are accumulated directly (the
-        // reference's own `ttn`).  Differs from the round trip through the cumulative sums by ~1e-16 absolute
-        // and saves one block scan per sub-step.
-#pragma unroll
-        for (int j = 0; j < E; ++j) ttn[j] += tti[j];
-    }
-    const UDiv by_N = udiv_prepare((double)P.substeps), by_flux = udiv_prepare(flux);   // (flux > 0 here: fh > 0)
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const double t = udiv(ttn[j], by_N);                                      // :482-490
-        const double q = (flux * t > sa[j] ? sa[j] : flux * t);                   // :493-496
-        tt[j] = udiv(q, by_flux);                                                 // :497-499  where(flux > 0, q / flux, 0)
-    }
-}
-template <int W, int E>
-SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, const double (&sa)[E], double mk, int base,
-                     double (&tt)[E]) {
-    const double code = p[0];
-    if (code == 6 || code == 61 || code == 62) calc_tt_family<W, E, FAM_POWER>(B, P, p, flux, sa, mk, base, tt);
-    else if (code == 1) calc_tt_family<W, E, FAM_UNIFORM>(B, P, p, flux, sa, mk, base, tt);
-    else if (code == 3 || (code >= 31 && code <= 37)) calc_tt_family<W, E, FAM_KUMARASWAMI>(B, P, p, flux, sa, mk, base, tt);
-    else if (code == 2) calc_tt_family<W, E, FAM_DIRAC>(B, P, p, flux, sa, mk, base, tt);
-    else if (code == 51) calc_tt_family<W, E, FAM_EXPONENTIAL>(B, P, p, flux, sa, mk, base, tt);
-#ifndef RH_SAS_NO_GAMMA  // (experiments: the kernel without the gamma family's code)
-    else if (code == 4) calc_tt_family<W, E, FAM_GAMMA>(B, P, p, flux, sa, mk, base, tt);
-#endif
-    else {
-        // 52, the exponential with reversed age order (sas.py:186-190): Omega DEcreases from 1 to 0 along the age axis,
-        // calc_tt clips every difference to 0 (:430-433) -- no water is selected, like Omega = 0.  Any other code is
-        // unknown to the reference's families (all masked out: Omega = 0 as well) and is reported.
-        if (code != 52 && B.tid == 0 && flux * (1 / (double)P.substeps) > 0) *P.unsupported = 1;
-        calc_tt_family<W, E, FAM_NONE>(B, P, p, flux, sa, mk, base, tt);
-    }
-}
-
-
-// One outgoing flux: SA, tt, TT, mtt, C, C_iso, the sink's isotope mixing, update_sa.
-// calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
-// calc_percolation_rz/ss_transport_iso_kernel (core/subsurface_runoff.py:1531-1626, 1753-1820),
-// calc_capillary_rise_rz_transport_iso_kernel (core/capillary_rise.py:404-500).
-template <int W, int E, bool SINK, bool KEEP>
-SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&sa)[E], double (&msa)[E], double (&sa_sink)[E],
-                     double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
-    const int A = P.ages;
-    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
-    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
-    double tt[E];
-    calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
-    double mtt[E], s[2] = {0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        tt[j] *= mk;
-        mtt[j] = (tt[j] > 0 ? msa[j] : 0) * mk;  // calc_mtt :565-596 with alpha = 1
-        s[0] += mtt[j] * tt[j];
-        s[1] += tt[j];
-    }
-    if (P.diag || (KEEP && stats_now(P))) {  // TT[1:] = cumsum(tt)
-        double TT_hi[E], TT_lo;
-        blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-        if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
-        if (P.diag) {
-            double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
-            double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
-            double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
-            if (B.tid == 0) o_TT[0] = 0.0;
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                if (base + j < A) {
-                    o_tt[base + j] = tt[j];
-                    o_mtt[base + j] = mtt[j];
-                    o_TT[base + j + 1] = TT_hi[j];
-                }
-        }
-    }
-    blk_sum<W, 2>(B, s);
-    if (B.tid == 0) {  // calc_conc_iso_flux :512-535
-        double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
-        conc = (conc != 0 ? conc : NAN);
-        const double C = conc * mk;
-        ((double *)P.a[SA_C_evap_soil + f])[cell] = C;
-        ((double *)P.a[SA_C_iso_evap_soil + f])[cell] = conc_to_delta(P, C) * mk;
-    }
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        if (SINK) {
-            const double add = tt[j] * flux;
-            const UDiv by_tot = udiv_prepare(add + sa_sink[j]);   // two quotients by one divisor (udiv: the bits of `/`)
-            msa_sink[j] = (add + sa_sink[j] > 0
-                               ? msa_sink[j] * udiv(sa_sink[j], by_tot) + mtt[j] * udiv(add, by_tot)
-                               : msa_sink[j]) * mk;
-        }
-        double v = sa[j] + -flux * tt[j];  // update_sa :599-619
-        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
-        sa[j] = v * mk;
-        if (SINK) sa_sink[j] += tt[j] * flux * mk;
-        msa[j] = (sa[j] <= 0 ? 0 : msa[j]) * mk;
-    }
-}
-
-// Infiltration into age class 0: calc_infiltration_rz_transport_iso_kernel (core/infiltration.py:2218-2346)
-// and calc_infiltration_ss_transport_iso_kernel (:2441-2512).  which: 0 matrix -> rz, 1 pf -> rz, 2 pf -> ss.
-template <int W, int E>
-SAS_DEV void inflow(Blk<W> &B, const SasArgs &P, int64_t cell, int which, double (&sa)[E], double (&msa)[E], double mk, int base) {
-    const double inf = ((const double *)P.a[SA_inf_mat_rz + which])[P.day_off + cell];
-    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
-    if (B.tid == 0) {
-        const double C = (inf > 0 ? C_in : 0) * mk;
-        ((double *)P.a[SA_C_inf_mat_rz + which])[cell] = C;
-        ((double *)P.a[SA_C_iso_inf_mat_rz + which])[cell] = conc_to_delta(P, C) * mk;
-    }
-    // tt is 1 in age class 0 and 0 elsewhere.  For the other classes the mixing formula reduces to msa * (sa / sa) + 0 = msa (sa > 0)
-    // or msa (sa <= 0): the identity, bit for bit (a NaN marker stays a NaN) -- only the thread that owns class 0 computes
-    if (base == 0) {
-        const double ttk = (inf > 0 ? 1 : 0) * mk;
-        const double mttk = (inf > 0 ? C_in : 0) * mk;
-        msa[0] = (inf * ttk + sa[0] > 0 ? msa[0] * (sa[0] / (ttk * inf + sa[0])) + mttk * ((ttk * inf) / (inf * ttk + sa[0]))
-                                        : msa[0]) * mk;
-        sa[0] += inf * mk;
-    }
-    if (mk != 1.0) {   // (the reference multiplies every class by maskCatch)
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (base + j != 0) msa[j] = msa[j] * mk;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// bromide: the reference's anion kernels.  msa is solute mass by age; a flux takes
-// mtt = msa / sa * alpha * tt * flux, clipped to [0, msa] (calc_mtt, core/transport.py:583-596).
-// ---------------------------------------------------------------------------------------------
-
-// TT = cumsum(tt) for the age statistics (KEEP) and the diagnostics arrays; mtt may be null (soil evaporation)
-template <int W, int E, bool KEEP>
-SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, int base, const double (&tt)[E], const double *mtt,
-                         Dist<E> &keep) {
-    if (!(P.diag || (KEEP && stats_now(P)))) return;
-    const int A = P.ages;
-    double TT_hi[E], TT_lo;
-    blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-    if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
-    if (P.diag) {
-        double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
-        double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
-        double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
-        if (B.tid == 0) o_TT[0] = 0.0;
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (base + j < A) {
-                o_tt[base + j] = tt[j];
-                if (mtt) o_mtt[base + j] = mtt[j];
-                o_TT[base + j + 1] = TT_hi[j];
-            }
-    }
-}
-
-// One outgoing flux of the anion kernels.  WATER: calc_evaporation_transport_kernel (core/evapotranspiration.py:620-650),
-// the solute stays behind.  Otherwise calc_transpiration_transport_anion_kernel (:905-985),
-// calc_percolation_rz/ss_transport_anion_kernel (core/subsurface_runoff.py:1630-1716, 1823-1893),
-// calc_capillary_rise_rz_transport_anion_kernel (core/capillary_rise.py:503-590).
-template <int W, int E, bool SINK, bool KEEP, bool WATER>
-SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double alpha, double (&sa)[E], double (&msa)[E],
-                           double (&sa_sink)[E], double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
-    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
-    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
-    double tt[E];
-    calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
-    double mtt[E], s[1] = {0.0};
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        tt[j] *= mk;
-        if (!WATER) {
-            double m = (sa[j] > 0 ? msa[j] / sa[j] : 0) * alpha * tt[j] * flux;
-            m = (m <= 0 ? 0 : m);
-            m = (m > msa[j] ? msa[j] : m);
-            mtt[j] = m * mk;
-            s[0] += mtt[j];
-        }
-    }
-    record_dist<W, E, KEEP>(B, P, cell, f, base, tt, WATER ? nullptr : mtt, keep);
-    if (!WATER) {
-        blk_sum<W, 1>(B, s);
-        if (B.tid == 0) {
-            ((double *)P.a[SA_C_evap_soil + f])[cell] = (flux > 0 ? s[0] / flux : 0) * mk;
-            ((double *)P.a[SA_M_evap_soil + f])[cell] = s[0] * mk;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        double v = sa[j] + -flux * tt[j];  // update_sa :599-619
-        v = ((v > -1e-5) && (v < 0)) ? 0 : v;
-        sa[j] = v * mk;
-        if (!WATER) msa[j] += -mtt[j] * mk;
-        if (SINK) {
-            msa_sink[j] += mtt[j] * mk;
-            sa_sink[j] += tt[j] * flux * mk;
-        }
-    }
-}
-
-// calc_infiltration_rz_transport_anion_kernel (core/infiltration.py:2350-2424): matrix and preferential-flow
-// infiltration join age class 0 in one addition; calc_infiltration_ss_transport_anion_kernel (:2516-2566).
-template <int W, int E>
-SAS_DEV void inflow_anion(Blk<W> &B, const SasArgs &P, int64_t cell, bool subsoil, double (&sa)[E], double (&msa)[E], double mk,
-                          int base) {
-    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
-    double d_sa, d_msa;
-    if (!subsoil) {
-        const double im = ((const double *)P.a[SA_inf_mat_rz])[P.day_off + cell];
-        const double ip = ((const double *)P.a[SA_inf_pf_rz])[P.day_off + cell];
-        const double C0 = (im > 0 ? C_in : 0) * mk, C1 = (ip > 0 ? C_in : 0) * mk;
-        const double M0 = C0 * im * mk, M1 = C1 * ip * mk;
-        if (B.tid == 0) {
-            ((double *)P.a[SA_C_inf_mat_rz])[cell] = C0;
-            ((double *)P.a[SA_C_inf_pf_rz])[cell] = C1;
-            ((double *)P.a[SA_M_inf_mat_rz])[cell] = M0;
-            ((double *)P.a[SA_M_inf_pf_rz])[cell] = M1;
-        }
-        d_sa = im + ip * mk;
-        d_msa = M0 + M1 * mk;
-    } else {
-        const double ip = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell];
-        const double C2 = (ip > 0 ? C_in : 0) * mk;
-        const double M2 = C2 * ip * mk;
-        if (B.tid == 0) {
-            ((double *)P.a[SA_C_inf_pf_ss])[cell] = C2;
-            ((double *)P.a[SA_M_inf_pf_ss])[cell] = M2;
-        }
-        d_sa = ip * mk;
-        d_msa = M2 * mk;
-    }
-#pragma unroll
-    for (int j = 0; j < E; ++j)
-        if (base + j == 0) {
-            sa[j] += d_sa;
-            msa[j] += d_msa;
-        }
-}
-
-
-// tt / TT of one flux back from the diagnostics arrays (age statistics in a launch of their own)
-template <int E>
-SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> &D) {
-    const int A = P.ages;
-    const double *g_tt = (const double *)P.a[SA_tt_evap_soil + f] + cell * A;
-    const double *g_TT = (const double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const bool in = base + j < A;
-        D.tt[j] = in ? g_tt[base + j] : 0.0;
-        D.TT_hi[j] = g_TT[in ? base + j + 1 : A];
-    }
-    D.TT_lo = g_TT[base < A ? base : A];
-}
-
-// RH_SAS_WAVES > 0: register budget for that many waves per SIMD (experiments; 0 = compiler's choice)
-#ifndef RH_SAS_WAVES
-#define RH_SAS_WAVES 3
-#endif
-#if RH_SAS_WAVES > 0
-#define SAS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RH_SAS_WAVES, RH_SAS_WAVES)))
-#else
-#define SAS_OCCUPANCY
-#endif
-// Eight age classes per thread (the <2, 8> shape for ages <= 1024, RH_SAS_E8): the scans and lane exchanges of a sub-step are paid
-// once per thread, so twice the classes per thread halve their share; the state then needs the register budget of 2 waves per SIMD.
-#define SAS_OCCUPANCY_E8 __attribute__((amdgpu_waves_per_eu(2, 2)))
-template <int W, int E, bool ANION>
-__device__ __forceinline__ void sas_body(const SasArgs &P);
-template <int W, int E, bool ANION>
-__global__ __launch_bounds__(W * 64) SAS_OCCUPANCY void k_sas(const SasArgs P) {
-    sas_body<W, E, ANION>(P);
-}
-template <int W, bool ANION>
-__global__ __launch_bounds__(W * 64) SAS_OCCUPANCY_E8 void k_sas8(const SasArgs P) {
-    sas_body<W, 8, ANION>(P);
-}
-// Sixteen age classes per thread, ONE wavefront per column (ages <= 1023): no workgroup barrier and no exchange through LDS at all, the
-// scans are the wave's DPP scan plus a running sum over the thread's own classes; the state of a column then takes the register file of
-// a whole SIMD (1 wave/SIMD, 512 registers: VGPRs + AGPRs).  -DRH_SAS_EXPERIMENT_E16 builds ONLY this shape (experiments).
-#define SAS_OCCUPANCY_E16 __attribute__((amdgpu_waves_per_eu(1, 1)))
-template <bool ANION>
-__global__ __launch_bounds__(64) SAS_OCCUPANCY_E16 void k_sas16(const SasArgs P) {
-    sas_body<1, 16, ANION>(P);
-}
-template <int W, int E, bool ANION>
-__device__ __forceinline__ void sas_body(const SasArgs &P) {
-    __shared__ double s_red[2][W][8];
-    __shared__ double s_xch[2][W][2];
-    __shared__ double2 s_logt[64];
-    if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
-    __syncthreads();
-    Blk<W> B;
-    B.logt = s_logt;
-    B.tid = threadIdx.x;
-    B.lane = threadIdx.x & 63;
-    B.wave = threadIdx.x >> 6;
-    B.phase = 0;
-    B.red = s_red;
-    B.xch = s_xch;
-    const int64_t cell = blockIdx.x;
-    const int A = P.ages;
-    const int base = B.tid * E;
-    const double mk = (double)((const int *)P.a[SA_maskCatch])[cell];
-
-    double sa_rz[E], msa_rz[E], sa_ss[E], msa_ss[E];
-    {
-        const double *g0 = (const double *)P.a[SA_sa_rz] + cell * A, *g1 = (const double *)P.a[SA_msa_rz] + cell * A;
-        const double *g2 = (const double *)P.a[SA_sa_ss] + cell * A, *g3 = (const double *)P.a[SA_msa_ss] + cell * A;
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool in = base + j < A;
-            sa_rz[j] = in ? g0[base + j] : 0.0;
-            msa_rz[j] = in ? g1[base + j] : 0.0;
-            sa_ss[j] = in ? g2[base + j] : 0.0;
-            msa_ss[j] = in ? g3[base + j] : 0.0;
-        }
-    }
-    Dist<E> d_transp, d_q_ss;
-    bool have_transp = false, have_q_ss = false;
-    const bool stats = P.stats && (P.stages & RH_SAS_STORAGE);
-
-    // order of svat_transport_model_deterministic :949-991
-    if constexpr (ANION) {
-        const double alpha_q = ((const double *)P.a[SA_alpha_q])[cell];
-        if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, sa_rz, msa_rz, mk, base);
-        if (P.stages & RH_SAS_EVAP) {   // water only -- but the virtual tracer leaves with it at alpha = 1
-            if (P.tracer == RH_SAS_TRACER_VIRTUAL)
-                outflux_anion<W, E, false, false, false>(B, P, cell, 0, 1.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
-            else
-                outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
-        }
-        if (P.stages & RH_SAS_TRANSP) {
-            // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
-            const int lu = ((const int *)P.a[SA_lu_id])[cell];
-            double S[1] = {0.0};
-#pragma unroll
-            for (int j = 0; j < E; ++j) S[0] += sa_rz[j];
-            blk_sum<W, 1>(B, S);
-            const bool stop = (lu > 500) && (lu < 599) && (S[0] >= 0.8 * ((const double *)P.a[SA_S_sat_rz])[cell]);
-            const double alpha = (stop ? 0 : ((const double *)P.a[SA_alpha_transp])[cell]) * mk;
-            outflux_anion<W, E, false, true, false>(B, P, cell, 1, alpha, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
-            have_transp = true;
-        }
-        if (P.stages & RH_SAS_Q_RZ)
-            outflux_anion<W, E, true, false, false>(B, P, cell, 2, alpha_q, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-        if (P.stages & RH_SAS_INF_SS) inflow_anion<W, E>(B, P, cell, true, sa_ss, msa_ss, mk, base);
-        if (P.stages & RH_SAS_Q_SS) {
-            outflux_anion<W, E, false, true, false>(B, P, cell, 3, alpha_q, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
-            have_q_ss = true;
-        }
-        if (P.stages & RH_SAS_CPR)
-            outflux_anion<W, E, true, false, false>(B, P, cell, 4, alpha_q, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
-    } else {
-    if (P.stages & RH_SAS_INF_RZ) {
-        inflow<W, E>(B, P, cell, 0, sa_rz, msa_rz, mk, base);
-        inflow<W, E>(B, P, cell, 1, sa_rz, msa_rz, mk, base);
-    }
-    if (P.stages & RH_SAS_EVAP) outflux<W, E, false, false>(B, P, cell, 0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
-    if (P.stages & RH_SAS_TRANSP) {
-        outflux<W, E, false, true>(B, P, cell, 1, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
-        have_transp = true;
-    }
-    if (P.stages & RH_SAS_Q_RZ) outflux<W, E, true, false>(B, P, cell, 2, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-    if (P.stages & RH_SAS_INF_SS) inflow<W, E>(B, P, cell, 2, sa_ss, msa_ss, mk, base);
-    if (P.stages & RH_SAS_Q_SS) {
-        outflux<W, E, false, true>(B, P, cell, 3, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
-        have_q_ss = true;
-    }
-    if (P.stages & RH_SAS_CPR) outflux<W, E, true, false>(B, P, cell, 4, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
-    }
-
-    if (P.stages & RH_SAS_STORAGE) {
-        // calc_root_zone_transport_iso_kernel (core/root_zone.py:189-217), calc_subsoil_transport_iso_kernel
-        // (core/subsoil.py:159-188), calculate_soil_transport_iso_kernel (core/soil.py:1036-1090)
-        double sa_s[E], msa_s[E];
-        double s[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            sa_rz[j] = (sa_rz[j] < 1e-8 ? 0 : sa_rz[j]);
-            sa_ss[j] = (sa_ss[j] < 1e-8 ? 0 : sa_ss[j]);
-            sa_s[j] = sa_rz[j] + sa_ss[j] * mk;
-            if constexpr (ANION) {
-                // calc_root_zone/subsoil_transport_anion_kernel (core/root_zone.py:221-258, subsoil.py:186-223),
-                // calculate_soil_transport_anion_kernel (core/soil.py:1094-1142): M = nansum(msa), C = M / sum(sa)
-                msa_rz[j] = (sa_rz[j] <= 0 ? 0 : msa_rz[j]);
-                msa_ss[j] = (sa_ss[j] <= 0 ? 0 : msa_ss[j]);
-                msa_s[j] = msa_rz[j] + msa_ss[j] * mk;
-                s[0] += (msa_rz[j] != msa_rz[j]) ? 0 : msa_rz[j];
-                s[2] += (msa_ss[j] != msa_ss[j]) ? 0 : msa_ss[j];
-                s[4] += (msa_s[j] != msa_s[j]) ? 0 : msa_s[j];
-            } else {
-                const double tot = sa_rz[j] + sa_ss[j];
-                const UDiv by_tot = udiv_prepare(tot);
-                const double v = (tot > 0 ? msa_rz[j] * udiv(sa_rz[j], by_tot) + msa_ss[j] * udiv(sa_ss[j], by_tot) : 0);
-                msa_s[j] = (v != v) ? 0 : v;
-                s[0] += msa_rz[j] * sa_rz[j];
-                s[2] += msa_ss[j] * sa_ss[j];
-                s[4] += msa_s[j] * sa_s[j];
-            }
-            s[1] += sa_rz[j];
-            s[3] += sa_ss[j];
-            s[5] += sa_s[j];
-        }
-        blk_sum<W, 6>(B, s);
-        if (B.tid == 0) {
-            for (int k = 0; k < 3; ++k) {
-                if constexpr (ANION) {
-                    const double M = s[2 * k] * mk;
-                    ((double *)P.a[SA_M_rz + k])[cell] = M;
-                    ((double *)P.a[SA_C_rz + k])[cell] = (s[2 * k + 1] > 0 ? M / s[2 * k + 1] : 0);
-                } else {  // calc_conc_iso_storage :538-562
-                    const double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0) * mk;
-                    ((double *)P.a[SA_C_rz + k])[cell] = C;
-                    ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
-                }
-            }
-        }
-        if (P.diag) {
-            double *o0 = (double *)P.a[SA_sa_s] + cell * A, *o1 = (double *)P.a[SA_msa_s] + cell * A;
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                if (base + j < A) {
-                    o0[base + j] = sa_s[j];
-                    o1[base + j] = msa_s[j];
-                }
-        }
-        if (stats) {  // calculate_age_statistics_* :59-312
-            // stages run one launch at a time: the distributions come back from the diagnostics arrays
-            if (!have_transp) {
-                Dist<E> d;
-                load_dist<E>(P, cell, base, 1, d);
-                age_stats<W, E>(B, P, cell, base, d.TT_hi, d.TT_lo, d.tt, SA_tt10_transp, false);
-            }
-            if (!have_q_ss) {
-                Dist<E> d;
-                load_dist<E>(P, cell, base, 3, d);
-                age_stats<W, E>(B, P, cell, base, d.TT_hi, d.TT_lo, d.tt, SA_tt10_q_ss, false);
-            }
-            // the reference never assigns rt10 / rt90 of root zone and subsoil (:181-196, :232-247)
-            residence_stats<W, E>(B, P, cell, base, sa_rz, mk, SA_rt10_rz, true);
-            residence_stats<W, E>(B, P, cell, base, sa_ss, mk, SA_rt10_ss, true);
-            residence_stats<W, E>(B, P, cell, base, sa_s, mk, SA_rt10_s, false);
-        }
-    }
-
-    if (P.stages & RH_SAS_RESCALE) {
-        // rescale_sa_msa_iso_soil_kernel, core/soil.py:1250-1395 (no maskCatch on sa and C here, as in the reference)
-        const double S_rz_init = ((const double *)P.a[SA_S_rz_init])[cell], S_ss_init = ((const double *)P.a[SA_S_ss_init])[cell];
-        double t[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            t[0] += sa_rz[j];
-            t[1] += sa_ss[j];
-        }
-        blk_sum<W, 2>(B, t);
-        double sa_s[E], msa_s[E], s[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool in = base + j < A;
-            sa_rz[j] = in ? S_rz_init * (sa_rz[j] / t[0]) : 0.0;
-            sa_ss[j] = in ? S_ss_init * (sa_ss[j] / t[1]) : 0.0;
-            sa_s[j] = sa_rz[j] + sa_ss[j];
-            if constexpr (ANION) {
-                if (P.tracer != RH_SAS_TRACER_BROMIDE) {  // rescale_sa_msa_anion_soil_kernel, chloride / virtual tracer (core/soil.py:1507-1640):
-                    msa_rz[j] *= S_rz_init / t[0];         // the solute is scaled with the water
-                    msa_ss[j] *= S_ss_init / t[1];
-                } else {  // bromide (:1399-1506): the soil starts free of it
-                    msa_rz[j] = 0;
-                    msa_ss[j] = 0;
-                }
-            }
-            const double tot = sa_rz[j] + sa_ss[j];
-            const double v = (tot > 0 ? msa_rz[j] * (sa_rz[j] / tot) + msa_ss[j] * (sa_ss[j] / tot) : 0);
-            msa_s[j] = ((v != v) || (base + j == 0)) ? 0 : v;
-            if constexpr (ANION) {
-                if (P.tracer != RH_SAS_TRACER_BROMIDE) {   // C = sum(msa) / sum(sa), msa_s = msa_rz + msa_ss
-                    msa_s[j] = msa_rz[j] + msa_ss[j];
-                    s[0] += msa_rz[j];
-                    s[2] += msa_ss[j];
-                    s[4] += msa_s[j];
-                    s[1] += sa_rz[j];
-                    s[3] += sa_ss[j];
-                    s[5] += sa_s[j];
-                    continue;
-                }
-            }
-            s[0] += msa_rz[j] * sa_rz[j];
-            s[1] += sa_rz[j];
-            s[2] += msa_ss[j] * sa_ss[j];
-            s[3] += sa_ss[j];
-            s[4] += msa_s[j] * sa_s[j];
-            s[5] += sa_s[j];
-        }
-        blk_sum<W, 6>(B, s);
-        if (B.tid == 0) {
-            for (int k = 0; k < 3; ++k) {
-                double C = (s[2 * k + 1] > 0 ? s[2 * k] / s[2 * k + 1] : 0);
-                if (ANION && P.tracer != RH_SAS_TRACER_BROMIDE) C = s[2 * k] / s[2 * k + 1];   // unguarded, M_* untouched
-                ((double *)P.a[SA_C_rz + k])[cell] = C;
-                if constexpr (ANION) {
-                    if (P.tracer == RH_SAS_TRACER_BROMIDE) ((double *)P.a[SA_M_rz + k])[cell] = 0.0;
-                } else {
-                    ((double *)P.a[SA_C_iso_rz + k])[cell] = conc_to_delta(P, C) * mk;
-                }
-            }
-        }
-        if (P.diag) {
-            double *o0 = (double *)P.a[SA_sa_s] + cell * A, *o1 = (double *)P.a[SA_msa_s] + cell * A;
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                if (base + j < A) {
-                    o0[base + j] = sa_s[j];
-                    o1[base + j] = msa_s[j];
-                }
-        }
-    }
-
-    if (P.stages & RH_SAS_AGEING) {
-        if constexpr (ANION) {
-            ageing_anion<W, E>(B, A, base, sa_rz, msa_rz);
-            ageing_anion<W, E>(B, A, base, sa_ss, msa_ss);
-        } else {
-            ageing<W, E>(B, A, base, sa_rz, msa_rz);
-            ageing<W, E>(B, A, base, sa_ss, msa_ss);
-        }
-    }
-
-    {
-        double *g0 = (double *)P.a[SA_sa_rz] + cell * A, *g1 = (double *)P.a[SA_msa_rz] + cell * A;
-        double *g2 = (double *)P.a[SA_sa_ss] + cell * A, *g3 = (double *)P.a[SA_msa_ss] + cell * A;
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (base + j < A) {
-                g0[base + j] = sa_rz[j];
-                g1[base + j] = msa_rz[j];
-                g2[base + j] = sa_ss[j];
-                g3[base + j] = msa_ss[j];
-            }
-    }
-}
 
 __global__ void k_selftest_div(const double *a, const double *d, double *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,22 +104,6 @@ static int64_t sas_elems(const rh_sas_config &c, int a) {
     case K_MASK: return c.n_cells;
     }
     return 0;
-}
-
-template <int W, int E>
-static void launch_sas(rh_sas_ctx *ctx, const SasArgs &args) {
-    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18)
-        hipLaunchKernelGGL((k_sas<W, E, true>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
-    else
-        hipLaunchKernelGGL((k_sas<W, E, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
-}
-
-template <int W>
-static void launch_sas8(rh_sas_ctx *ctx, const SasArgs &args) {
-    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18)
-        hipLaunchKernelGGL((k_sas8<W, true>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
-    else
-        hipLaunchKernelGGL((k_sas8<W, false>), dim3((unsigned)ctx->cfg.n_cells), dim3(W * 64), 0, ctx->stream, args);
 }
 
 extern "C" {
@@ -938,42 +332,22 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
         // the explicit solvers evaluate all fluxes of a sub-step on one state: the day cannot be cut into stages
         if (stages != RH_SAS_ALL)
             return sfail(ctx, RH_ERR_ARG, "rh_sas_stages: with an explicit solver the day runs in one launch (RH_SAS_ALL); only RH_SAS_RESCALE may run on its own");
-        const int rc = rh_sas_launch_solver(c.solver, ctx->stream, args);
+        const bool anion = c.tracer != RH_SAS_TRACER_OXYGEN18;
+        const int rc = c.solver == RH_SAS_SOLVER_RK4 ? (anion ? rh_sas_launch_rk4_anion : rh_sas_launch_rk4_iso)(ctx->stream, args)
+                                                     : (anion ? rh_sas_launch_euler_anion : rh_sas_launch_euler_iso)(ctx->stream, args);
         if (rc) return sfail(ctx, rc, "rh_sas_stages: unknown solver");
         SHIPCHK(ctx, hipGetLastError());
         if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
         return RH_OK;
     }
-    // smallest workgroup whose blocked layout covers the ages + 1 edges: waves x classes per thread
-    const int nages = c.ages + 1;
-    // eight classes per thread from 257 age classes on (9.63 against 10.17 ms per day at 10^5 columns x 1000 ages); RH_SAS_E4=1: the
-    // four-class shapes for comparison
-#ifdef RH_SAS_EXPERIMENT_E16
-    if (nages > 1024) return sfail(ctx, RH_ERR_ARG, "RH_SAS_EXPERIMENT_E16: ages <= 1023 only");
-    if (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18) hipLaunchKernelGGL((k_sas16<true>), dim3((unsigned)ctx->cfg.n_cells), dim3(64), 0, ctx->stream, args);
-    else hipLaunchKernelGGL((k_sas16<false>), dim3((unsigned)ctx->cfg.n_cells), dim3(64), 0, ctx->stream, args);
-    SHIPCHK(ctx, hipGetLastError());
-    if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
-    return RH_OK;
-#else
+    // smallest workgroup whose blocked layout covers the ages + 1 edges (rh_sas_kernels.h; the isotope and the anion kernels are
+    // translation units of their own, rh_sas_det_iso.hip / rh_sas_det_anion.hip)
     static const bool e4 = std::getenv("RH_SAS_E4") != nullptr;
-    if (!e4 && nages > 256 && nages <= 4096) {
-        if (nages <= 512) launch_sas8<1>(ctx, args);
-        else if (nages <= 1024) launch_sas8<2>(ctx, args);
-        else if (nages <= 2048) launch_sas8<4>(ctx, args);
-        else launch_sas8<8>(ctx, args);
-    } else
-    if (nages <= 64) launch_sas<1, 1>(ctx, args);
-    else if (nages <= 128) launch_sas<1, 2>(ctx, args);
-    else if (nages <= 256) launch_sas<1, 4>(ctx, args);
-    else if (nages <= 512) launch_sas<2, 4>(ctx, args);
-    else if (nages <= 1024) launch_sas<4, 4>(ctx, args);
-    else if (nages <= 2048) launch_sas<8, 4>(ctx, args);
-    else launch_sas<16, 4>(ctx, args);
+    const int lrc = (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18 ? rh_sas_launch_det_anion : rh_sas_launch_det_iso)(ctx->stream, args, (unsigned)ctx->cfg.n_cells, c.ages + 1, e4);
+    if (lrc) return sfail(ctx, lrc, "rh_sas_stages: the age axis does not fit the kernel shapes of this build");
     SHIPCHK(ctx, hipGetLastError());
     if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     return RH_OK;
-#endif
 }
 
 int rh_sas_step(rh_sas_ctx *ctx, int64_t day) { return rh_sas_stages(ctx, day, RH_SAS_ALL); }

@@ -1,5 +1,5 @@
-// rh_sas_dev.h -- device-side building blocks shared by the SAS kernels: rh_sas.hip (deterministic solver) and
-// rh_sas_solvers.hip (explicit Euler / RK4 solvers).  Everything here is inlined into the kernels of the including
+// rh_sas_dev.h -- device-side building blocks shared by the SAS kernels: rh_sas_kernels.h (deterministic solver) and
+// rh_sas_solvers_impl.h (explicit Euler / RK4 solvers).  Everything here is inlined into the kernels of the including
 // translation unit; constants and the one out-of-line function are `static` so that the two units do not clash at link time.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -679,5 +679,11 @@ SAS_DEV void ageing(Blk<W> &B, int A, int base, double (&sa)[E], double (&msa)[E
     }
 }
 
-// rh_sas_solvers.hip: the whole day of an explicit solver (RH_SAS_SOLVER_EULER, _RK4) in one launch on `stream`
-int rh_sas_launch_solver(int solver, hipStream_t stream, const SasArgs &args);
+// the whole day (deterministic: the stages in args.stages) in one launch on `stream`, per kernel family:
+// launchers of the kernel translation units (host functions)
+int rh_sas_launch_det_iso(hipStream_t stream, const SasArgs &args, unsigned n_cells, int nages, bool e4);
+int rh_sas_launch_det_anion(hipStream_t stream, const SasArgs &args, unsigned n_cells, int nages, bool e4);
+int rh_sas_launch_euler_iso(hipStream_t stream, const SasArgs &args);
+int rh_sas_launch_euler_anion(hipStream_t stream, const SasArgs &args);
+int rh_sas_launch_rk4_iso(hipStream_t stream, const SasArgs &args);
+int rh_sas_launch_rk4_anion(hipStream_t stream, const SasArgs &args);

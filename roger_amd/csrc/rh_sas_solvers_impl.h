@@ -1,4 +1,4 @@
-// rh_sas_solvers.hip -- the explicit solvers of the SAS / oxygen-18 transport step (settings.sas_solver = "Euler", "RK4") for gfx950.
+// rh_sas_solvers_impl.h -- the explicit solvers of the SAS / oxygen-18 transport step (settings.sas_solver = "Euler", "RK4") for gfx950.
 //
 // The reference's explicit Euler scheme (svat_transport_model_euler, roger/core/transport.py:2064-2414, driven by
 // calculate_storage_selection :3220-3262) splits the day into `substeps` sub-steps of length h = 1 / substeps.  In each of them
@@ -12,9 +12,10 @@
 // Concentrations of the fluxes, the age statistics and the diagnostics arrays are those of the LAST sub-step (each sub-step overwrites
 // them in the reference); the day ends with the ageing.
 //
-// Same layout as the deterministic kernel (rh_sas.hip): one workgroup per column, thread t owns E consecutive age classes of the four
+// Same layout as the deterministic kernel (rh_sas_kernels.h): one workgroup per column, thread t owns E consecutive age classes of the four
 // state vectors in registers for the whole day -- one read and one write of the state per column and day.  The five fluxes run
 // through ONE call site of the SAS function (a loop over the fluxes, uniform branches) to keep the code small.
+#pragma once
 #include "rh_sas_dev.h"
 
 // The f-th of five consecutive arrays of the kernel argument.  Indexing `P.a[first + f]` with a run-time f would make the compiler copy
@@ -639,28 +640,24 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     }
 }
 
-template <int W, int E>
-static void launch_explicit(int solver, hipStream_t stream, const SasArgs &args) {
-    const bool anion = args.tracer != RH_SAS_TRACER_OXYGEN18;
-    const dim3 grid((unsigned)args.n), block(W * 64);
-    if (solver == RH_SAS_SOLVER_RK4) {
-        if (anion) hipLaunchKernelGGL((k_sas_rk4<W, E, true>), grid, block, 0, stream, args);
-        else hipLaunchKernelGGL((k_sas_rk4<W, E, false>), grid, block, 0, stream, args);
-    } else {
-        if (anion) hipLaunchKernelGGL((k_sas_euler<W, E, true>), grid, block, 0, stream, args);
-        else hipLaunchKernelGGL((k_sas_euler<W, E, false>), grid, block, 0, stream, args);
-    }
-}
-
+#ifdef RH_SOLVER_RK4   // this unit's kernels: RH_SOLVER_RK4 0 / 1 (Euler / RK4), RH_SOLVER_ANION 0 / 1
 // The whole day of an explicit solver in one launch; the smallest workgroup whose blocked layout covers the age classes.
-int rh_sas_launch_solver(int solver, hipStream_t stream, const SasArgs &args) {
-    if (solver != RH_SAS_SOLVER_EULER && solver != RH_SAS_SOLVER_RK4) return RH_ERR_ARG;
+int RH_SOLVER_NAME(hipStream_t stream, const SasArgs &args) {
+    constexpr bool AN = RH_SOLVER_ANION != 0;
+    const dim3 grid((unsigned)args.n);
+#if RH_SOLVER_RK4
+#define RH_LX(W, E) hipLaunchKernelGGL((k_sas_rk4<W, E, AN>), grid, dim3(W * 64), 0, stream, args)
+#else
+#define RH_LX(W, E) hipLaunchKernelGGL((k_sas_euler<W, E, AN>), grid, dim3(W * 64), 0, stream, args)
+#endif
     const int nages = args.ages + 1;
-    if (nages <= 64) launch_explicit<1, 1>(solver, stream, args);
-    else if (nages <= 256) launch_explicit<1, 4>(solver, stream, args);
-    else if (nages <= 512) launch_explicit<2, 4>(solver, stream, args);
-    else if (nages <= 1024) launch_explicit<4, 4>(solver, stream, args);
-    else if (nages <= 2048) launch_explicit<8, 4>(solver, stream, args);
-    else launch_explicit<8, 8>(solver, stream, args);   // (sixteen waves would leave 128 registers per thread: 700 spilled)
+    if (nages <= 64) RH_LX(1, 1);
+    else if (nages <= 256) RH_LX(1, 4);
+    else if (nages <= 512) RH_LX(2, 4);
+    else if (nages <= 1024) RH_LX(4, 4);
+    else if (nages <= 2048) RH_LX(8, 4);
+    else RH_LX(8, 8);   // (sixteen waves would leave 128 registers per thread: 700 spilled)
+#undef RH_LX
     return RH_OK;
 }
+#endif

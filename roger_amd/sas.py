@@ -2,7 +2,7 @@
 backend: what `SVATOXYGEN18_benchmark.py` does in `set_parameters_setup`, `set_initial_conditions`
 and `set_forcing`, written against the C ABI of include/roger_hip_sas.h.
 
-The product path: there is no CPU implementation here; every step runs in rh_sas.hip."""
+The product path: there is no CPU implementation here; every step runs in the kernels of csrc/rh_sas_kernels.h / rh_sas_solvers_impl.h."""
 import numpy as np
 
 from . import _native

@@ -1,4 +1,4 @@
-"""GPU parity of the SAS / oxygen-18 transport step (roger_amd/csrc/rh_sas.hip through the C ABI of
+"""GPU parity of the SAS / oxygen-18 transport step (roger_amd/csrc/rh_sas_kernels.h through the C ABI of
 include/roger_hip_sas.h) against the reference's golden vectors and against the CPU oracle.
 
 Tolerance (fp64): rtol 1e-10, atol 1e-12 on every output, NaN patterns identical.  The kernel keeps
@@ -266,7 +266,7 @@ def test_gamma_and_reversed_exponential_against_oracle():
 
 
 def test_power_function_accuracy():
-    """The kernel's own x**k (2**(k * log2 x), rh_sas.hip:sas_pow) against the host's pow over the argument range of
+    """The kernel's own x**k (2**(k * log2 x), rh_sas_dev.h:sas_pow) against the host's pow over the argument range of
     the power-law SAS function: relative error < 2e-14 * max(1, k) for x down to 1e-21, exact 1 at x == 1."""
     from roger_amd import _native
 
@@ -365,7 +365,7 @@ def test_rescale_after_warmup():
 
 
 def test_hoisted_division_is_ieee_division():
-    """The sub-step loop divides by flux * h through a hoisted refined reciprocal (rh_sas.hip: udiv); its quotients
+    """The sub-step loop divides by flux * h through a hoisted refined reciprocal (rh_sas_dev.h: udiv); its quotients
     must be the correctly rounded ones, bit for bit, over the operand range of the loop (q from 0 and 1e-18 mm up,
     flux * h from 1e-6 to 1e2 mm)."""
     from roger_amd import _native
@@ -404,7 +404,7 @@ def test_closed_form_exponents_against_oracle():
         ctx.close()
 
 
-# ---- settings.sas_solver = "Euler" (roger_amd/csrc/rh_sas_solvers.hip) -----------------------------------------------------------
+# ---- settings.sas_solver = "Euler" (roger_amd/csrc/rh_sas_solvers_impl.h) -----------------------------------------------------------
 @pytest.mark.parametrize("case", [c for c in SOLVER_CASES if os.path.exists(os.path.join(GOLDEN, f"{c}.npz"))])
 def test_explicit_solver_single_days_from_reference_states(case):
     """Each day of the reference's run with an explicit solver (svat_transport_model_euler, transport.py:2064-2414; _rk4 :1139-2047) restarted

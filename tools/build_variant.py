@@ -2,7 +2,7 @@
 """Builds a kernel variant next to the product library, for A/B measurements on the GPU box:
 
     python tools/build_variant.py nt3 -DRH_NT=3                          -> roger_amd/variants/libroger_hip_nt3.so
-    python tools/build_variant.py ew4 --unit rh_sas_solvers -DRH_EULER_WAVES=4    (only that unit is recompiled with the flags)
+    python tools/build_variant.py ew4 --unit rh_sas_euler_iso -DRH_EULER_WAVES=4    (only that unit is recompiled with the flags)
     ROGER_HIP_LIB=roger_amd/variants/libroger_hip_nt3.so python bench.py ...
 
 (roger_amd/variants/ is git-ignored; it travels with gpurun like the product .so.)"""

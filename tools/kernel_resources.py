@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / scratch / LDS use of every kernel of a translation unit (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python tools/kernel_resources.py roger_hip [pattern]      # or rh_sas
+    python tools/kernel_resources.py roger_hip [pattern]      # or rh_sas_det_iso, rh_sas_rk4_anion, ... (roger_amd/build.py UNITS)
 """
 import os
 import re
