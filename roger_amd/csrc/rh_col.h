@@ -123,7 +123,7 @@ struct StepCtx {
     int cond_time;
     int64_t dt_secs_prelim;
     int64_t itt_day;
-    int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 0: k_select did
+    int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 2: from the per-cell aggregates; 0: k_select did
     int forc_exhausted;   // the device-side set_forcing hook found midnight beyond the end of the resident series
 };
 

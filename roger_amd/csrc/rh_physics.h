@@ -1252,10 +1252,11 @@ RH_DEV void rt_select_prec_ta(Col &c, const StepCtx &X, double prec_v, double ta
     }
 }
 // the same selection inside the fused kernel (summary path, shared forcing: the selected values are uniform)
-RH_DEV void rt_select_prec(Col &c, const StepCtx &X) {
+// (prec_v / ta_v: X.prec_sel / X.ta_sel, or the column's own aggregates when the per-cell selection was deferred to this kernel)
+RH_DEV void rt_select_prec(Col &c, const StepCtx &X, double prec_v, double ta_v) {
     if (X.apply_sel && X.sel_p >= 0) {
-        c.prec = X.prec_sel;
-        c.ta = X.ta_sel;
+        c.prec = prec_v;
+        c.ta = ta_v;
     }
 }
 // pet/ta for the final step class (cond6..cond11) and the residual PET, :262-376
@@ -1316,7 +1317,7 @@ RH_DEV bool rt_routed_c_after(Col &c, const Consts &K, const StepCtx &X) {   // 
     return bad;
 }
 RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
-    rt_select_prec(c, X);
+    rt_select_prec(c, X, X.prec_sel, X.ta_sel);
     rt_select_pet(c, X, pet_v, ta_v);
     const bool bad = rt_step_core(c, K, X);
     rt_after_timestep(c);
@@ -1324,7 +1325,7 @@ RH_DEV bool rt_step(Col &c, const Consts &K, const StepCtx &X, double pet_v, dou
 }
 // first step of a month: `set_parameters` re-derives the surface parameters (svat.py:115-120)
 RH_DEV bool rt_step_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
-    rt_select_prec(c, X);
+    rt_select_prec(c, X, X.prec_sel, X.ta_sel);
     rt_select_pet(c, X, pet_v, ta_v);
     rt_params_surface(c, L, X);
     const bool bad = rt_step_core(c, K, X);
@@ -1332,14 +1333,14 @@ RH_DEV bool rt_step_monthly(Col &c, const Consts &K, const StepCtx &X, const Lut
     return bad;
 }
 RH_DEV bool rt_step_lateral(Col &c, const Consts &K, const StepCtx &X, double pet_v, double ta_v) {
-    rt_select_prec(c, X);
+    rt_select_prec(c, X, X.prec_sel, X.ta_sel);
     rt_select_pet(c, X, pet_v, ta_v);
     const bool bad = rt_step_core_lateral(c, K, X);
     rt_after_timestep_oned(c);
     return bad;
 }
 RH_DEV bool rt_step_lateral_monthly(Col &c, const Consts &K, const StepCtx &X, const Luts &L, double pet_v, double ta_v) {
-    rt_select_prec(c, X);
+    rt_select_prec(c, X, X.prec_sel, X.ta_sel);
     rt_select_pet(c, X, pet_v, ta_v);
     rt_params_surface(c, L, X);
     const bool bad = rt_step_core_lateral(c, K, X);

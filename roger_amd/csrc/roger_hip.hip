@@ -130,6 +130,7 @@ struct rh_ctx {
     bool summary_valid;   // the summary word (words[3]) describes the columns as they are in the arena now
     bool routed_summary = false;     // routing: sumw holds the summary bits of the arena's state (posted by k_routed_a2)
     bool routed_device_ok = true;    // RH_ROUTED_BY_ROUTINE: rh_run_steps takes rh_step_routed per step (A/B, tests)
+    bool defer_select_ok = true;     // RH_NO_DEFERRED_SELECT: k_select stores the per-cell prec / ta itself (A/B, tests)
     bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
     int pending_hooks;    // ... formed with / without the device-side hooks
     bool tail_ok;         // RH_NO_TAIL_CTRL unset
@@ -589,7 +590,12 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
 
-__global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
+// mode: RH_SELECT_M1_PENDING = the tau -> taum1 copies of the last fused step are still pending (lazy rotation): prec_m1 / swe_m1 are
+// the tau planes as they stand; RH_SELECT_DEFER = the selected prec / ta are not stored, the fused kernel applies the selection itself
+// (StepCtx.apply_sel = 2) -- the planes stay untouched between two fused steps, so the rotation can stay pending
+#define RH_SELECT_M1_PENDING 1
+#define RH_SELECT_DEFER 2
+__global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D, int mode) {
     const Consts K = D->K;
     const StepCtx X = D->X;
     const bool per_cell = D->per_cell != 0;
@@ -599,17 +605,24 @@ __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D) {
         rh_ld(a, RH_P_prec, i, c.prec);
         rh_ld(a, RH_P_ta, i, c.ta);
         double prec_m1, swe, swe_top, swe_m1;
-        rh_ld(a, RH_P_prec_m1, i, prec_m1);
         rh_ld(a, RH_P_swe, i, swe);
         rh_ld(a, RH_P_swe_top, i, swe_top);
-        rh_ld(a, RH_P_swe_m1, i, swe_m1);
+        if (mode & RH_SELECT_M1_PENDING) {
+            prec_m1 = c.prec;
+            swe_m1 = swe;
+        } else {
+            rh_ld(a, RH_P_prec_m1, i, prec_m1);
+            rh_ld(a, RH_P_swe_m1, i, swe_m1);
+        }
         if (X.sel_p >= 0) {
             if (per_cell)
                 rt_select_prec_ta(c, X, cell_agg(D, a.n, i, 3 * X.sel_p), cell_agg(D, a.n, i, 3 * X.sel_p + 1));
             else
                 rt_select_prec_ta(c, X, X.prec_sel, X.ta_sel);
-            rh_st(a, RH_P_prec, i, c.prec);
-            rh_st(a, RH_P_ta, i, c.ta);
+            if (!(mode & RH_SELECT_DEFER)) {
+                rh_st(a, RH_P_prec, i, c.prec);
+                rh_st(a, RH_P_ta, i, c.ta);
+            }
         }
         const bool warm = c.ta > K.ta_fm;
         b |= ((c.prec > 0) && warm) ? BIT(PC_RAIN) : 0;
@@ -637,12 +650,12 @@ RH_DEV void infiltration_conds(const rh_scalars &S, StepCtx &X, unsigned long lo
 
 // adaptive_time_stepping.py:192-373, scalar part
 RH_DEV void scalars_body(DevState *D, unsigned long long w, int do_finish, int apply_sel);
-__global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce, int do_finish) {
+__global__ __launch_bounds__(RH_BLOCK) void k_scalars(DevState *D, int do_reduce, int do_finish, int apply_sel = 0) {
     unsigned long long w = 0;
     if (do_reduce) w = reduce_bflags(D->bflags[1], D->pred_blocks);
     if (threadIdx.x != 0) return;
     if (!do_reduce) w = D->words[1];
-    scalars_body(D, w, do_finish, 0);
+    scalars_body(D, w, do_finish, apply_sel);
 }
 // agg[3 * sel + off] without a dynamic index (which would put the whole step context into scratch memory)
 RH_DEV double agg_pick(const StepCtx &X, int sel, int off) {
@@ -1084,7 +1097,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 #if RH_STEP_PREFETCH
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
     RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)  \
-    rt_select_prec(c, X); RH_STORES(seq, rt_select_prec)                                                 \
+    rt_select_prec(c, X, prec_s, ta_s); RH_STORES(seq, rt_select_prec)                                                \
     rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
     q = summary_bits_pt(c.prec, c.ta, K);                                                                \
     MON_RUN                                                                                              \
@@ -1129,7 +1142,7 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // q_pt / q_sw: the column's summary values for the next step's predicates, sampled where they are final
 // (tools/gen_sets.py asserts that no later stage assigns them)
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
-    RH_DBG_SEL(RH_STAGE(seq, rt_select_prec, rt_select_prec(c, X)))                                      \
+    RH_DBG_SEL(RH_STAGE(seq, rt_select_prec, rt_select_prec(c, X, prec_s, ta_s)))                                     \
     RH_STAGE(seq, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))                                       \
     RH_DBG_SUM(q = summary_bits_pt(c.prec, c.ta, K);)                                                    \
     MON_LOADS MON_RUN                                                                                    \
@@ -1175,6 +1188,13 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
         ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
     }
+    double prec_s = X.prec_sel, ta_s = X.ta_sel;   // the column's own when the per-cell selection was deferred to this kernel
+#ifndef RH_CENSUS   // (tools/isa_census.py counts the step with shared forcing: these two loads belong to the per-cell path only)
+    if (X.apply_sel == 2 && D->per_cell && X.sel_p >= 0) {
+        prec_s = cell_agg(D, a.n, i, 3 * X.sel_p);
+        ta_s = cell_agg(D, a.n, i, 3 * X.sel_p + 1);
+    }
+#endif
     if (MONTHLY && LATERAL) {
         RH_STEP_BODY(step_lateral_monthly, rt_params_surface, RH_LOADS(step_lateral_monthly, rt_params_surface),
                      rt_params_surface(c, D->L, X); RH_STORES(step_lateral_monthly, rt_params_surface),
@@ -1360,13 +1380,13 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_a2(Arena a, 
 #else
     if (D->monthly != 0) {
 #endif
-        RH_PSTAGE(routed_a2_monthly, rt_select_prec, rt_select_prec(c, X))
+        RH_PSTAGE(routed_a2_monthly, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
         RH_PSTAGE(routed_a2_monthly, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
         q = summary_bits_pt(c.prec, c.ta, K);
         RH_PSTAGE(routed_a2_monthly, rt_params_surface, rt_params_surface(c, D->L, X))
         RH_ROUTED_A2_TAIL(routed_a2_monthly)
     } else {
-        RH_PSTAGE(routed_a2, rt_select_prec, rt_select_prec(c, X))
+        RH_PSTAGE(routed_a2, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
         RH_PSTAGE(routed_a2, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
         q = summary_bits_pt(c.prec, c.ta, K);
         RH_ROUTED_A2_TAIL(routed_a2)
@@ -1898,6 +1918,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->pending_hooks = 0;
     ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
     ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
+    ctx->defer_select_ok = std::getenv("RH_NO_DEFERRED_SELECT") == nullptr;
     ctx->grp_shift = 6;
     while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
     ctx->summary_valid = false;
@@ -2345,7 +2366,7 @@ int rh_subsurface_routing(rh_ctx *ctx) { return route_all(ctx, 1); }
 #define LAUNCH_PRED(ctx, kern)                                                                                           \
     do {                                                                                                                 \
         planes_touched(ctx);                                                                                             \
-        hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev); \
+        hipLaunchKernelGGL(kern, dim3((ctx)->pred_blocks), dim3(RH_BLOCK), 0, (ctx)->stream, (ctx)->arena, (ctx)->dev, 0); \
     } while (0)
 
 // the next pair of timing events (rh_enable_timing): they ride on a kernel's own dispatch (hipExtLaunchKernelGGL)
@@ -2487,16 +2508,24 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         launch_hooks(ctx);
         hooks = 0;
     }
-    planes_touched(ctx);
+    // None of the kernels in front of the fused one writes a plane: the selected prec / ta are applied inside the fused kernel
+    // (apply_sel = 2, from the per-cell aggregates), the predicate kernels read tau planes only -- with the rotation pending, prec_m1 /
+    // swe_m1 are the tau planes themselves.  So the fused kernel keeps its lazy rotation in the per-cell path too.
+    ctx->summary_valid = false;
+    ctx->pending_valid = false;
+    ctx->exch_valid = false;
     hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
     ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
-    if (ctx->per_cell) {   // (does not touch the planes: no LAUNCH_CELLS)
+    if (ctx->per_cell) {
         hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
         ctx->agg_daily_stale = false;
     }
-    LAUNCH_PRED(ctx, k_select);
-    LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1);
+    const bool defer = ctx->per_cell && ctx->defer_select_ok;   // (shared forcing on this path, e.g. before the series is resident: k_select stores)
+    if (!defer) planes_touched(ctx);
+    hipLaunchKernelGGL(k_select, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev,
+                       (ctx->m1_stale ? RH_SELECT_M1_PENDING : 0) | (defer ? RH_SELECT_DEFER : 0));
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1, defer ? 2 : 0);
     int rc = launch_fused_kernel(ctx, monthly);
     if (rc) return rc;
     CHECK_LAUNCH(ctx);

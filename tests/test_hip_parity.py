@@ -650,3 +650,29 @@ def test_month_change_inside_device_driven_steps(native, oracle, case):
         compare_bulk(H.download_snapshot(ctx, names), st.snapshot(names), names, what=f"{case} step {step}")
     assert changed == 1 and not np.array_equal(gc0, st.planes["ground_cover"])
     ctx.close()
+
+
+def test_per_cell_forcing_keeps_the_rotation_pending(native, monkeypatch):
+    """With per-cell forcing the selected prec / ta are applied inside the fused kernel (from the per-cell aggregates) and the predicate
+    kernels read tau planes only, so nothing writes a plane between two fused steps and the tau -> taum1 copies stay pending as with
+    shared forcing.  RH_NO_DEFERRED_SELECT=1: the selection kernel stores prec / ta itself (eager fused kernel) -- the same bits."""
+    import hip_util as H
+
+    g, names, forcing = load_case(WEIGHTED_CASES[0])
+    w = load_weights(g)
+    out = {}
+    for mode in ("deferred", "stored"):
+        if mode == "stored":
+            monkeypatch.setenv("RH_NO_DEFERRED_SELECT", "1")
+        else:
+            monkeypatch.delenv("RH_NO_DEFERRED_SELECT", raising=False)
+        ctx = _ctx(native, g, names)
+        ctx.set_forcing_series(forcing)
+        ctx.set_forcing_weights(w["prec_weight"], w["ta_offset"], w["pet_weight"])
+        ctx.run_steps(int(g["nsteps"]))
+        lazy, _ = ctx.step_mode()
+        assert lazy == (mode == "deferred"), mode
+        out[mode] = (H.scalars_to_row(ctx.get_scalars()), H.download_snapshot(ctx, names))
+        ctx.close()
+    np.testing.assert_array_equal(out["deferred"][0], out["stored"][0])
+    assert np.array_equal(out["deferred"][1], out["stored"][1], equal_nan=True)
