@@ -287,6 +287,14 @@ def main():
             all_w |= write
             lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in sorted(ld, key=order.get)))
             lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in sorted(st, key=order.get)))
+        if seq.startswith("routed_a2"):
+            # k_routed_a2 samples the summary bits of the next step's predicates like the fused kernel: prec / ta after rt_select_pet, swe /
+            # swe_top after rt_snow -- no later stage of this pass and no stage of the passes behind it may assign them
+            behind = [r for q in ("routed_b", "routed_c_after", "routed_c") for r in PLAIN_SEQUENCES[q]] + ["rt_after_timestep_oned"]
+            for fld, after in (("prec", "rt_select_pet"), ("ta", "rt_select_pet"), ("swe", "rt_snow"), ("swe_top", "rt_snow")):
+                late = [r for r in stages[stages.index(after) + 1:] + behind if fld in sets[r][1]]
+                if late:
+                    sys.exit(f"sequence {seq}: {fld} is assigned after {after} by {late}; move the summary sampling")
         if seq in PLAIN_CHECK:
             ref_m, ref_w = sets[PLAIN_CHECK[seq]]
             if all_m != ref_m or all_w != ref_w:
