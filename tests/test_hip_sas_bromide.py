@@ -320,3 +320,40 @@ def test_explicit_solvers_random_columns_against_oracle(n, ages, substeps, stats
         for k in st.state:   # the next day starts from the device's state on both sides
             ref.state[k][:] = st.state[k]
     ctx.close()
+
+
+@pytest.mark.parametrize("solver", ["Euler", "RK4"])
+@pytest.mark.parametrize("tracer", ["oxygen18", "bromide"])
+def test_explicit_solvers_at_the_benchmark_age_axis(solver, tracer):
+    """10^4 columns x 1000 ages x 6 sub-steps (the kernel shape of BASELINE configs[2]): the StorAges stay non-negative and equal the
+    oracle's on a sample of columns, a distribution sums to <= 1, and with bromide the solute never turns negative."""
+    n, ages, sub = 10_000, 1000, 6
+    st = bromide_problem(n, ages, sub, 77, False, solver=solver) if tracer == "bromide" else random_problem(n, ages, sub, seed=77, solver=solver)
+    ctx = make_ctx(st)
+    push(ctx, st)
+    ref = clone(st)
+    ctx.step(0)
+    sa_rz, sa_ss = ctx.download("sa_rz"), ctx.download("sa_ss")
+    assert (sa_rz >= 0).all() and (sa_ss >= 0).all()
+    # (no bound on the stored water: the scheme's limiter keeps a source class from turning negative while the receiving storage still gets
+    # the unlimited amount, as in the reference) -- the storages against the oracle instead, on the columns it finishes in a second
+    k = 48
+    sub_ref = SasState(k, ages, sub, False, tracer=tracer, solver=solver)
+    sub_ref.maskCatch[:] = ref.maskCatch[:k]
+    for grp in ("state", "inp", "sas", "par"):
+        for name, arr in getattr(ref, grp).items():
+            getattr(sub_ref, grp)[name][:] = arr[:k]
+    sub_ref.step_oracle()
+    steep = np.zeros(k, bool)
+    for f in FLUXES:
+        steep |= np.isin(sub_ref.sas[f][:, 0], [3, 31, 32, 33, 34, 35, 36, 37])
+    for name, got in (("sa_rz", sa_rz[:k]), ("sa_ss", sa_ss[:k])):
+        ok = np.isclose(got, sub_ref.state[name], rtol=1e-9, atol=1e-10).all(axis=1) | steep
+        assert ok.sum() >= k - 1, (name, np.argwhere(~ok).ravel())   # (RK4: at most one residue tie, see the random-column tests)
+    for f in FLUXES:
+        s_ = ctx.download(f"tt_{f}").sum(axis=1)
+        assert (s_ <= 1 + 1e-9).all() and (s_ >= 0).all(), f
+    if tracer == "bromide":
+        assert (ctx.download("msa_rz") >= 0).all() and (ctx.download("msa_ss") >= 0).all()
+        assert (ctx.download("M_s") >= 0).all()
+    ctx.close()
