@@ -60,10 +60,11 @@ typedef struct rh_config {
     double z_evap_max, zroot_to_zsoil_max, a_bc, b_bc;
     int64_t end_event, hpi;
     double dx;        /* settings.dx, grid spacing in m (enters the lateral flow rates) */
-    int32_t placement_probes; /* where the arena lands in HBM decides which of three bandwidth levels the fused kernel
-                                 runs at (0.35 / 0.39 / 0.41 ms per step at 10^6 columns): rh_create
-                                 allocates up to this many candidate arenas, times a streaming kernel on each and keeps
-                                 the fastest (default 1 = take the first; never more than a quarter of the free memory) */
+    int32_t placement_probes; /* where the arena lands in HBM decides which bandwidth level the fused kernel runs at (arenas of
+                                 one process at 0.30 / 0.32 / 0.33 / 0.35 ms per step at 10^6 columns, tools/arena_levels.py,
+                                 DESIGN.md section 5): rh_create allocates up to this many candidate arenas, times a streaming
+                                 kernel on each and keeps the fastest (default 4; 1 = take the first; the candidates held at
+                                 once never exceed a quarter of the free memory; grids below 65 536 columns are not probed) */
     int32_t enable_routing_1D; /* settings.enable_routing_1D (with enable_lateral_flow): surface and subsurface runoff move to
                                   the D8 neighbour (rh_surface_routing / rh_subsurface_routing); the columns are then coupled
                                   twice per step and the fused step (rh_svat_step, rh_run_steps) is not available */
