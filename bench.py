@@ -550,6 +550,7 @@ def main():
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, " + ("one 256-byte predicate all-reduce per step" if world > 1 else "single GPU: no exchange"),
                 "stepping": stepping,
+                "placement_probe_ms": [round(v, 4) for v in ctx.placement_report()],   # the candidate arenas' copy times, the chosen one first
                 # per time-step class (kernel time only, rank 0); `value` is the aggregate over the run
                 "dt_classes": {
                     name: {"steps": int((per_dt == secs).sum()),
