@@ -152,7 +152,7 @@ struct rh_ctx {
     int *dt_log_buf;
     std::vector<double> probe_ms;   // placement probing: streaming-kernel time per candidate arena, the chosen one first
     char *arena_alloc;    // what hipMalloc returned for the arena (arena.base = arena_alloc + arena_offset)
-    size_t arena_offset;
+    size_t arena_offset, arena_pad = 0;
     void *stage_buf;      // one contiguous plane (n * 8 bytes): uploads and downloads pass through it
     // multi-GPU: RCCL communicator and the exchange buffers of the summary word (64 int32 sent, 64 received)
     ncclComm_t comm;
@@ -1836,6 +1836,8 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     {   // experiments (tools/placement_diag*.py): RH_ARENA_OFFSET_KB shifts the arena inside a larger allocation
         const char *off = std::getenv("RH_ARENA_OFFSET_KB");
         ctx->arena_offset = off ? (size_t)std::atoll(off) * 1024 : 0;
+        const char *pad = std::getenv("RH_ARENA_PAD_KB");   // ... and RH_ARENA_PAD_KB pads the allocation behind the arena
+        ctx->arena_pad = pad ? (size_t)std::atoll(pad) * 1024 : 0;
     }
     {
         // Placement probing (rh_config.placement_probes): candidates are allocated one after the other and held until
@@ -1852,10 +1854,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
             if (k > 0) {   // all candidates are held until the choice is made: never more than a quarter of the free memory in total
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-                    (free_b + k * (arena_bytes + ctx->arena_offset)) / 4 < (k + 1) * (arena_bytes + ctx->arena_offset)) break;
+                    (free_b + k * (arena_bytes + ctx->arena_offset + ctx->arena_pad)) / 4 < (k + 1) * (arena_bytes + ctx->arena_offset + ctx->arena_pad)) break;
             }
             char *p = nullptr;
-            if ((e = hipMalloc((void **)&p, arena_bytes + ctx->arena_offset)) != hipSuccess) {
+            if ((e = hipMalloc((void **)&p, arena_bytes + ctx->arena_offset + ctx->arena_pad)) != hipSuccess) {
                 if (k == 0) return bail(e, "hipMalloc(arena)");
                 (void)hipGetLastError();
                 break;
