@@ -402,9 +402,9 @@ def main():
     ap.add_argument("--station-weights", action="store_true",
                     help="svat: per-cell prec_weight / ta_offset / pet_weight on the station series (the distributed catchment "
                          "setups, BASELINE configs[4]: --size 80 53 --params hetero --station-weights)")
-    ap.add_argument("--placement-probes", type=int, default=4,
+    ap.add_argument("--placement-probes", type=int, default=8,
                     help="svat / oned: candidate arenas rh_create times a streaming copy on before keeping the fastest (DESIGN.md section 5; "
-                         "the library's default is 1 = take the first)")
+                         "the library's default too; 1 = take the first)")
     ap.add_argument("--prewarm-ms", type=float, default=0.0,
                     help="keep the device busy with a plain copy for this long right before the timed region (untimed; the memory-side "
                          "clocks fall back while the host reads rocm-smi between warm-up and timing)")

@@ -63,7 +63,7 @@ typedef struct rh_config {
     int32_t placement_probes; /* where the arena lands in HBM decides which bandwidth level the fused kernel runs at (arenas of
                                  one process at 0.30 / 0.32 / 0.33 / 0.35 ms per step at 10^6 columns, tools/arena_levels.py,
                                  DESIGN.md section 5): rh_create allocates up to this many candidate arenas, times a streaming
-                                 kernel on each and keeps the fastest (default 4; 1 = take the first; the candidates held at
+                                 kernel on each and keeps the fastest (default 8; 1 = take the first; the candidates held at
                                  once never exceed a quarter of the free memory; grids below 65 536 columns are not probed) */
     int32_t enable_routing_1D; /* settings.enable_routing_1D (with enable_lateral_flow): surface and subsurface runoff move to
                                   the D8 neighbour (rh_surface_routing / rh_subsurface_routing); the columns are then coupled

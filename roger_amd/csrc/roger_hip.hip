@@ -1742,7 +1742,7 @@ void rh_default_config(rh_config *cfg) {
     cfg->enable_lateral_flow = 0;
     cfg->enable_routing_1D = 0;
     cfg->dy = 1.0;
-    cfg->placement_probes = 4;   // up to four candidate arenas, never more than a quarter of the free memory held at once (1 or RH_PLACEMENT_PROBES=1: none)
+    cfg->placement_probes = 8;   // up to eight candidate arenas, never more than a quarter of the free memory held at once (1 or RH_PLACEMENT_PROBES=1: none)
 }
 
 const char *rh_last_error(const rh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
