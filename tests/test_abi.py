@@ -110,3 +110,19 @@ def test_no_gpu_means_loud_failure():
         _native.Context(2, 2)
     with pytest.raises(_native.NativeError, match="no CPU fallback"):
         _native.SasContext(4, 40)
+
+
+def test_integration_stub_names_every_config_field():
+    """INTEGRATION.md shows the ctypes structs a maintainer would add on the reference's side: they must carry every field of rh_config /
+    rh_sas_config in the header's order (a shorter struct would let rh_default_config write past it)."""
+    import os
+    import re
+
+    from roger_amd import _native
+
+    doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    for cls, start in ((_native.RhConfig, "class RhConfig(C.Structure)"), (_native.RhSasConfig, "class RhSasConfig(C.Structure)")):
+        block = doc[doc.index(start):]
+        block = block[:block.index("\n\n")]
+        names = re.findall(r'"(\w+)"', block)
+        assert names == [n for n, _ in cls._fields_], (cls.__name__, names)
