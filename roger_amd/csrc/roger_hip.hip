@@ -131,6 +131,7 @@ struct rh_ctx {
     bool routed_summary = false;     // routing: sumw holds the summary bits of the arena's state (posted by k_routed_a2)
     bool routed_device_ok = true;    // RH_ROUTED_BY_ROUTINE: rh_run_steps takes rh_step_routed per step (A/B, tests)
     bool defer_select_ok = true;     // RH_NO_DEFERRED_SELECT: k_select stores the per-cell prec / ta itself (A/B, tests)
+    int64_t cell_agg_split_min = 65536;   // columns from which the per-cell aggregates run as two kernels (RH_CELL_AGG_SPLIT_MIN: tests)
     bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
     int pending_hooks;    // ... formed with / without the device-side hooks
     bool tail_ok;         // RH_NO_TAIL_CTRL unset
@@ -299,12 +300,12 @@ RH_DEV double np_sum144_window(Get get, int64_t itd) {
 // weighted station forcing: PREC[k] * w, TA[k] + offset, PET[k] * w).  daily = false leaves a[0..2] alone: the daily
 // sums only change with the day.
 template <class P, class T, class E>
-RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily = true);
+RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily = true, bool hourly = true);
 RH_DEV void forcing_aggregates(const double *p, const double *t, const double *e, int64_t itd, double *a) {
     forcing_aggregates_of([&](int k) { return p[k]; }, [&](int k) { return t[k]; }, [&](int k) { return e[k]; }, itd, a);
 }
 template <class P, class T, class E>
-RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily) {
+RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool daily, bool hourly) {
     if (daily) {
         a[0] = np_sum144([&](int k) { return p(k); });
         int cnt = 0;
@@ -312,6 +313,7 @@ RH_DEV void forcing_aggregates_of(P p, T t, E e, int64_t itd, double *a, bool da
         a[1] = np_sum144([&](int k) { const double v = t(k); return isnan(v) ? 0.0 : v; }) / (double)cnt;
         a[2] = np_sum144([&](int k) { return e(k); });
     }
+    if (!hourly) return;
     a[3] = np_sum144_window([&](int k) { return p(k); }, itd);
     {
         int cnt = 0;
@@ -575,28 +577,36 @@ __global__ __launch_bounds__(RH_BLOCK) void k_agg(DevState *D, int do_hooks, int
 
 // Per-cell forcing only: aggregates of every column's own 144-slot series, once per step, into
 // nine SoA planes (so the per-column kernels stay free of the 144-element loops).
+// PART: 0 = everything in one launch; 1 = the hourly window and the current slot only; 2 = the daily sums only (returns at once unless they
+// are due).  From 65 536 columns on the host launches 1 and 2: the daily sums' code needs 214 registers, which leaves the hourly part --
+// every step's part -- two waves per SIMD for a chain of dependent loads (58 us at 10^6 columns; on its own 25 us).
+template <int PART>
 __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int force_daily) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const bool weighted = D->weights[0] != nullptr;
+    // the station series of the day changes at midnight only (device-side hooks): its daily sums are formed once a day,
+    // the first step of the day has itt_day == 0; rows uploaded by the host may change at any time
+    const bool daily = (PART != 1) && (!weighted || force_daily || D->S.itt_day == 0);
+    if (PART == 2 && !daily) return;
     __shared__ DaySeries day;
     if (weighted) stage_day(D, day);
     if (i >= a.n) return;
     double agg[9];
-    // the station series of the day changes at midnight only (device-side hooks): its daily sums are formed once a day,
-    // the first step of the day has itt_day == 0; rows uploaded by the host may change at any time
-    const bool daily = !weighted || force_daily || D->S.itt_day == 0;
     if (weighted) {
         const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
         const DayView F = day_view(D, day, i);
         forcing_aggregates_of([&](int k) { return F(0, k) * pw; }, [&](int k) { return F(1, k) + toff; },
-                              [&](int k) { return F(2, k) * ew; }, D->S.itt_day, agg, daily);
+                              [&](int k) { return F(2, k) * ew; }, D->S.itt_day, agg, daily, PART != 2);
     } else {
         const double *p = D->forc_cell[0] + i, *t = D->forc_cell[1] + i, *e = D->forc_cell[2] + i;
         const size_t n = (size_t)a.n;
         forcing_aggregates_of([&](int k) { return p[k * n]; }, [&](int k) { return t[k * n]; }, [&](int k) { return e[k * n]; },
-                              D->S.itt_day, agg);
+                              D->S.itt_day, agg, daily, PART != 2);
     }
-    for (int k = daily ? 0 : 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
+    if (daily)
+        for (int k = 0; k < 3; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
+    if (PART != 2)
+        for (int k = 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
 
@@ -1931,6 +1941,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
     ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
     ctx->defer_select_ok = std::getenv("RH_NO_DEFERRED_SELECT") == nullptr;
+    if (const char *v = std::getenv("RH_CELL_AGG_SPLIT_MIN")) ctx->cell_agg_split_min = std::atoll(v);
     ctx->grp_shift = 6;
     while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
     ctx->summary_valid = false;
@@ -2470,11 +2481,21 @@ int rh_step_phase1(rh_ctx *ctx) {
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
+// per-cell forcing: the columns' aggregates of the step (k_cell_agg); does not touch the planes
+static void launch_cell_agg(rh_ctx *ctx) {
+    const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
+    const int force = ctx->agg_daily_stale ? 1 : 0;
+    if (ctx->n >= ctx->cell_agg_split_min) {
+        hipLaunchKernelGGL(k_cell_agg<2>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force);
+        hipLaunchKernelGGL(k_cell_agg<1>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force);
+    } else
+        hipLaunchKernelGGL(k_cell_agg<0>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force);
+}
 int rh_step_phase2(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     LAUNCH_WG(ctx, k_agg, ctx->dev, 0, 0);
     if (ctx->per_cell) {   // (does not touch the planes: no LAUNCH_CELLS)
-        hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
+        launch_cell_agg(ctx);
         ctx->agg_daily_stale = false;
     }
     LAUNCH_PRED(ctx, k_select);
@@ -2530,7 +2551,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
     if (ctx->per_cell) {
-        hipLaunchKernelGGL(k_cell_agg, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
+        launch_cell_agg(ctx);
         ctx->agg_daily_stale = false;
     }
     const bool defer = ctx->per_cell && ctx->defer_select_ok;   // (shared forcing on this path, e.g. before the series is resident: k_select stores)

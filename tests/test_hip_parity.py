@@ -353,8 +353,18 @@ def test_weighted_station_forcing_on_device(native, oracle):
     ctx.close()
 
 
+@pytest.fixture(params=["one kernel", "split"])
+def cell_agg_split(request, monkeypatch):
+    """The per-cell aggregates in one kernel (grids below 65 536 columns) or as the hourly + the daily kernel (above; forced here)."""
+    if request.param == "split":
+        monkeypatch.setenv("RH_CELL_AGG_SPLIT_MIN", "1")
+    else:
+        monkeypatch.delenv("RH_CELL_AGG_SPLIT_MIN", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("case", WEIGHTED_CASES)
-def test_weighted_station_forcing_golden(native, case):
+def test_weighted_station_forcing_golden(native, case, cell_agg_split):
     """BASELINE configs[4] pinned by the reference itself: the golden run's set_forcing multiplies / offsets the station's measured
     series (first 40 days of the shipped Eberbaechle PREC/TA/PET.txt) by per-cell prec_weight / ta_offset / pet_weight
     (examples/catchment_scale/eberbaechle/svat_distributed/svat.py:169-186, 276-296).  The device forms every column's day from
@@ -396,7 +406,7 @@ def test_weighted_station_forcing_golden(native, case):
 
 
 @pytest.mark.parametrize("case", STATION_CASES)
-def test_station_mapped_forcing_golden(native, case):
+def test_station_mapped_forcing_golden(native, case, cell_agg_split):
     """settings.enable_distributed_input: three stations' series resident on the device, every column mapped
     to one of them (one column to none: zeros), per-cell weights on top -- the reference's own run of such a setup
     (roger/bmimodels/svat_dist/svat_dist.py:274-322) reproduced by rh_set_forcing_stations + rh_set_forcing_weights + rh_run_steps, no
