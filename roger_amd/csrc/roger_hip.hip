@@ -3085,7 +3085,13 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) 
     for (int p = 0; p < nplanes; ++p)
         if (PLANE_IS_INT[src_plane0 + p] || PLANE_IS_INT[dst_plane0 + p]) return fail(ctx, RH_ERR_ARG, "calibration planes must be float64");
     planes_touched(ctx);
-    hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, src_plane0, dst_plane0, nplanes);
+    Arena probe = ctx->arena;
+    if (const char *sh = std::getenv("RH_CALIB_SHIFT_KB")) {   // experiment (tools/arena_phase.py): the same copy shifted inside the allocation's padding
+        const size_t shift = (size_t)std::atoll(sh) * 1024;
+        if (shift > ctx->arena_pad) return fail(ctx, RH_ERR_ARG, "RH_CALIB_SHIFT_KB exceeds RH_ARENA_PAD_KB");
+        probe.base = ctx->arena.base + shift;
+    }
+    hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, probe, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
