@@ -11,6 +11,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+os.environ.setdefault("RH_PLACEMENT_PROBES", "1")   # the raw level of each allocation: no placement probing (the library's default is 8 candidates)
 from roger_amd.forcing import combo_forcing  # noqa: E402
 from roger_amd.svat import create_svat        # noqa: E402
 
