@@ -96,7 +96,7 @@ def test_bromide_warmup_on_device():
     model.state.sas_context.close()
 
 
-@pytest.mark.parametrize("case", ["sas_chloride_warmup_a30", "sas_chloride_rk4_warmup_a30"])
+@pytest.mark.parametrize("case", ["sas_chloride_warmup_a30", "sas_chloride_rk4_warmup_a30", "sas_virtualtracer_euler_a30"])
 def test_chloride_warmup_on_device(case):
     g = sb.SasGolden(case)
     model = bromide_model(g, warmup_days=g.ndays)

@@ -162,7 +162,7 @@ def test_bromide_warmup_and_run(oracle_sas):
     run_and_compare_bromide(g, bromide_model(g, warmup_days=g.ndays), warmup=1)
 
 
-@pytest.mark.parametrize("case", ["sas_chloride_warmup_a30", "sas_chloride_rk4_warmup_a30"])
+@pytest.mark.parametrize("case", ["sas_chloride_warmup_a30", "sas_chloride_rk4_warmup_a30", "sas_virtualtracer_euler_a30"])
 def test_chloride_warmup_and_run(oracle_sas, case):
     """settings.enable_chloride: setup(); warmup(); run() against the reference's chloride run (deterministic and RK4)."""
     g = sb.SasGolden(case)
