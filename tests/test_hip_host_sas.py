@@ -101,7 +101,7 @@ def test_chloride_warmup_on_device(case):
     g = sb.SasGolden(case)
     model = bromide_model(g, warmup_days=g.ndays)
     run_and_compare_bromide(g, model, warmup=1)
-    assert model.state.sas_context.tracer == "chloride"
+    assert model.state.sas_context.tracer == g.tracer
     model.state.sas_context.close()
 
 
