@@ -238,6 +238,7 @@ def main():
         # settings.sas_solver = "Euler" / "RK4" (transport.py:2064-2414, 1139-2047): all fluxes of a sub-step from one StorAge
         "sas_euler_a40": (3, 2, 14, 40, 4, "mixed", True, 61, False, "oxygen18", "Euler"),
         "sas_rk4_a40": (3, 2, 14, 40, 4, "mixed", True, 67, False, "oxygen18", "RK4"),
+        "sas_euler_families_a50": (4, 3, 12, 50, 3, "families", False, 89, False, "oxygen18", "Euler"),   # dirac, kumaraswami, exponential, power
         # ... with the anion kernels (the reference's bromide tutorial runs RK4: examples/plot_scale/svat_bromide_tutorial/config.yml)
         "sas_bromide_euler_a30": (3, 2, 12, 30, 3, "power", True, 71, False, "bromide", "Euler"),
         "sas_bromide_rk4_a30": (3, 2, 12, 30, 6, "power", True, 73, False, "bromide", "RK4"),
