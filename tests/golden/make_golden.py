@@ -531,6 +531,21 @@ def main():
         run_case(roger, "oned_routing", p, toy_forcing("heavyrain", ndays=4), 4, 100000, 25, {1, 2, 30, 31, 60}, args.out,
                  lateral=True, pair_every=10, routing=routing)
 
+    # ... the same with every step class: snowfall and melt, rain with pauses, heavy rain, dry days and a month change (combo forcing,
+    # 14 days from 2018-01-20) on a 5 x 4 hillslope with random flow directions
+    if not args.only or args.only == "oned_routing_combo":
+        nx, ny = 5, 4
+        rng = np.random.default_rng(37)
+        flow = rng.choice([1, 2, 4, 8, 16, 32, 64, 128], (nx, ny))
+        flow[:, :2] = 4
+        flow[2, 2] = 0
+        outer = np.zeros((nx, ny), dtype=int)
+        outer[4, 3] = 1
+        p = oned_params(nx, ny, 29)
+        routing = dict(flow_dir_topo=flow, outer_boundary=outer, k_st=rng.uniform(8, 30, (nx, ny)), dx=5, dy=5)
+        run_case(roger, "oned_routing_combo", p, combo_forcing(ndays=14), 14, 100000, 40, {1, 2, 100, 101}, args.out,
+                 lateral=True, pair_every=10, routing=routing)
+
     # the reference's own routing example (examples/hillslope_scale/oneD_distributed_routing_tutorial: config.yml, oneD.py:127-335,
     # 455-483): a 1 x 20 hillslope, dx = dy = 1 m, every cell draining towards +y, uniform soil, Strickler coefficient 50, soil at field
     # capacity, the station's series (the same files as Eberbaechle's: the first 40 days, 2019-11-01 ...) with the example's weights

@@ -11,6 +11,8 @@ ONED_CASES = ("oned_hetero_heavyrain", "oned_hetero_combo", "oned_uniform_benchm
 # settings.enable_routing_1D: surface and subsurface runoff routed to the D8 neighbour (oneD_distributed_routing_tutorial)
 # ... and the reference's own routing example (1 x 20 hillslope, the station's measured series, uniform weights)
 ROUTING_CASES = ("oned_routing", "oned_routing_tutorial")
+# ... and cases used step by step only (from the reference's states: a free run meets the oneD residue ties, which routing carries downstream)
+ROUTING_STEP_CASES = ROUTING_CASES + ("oned_routing_combo",)
 CASES = SVAT_CASES + ONED_CASES
 # BASELINE configs[4] (Eberbaechle, svat_distributed): the station's measured series x per-cell prec_weight / ta_offset / pet_weight
 WEIGHTED_CASES = ("svat_eberbaechle_weights",)

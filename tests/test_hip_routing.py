@@ -4,7 +4,7 @@ flow directions, a pit, an interior outlet; 240 steps) and, for the halo path of
 import numpy as np
 import pytest
 
-from golden_util import ROUTING_CASES, compare, load_case
+from golden_util import ROUTING_CASES, ROUTING_STEP_CASES, compare, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def routed_ctx(native, g, names, key="state0", scal_key="scal0", columns=None):
     return ctx
 
 
-@pytest.mark.parametrize("case", ROUTING_CASES)
+@pytest.mark.parametrize("case", ROUTING_STEP_CASES)
 def test_single_steps_from_reference_states(native, case):
     """One routed step from the reference's state k-1 gives the reference's state k (every pair of consecutive snapshots)."""
     import hip_util as H
@@ -78,7 +78,7 @@ def test_trajectory_golden(native, case):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ROUTING_CASES)
+@pytest.mark.parametrize("case", ROUTING_STEP_CASES)
 def test_routing_entry_points_golden(native, case):
     """rh_surface_routing and rh_subsurface_runoff + rh_subsurface_routing: state before the reference routine in, state after it out."""
     import hip_util as H
@@ -97,7 +97,7 @@ def test_routing_entry_points_golden(native, case):
             ctx.close()
 
 
-@pytest.mark.parametrize("case", ROUTING_CASES)
+@pytest.mark.parametrize("case", ROUTING_STEP_CASES)
 def test_halo_columns_of_a_cut_domain(native, case):
     """The grid cut in two along x (as a (2, 1) decomposition cuts it), one context per half, the edge columns handed over by hand
     (rh_route_get_edges / rh_route_set_halo: what the RCCL exchange of rh_surface_routing does between ranks): both routings give the

@@ -3,7 +3,7 @@ backend (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_util import (CASES, ONED_CASES, ONED_TIE_COLUMNS, ROUTING_CASES, STATION_CASES, WEIGHTED_CASES, compare, configure_settings,
+from golden_util import (CASES, ONED_CASES, ONED_TIE_COLUMNS, ROUTING_CASES, ROUTING_STEP_CASES, STATION_CASES, WEIGHTED_CASES, compare, configure_settings,
                          deviating_columns, is_lateral, load_case, load_stations, load_weights)
 
 
@@ -34,7 +34,7 @@ def single_step_pairs(g):
     return [k for k in have if k - 1 in have and k >= 2]
 
 
-@pytest.mark.parametrize("case", ONED_CASES + ROUTING_CASES)
+@pytest.mark.parametrize("case", ONED_CASES + ROUTING_STEP_CASES)
 def test_single_steps_from_reference_states(oracle, case):
     """oneD model: one step from the reference's state k-1 must give the reference's state k.  (The
     oneD model keeps the rounding residue of emptied stores -- no snap-to-zero as in the SVAT
@@ -84,7 +84,7 @@ def test_trajectory(oracle, case):
     assert checked >= 3
 
 
-@pytest.mark.parametrize("case", CASES + ROUTING_CASES)
+@pytest.mark.parametrize("case", CASES + ROUTING_STEP_CASES)
 def test_per_routine(oracle, case):
     """Each routine separately: start from the reference state before the routine, run the
     oracle routine, compare with the reference state after it."""
@@ -92,7 +92,7 @@ def test_per_routine(oracle, case):
     order = ["adaptive_time_stepping", "calculate_interception", "calculate_evapotranspiration", "calculate_snow",
              "calculate_infiltration", "calculate_subsurface_runoff", "calculate_capillary_rise", "calculate_soil",
              "calc_storage"]
-    routed = case in ROUTING_CASES
+    routed = case in ROUTING_STEP_CASES
     if routed:
         order.insert(5, "calculate_surface_runoff")
     steps = sorted({int(k[1:6]) for k in g.files if k.startswith("r") and k.endswith("_calc_storage")})
