@@ -243,6 +243,7 @@ def main():
         "sas_bromide_euler_a30": (3, 2, 12, 30, 3, "power", True, 71, False, "bromide", "Euler"),
         "sas_bromide_rk4_a30": (3, 2, 12, 30, 6, "power", True, 73, False, "bromide", "RK4"),
         "sas_chloride_rk4_warmup_a30": (2, 2, 10, 30, 4, "power", False, 79, True, "chloride", "RK4"),
+        "sas_bromide_rk4_families_a50": (4, 3, 10, 50, 3, "families", False, 97, False, "bromide", "RK4"),
         "sas_virtualtracer_euler_a30": (2, 2, 10, 30, 3, "power", False, 83, True, "virtualtracer", "Euler"),
     }
     for name, (nx, ny, ndays, ages, substeps, variant, stats, seed, *rest) in cases.items():

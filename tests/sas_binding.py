@@ -19,7 +19,7 @@ SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a5
              "sas_deuterium_a40", "sas_benchmark_a1000")
 # settings.sas_solver = "Euler" / "RK4" (the explicit solvers of roger/core/transport.py:1139-2414)
 SOLVER_CASES = ("sas_euler_a40", "sas_rk4_a40", "sas_euler_families_a50")
-ANION_SOLVER_CASES = ("sas_bromide_euler_a30", "sas_bromide_rk4_a30")   # the anion kernels under Euler / RK4
+ANION_SOLVER_CASES = ("sas_bromide_euler_a30", "sas_bromide_rk4_a30", "sas_bromide_rk4_families_a50")   # the anion kernels under Euler / RK4
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 
