@@ -238,6 +238,9 @@ def main():
         # settings.sas_solver = "Euler" / "RK4" (transport.py:2064-2414, 1139-2047): all fluxes of a sub-step from one StorAge
         "sas_euler_a40": (3, 2, 14, 40, 4, "mixed", True, 61, False, "oxygen18", "Euler"),
         "sas_rk4_a40": (3, 2, 14, 40, 4, "mixed", True, 67, False, "oxygen18", "RK4"),
+        # ... at the benchmark's shape (ages = 1000, 6 sub-steps, its exponents): the kernel shapes k_sas_rk4<4, 4> / k_sas_euler<4, 4>
+        "sas_rk4_a1000": (3, 1, 3, 1000, 6, "benchmark", True, 101, False, "oxygen18", "RK4"),
+        "sas_bromide_euler_a1000": (3, 1, 7, 1000, 6, "benchmark", False, 103, False, "bromide", "Euler"),
         "sas_euler_families_a50": (4, 3, 12, 50, 3, "families", False, 89, False, "oxygen18", "Euler"),   # dirac, kumaraswami, exponential, power
         # ... with the anion kernels (the reference's bromide tutorial runs RK4: examples/plot_scale/svat_bromide_tutorial/config.yml)
         "sas_bromide_euler_a30": (3, 2, 12, 30, 3, "power", True, 71, False, "bromide", "Euler"),

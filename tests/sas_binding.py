@@ -18,8 +18,8 @@ STAT_Q = ("10", "25", "50", "75", "90", "avg")
 SAS_CASES = ("sas_power_a40", "sas_mixed_a70", "sas_stats_a30", "sas_families_a50", "sas_warmup_a30", "sas_gamma_a40",
              "sas_deuterium_a40", "sas_benchmark_a1000")
 # settings.sas_solver = "Euler" / "RK4" (the explicit solvers of roger/core/transport.py:1139-2414)
-SOLVER_CASES = ("sas_euler_a40", "sas_rk4_a40", "sas_euler_families_a50")
-ANION_SOLVER_CASES = ("sas_bromide_euler_a30", "sas_bromide_rk4_a30", "sas_bromide_rk4_families_a50")   # the anion kernels under Euler / RK4
+SOLVER_CASES = ("sas_euler_a40", "sas_rk4_a40", "sas_euler_families_a50", "sas_rk4_a1000")
+ANION_SOLVER_CASES = ("sas_bromide_euler_a30", "sas_bromide_rk4_a30", "sas_bromide_rk4_families_a50", "sas_bromide_euler_a1000")   # the anion kernels under Euler / RK4
 
 ANION_MASSES = tuple(f"M_{f}" for f in FLUXES[1:] + INFS) + ("M_rz", "M_ss", "M_s")   # bromide runs only
 
@@ -233,7 +233,7 @@ DEVICE_TIES = {"sas_power_a40": 2, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_
                "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0}
 # ... and of the ORACLE (glibc's pow against numpy's AVX-512 pow), same criterion, measured in the build container
 ORACLE_TIES = {"sas_power_a40": 0, "sas_mixed_a70": 0, "sas_stats_a30": 0, "sas_families_a50": 1, "sas_warmup_a30": 0, "sas_gamma_a40": 4,
-               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0, "sas_euler_a40": 0, "sas_rk4_a40": 0, "sas_euler_families_a50": 0}
+               "sas_deuterium_a40": 0, "sas_benchmark_a1000": 0, "sas_euler_a40": 0, "sas_rk4_a40": 0, "sas_euler_families_a50": 0, "sas_rk4_a1000": 0}
 # Random columns against the oracle (tests/test_hip_sas.py::test_random_columns_against_oracle), per configuration (n, ages,
 # substeps): columns that newly miss 1e-10 on day 0, 1, 2 (a column that tied stays off afterwards: its state carries on).
 DEVICE_NEW_TIES = {(96, 1000, 6): (0, 4, 1), (200, 300, 3): (2, 4, 3), (64, 1500, 2): (0, 3, 1), (64, 2500, 2): (0, 1, 0),
