@@ -383,6 +383,61 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
     ctx.close()
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script, one per GPU of this node, as CHILD processes
+    (never exec: the parent stays the process the caller waits for), hand them the rendezvous through RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT -- what `python -m torch.distributed.run --nproc-per-node N` would set, and what the reference's
+    benchmarks get from `mpirun -n N` (benchmarks/run_benchmarks.py:27-31,181; benchmark_base.py:8-29) --, pass on what they print
+    (rank 0 prints the JSON line) and return their exit status: non-zero as soon as one rank fails, the others are then stopped."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:   # a free port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    status, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.monotonic()
+            print(f"bench: rank {bad[0][0]} exited with status {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+        if failed_at is not None and time.monotonic() - failed_at > 5.0:   # a rank waiting in a collective for the failed one
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()   # exactly the processes started here
+    for r, p in enumerate(procs):
+        rc = p.wait()
+        if rc != 0 and status == 0:
+            status = rc if rc > 0 else 1
+    return status
+
+
+def launch_check(dist, torch, rank, world):
+    """--launch-check: what a rank does up to the first collective, without a GPU (gloo)."""
+    if os.environ.get("RH_BENCH_TEST_FAIL_RANK") == str(rank):   # the launcher's failure path (tests)
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "sum_of_rank_ids_plus_one": int(t.item()),
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,7 +466,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="the launcher's own test: start the ranks, form the process group over gloo, all-reduce the rank ids and print "
+                         "one line -- no GPU work, no model (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the bare command `python bench.py --gpus N`: this process becomes the launcher (nothing here has touched torch or the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -420,7 +482,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the ranks disagree")
+    if args.launch_check:
+        return launch_check(dist, torch, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hip backend has no CPU fallback")
     # rehearsal of the multi-rank path on a one-GPU box: RH_BENCH_SINGLE_DEVICE=1 puts every rank on device 0 and
@@ -472,20 +536,19 @@ def main():
         ctx.set_forcing_weights(rng.uniform(0.8, 1.2, n_local), rng.uniform(-1.5, 1.5, n_local), rng.uniform(0.9, 1.1, n_local))
     if args.station_weights and world > 1:
         raise SystemExit("--station-weights: the three-phase exchange of per-cell forcing is not wired into bench.py (single GPU only)")
-    stepping = "rh_run_steps"
+    stepping, comm_ranks = "rh_run_steps", None
     if (world > 1 and not rehearsal) or os.environ.get("RH_BENCH_FORCE_DIST"):
         # multi-GPU: per step ncclAllReduce (64 x int32) -> control kernel -> fused kernel, enqueued from C (rh_run_steps_dist);
         # RH_BENCH_FORCE_DIST=1 rehearses it on one GPU with a one-rank communicator
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        try:
-            ctx.comm_init_torch()
-            run = ctx.run_steps_dist
-            stepping = "rh_run_steps_dist (RCCL from C)"
-        except Exception as exc:   # noqa: BLE001  (no librccl the library can open, or its communicator cannot be formed)
-            # every rank fails or succeeds alike (same image, same node); the exchange then goes through torch.distributed
-            print(f"bench: rank {rank}: RCCL communicator from C not available ({exc}); stepping through torch.distributed", file=sys.stderr)
-            run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run
-            stepping = "PhasedStepper (torch.distributed; the C-side communicator could not be formed)"
+        # no fallback: a rank whose C-side communicator cannot be formed ends the job with a non-zero status (the launcher stops the
+        # others); stepping through torch.distributed instead costs 20 x more per step outside the kernel and would still print a line
+        ctx.comm_init_torch()
+        comm_ranks, comm_rank = ctx.comm_info()   # ncclCommCount / ncclCommUserRank of the communicator the steps will use
+        if comm_ranks != world or comm_rank != rank:
+            raise SystemExit(f"bench: rank {rank}: the RCCL communicator has {comm_ranks} ranks (this is rank {comm_rank} of it), the job has {world}")
+        run = ctx.run_steps_dist
+        stepping = "rh_run_steps_dist (RCCL from C)"
     elif world > 1 or os.environ.get("RH_BENCH_FORCE_PHASED"):   # rehearsals: the Python orchestration (gloo between CPU-side ranks)
         run = PhasedStepper(HipPhases(ctx, device), always_exchange=True).run   # one summary all-reduce per step
         stepping = "PhasedStepper (torch.distributed)"
@@ -550,6 +613,7 @@ def main():
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, " + ("one 256-byte predicate all-reduce per step" if world > 1 else "single GPU: no exchange"),
                 "stepping": stepping,
+                "n_ranks_in_comm": comm_ranks,   # ncclCommCount of the communicator the timed steps used (None: no communicator, single GPU)
                 "placement_probe_ms": [round(v, 4) for v in ctx.placement_report()],   # the candidate arenas' copy times, the chosen one first
                 # per time-step class (kernel time only, rank 0); `value` is the aggregate over the run
                 "dt_classes": {

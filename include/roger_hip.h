@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 1
+#define RH_ABI_VERSION 3   /* 2: rh_config gained enable_routing_1D + dy, rh_sas_config.solver (round 2); 3: rh_comm_info (round 3) */
 #define RH_SLOTS_PER_DAY 144 /* roger/variables.py:109 "timesteps_day": 6 * 24 */
 
 typedef enum rh_status {
@@ -280,6 +280,8 @@ int rh_predicates_compress(rh_ctx *ctx, int word, const int32_t *dev_src64);
 int rh_comm_unique_id(void *id128);
 int rh_comm_init(rh_ctx *ctx, const void *id128, int nranks, int rank);
 int rh_set_comm(rh_ctx *ctx, void *nccl_comm);
+/* ncclCommCount / ncclCommUserRank of the communicator the context holds, asked of RCCL itself (1 / 0 without a communicator). */
+int rh_comm_info(rh_ctx *ctx, int *nranks, int *rank);
 int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps);
 
 /* ---- device-side output accumulators --------------------------------
@@ -328,6 +330,8 @@ int rh_timing_detail(rh_ctx *ctx, double *kernel_ms, int32_t *dt_secs, int64_t c
  * the access shape of the fused kernel (8 bytes per lane and plane); moves a known
  * 2 * nplanes * n_cells * 8 bytes, used to calibrate the HBM counters.  Overwrites the planes. */
 int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes);
+/* Measurement aid: two contexts of the same shape and state exchange their arenas (does a speed level belong to the allocation?). */
+int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b);
 
 #ifdef __cplusplus
 }

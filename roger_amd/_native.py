@@ -12,6 +12,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROGER_HIP_LIB", os.path.join(PKG, "libroger_hip.so"))  # override: kernel experiments
 
 
+ABI_VERSION = 3   # include/roger_hip.h: RH_ABI_VERSION
+
+
 class RhConfig(C.Structure):
     _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("device", C.c_int32), ("enable_lateral_flow", C.c_int32)] + [
         (k, C.c_double) for k in (
@@ -85,6 +88,13 @@ def load():
         lib = _Tolerant(lib)               # it lacks are declared on a stand-in that raises when called
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     lib.rh_abi_version.restype = i32
+    # the structures below are laid out for ONE version of include/roger_hip.h: a library built from another one would read past
+    # (or short of) the caller's rh_config / rh_sas_config.  RH_OLD_VARIANT=1 (A/B against a library of an older commit) accepts
+    # an older library, whose structures are prefixes of today's.
+    got = int(lib.rh_abi_version())
+    if got != ABI_VERSION and not (os.environ.get("RH_OLD_VARIANT") and got < ABI_VERSION):
+        raise NativeError(f"{LIB_PATH} implements ABI version {got}, this binding is written for version {ABI_VERSION} "
+                          "(include/roger_hip.h: RH_ABI_VERSION): rebuild with `python -m roger_amd.build --force`")
     lib.rh_default_config.argtypes = [C.POINTER(RhConfig)]
     lib.rh_default_config.restype = None
     lib.rh_create.argtypes = [C.POINTER(RhConfig), C.POINTER(vp)]
@@ -121,6 +131,7 @@ def load():
     lib.rh_comm_unique_id.argtypes = [vp]
     lib.rh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.rh_set_comm.argtypes = [vp, vp]
+    lib.rh_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rh_run_steps_dist.argtypes = [vp, i64]
     lib.rh_step_routed.argtypes = [vp, i32]
     lib.rh_planes_held.argtypes = [vp]
@@ -145,6 +156,7 @@ def load():
     lib.rh_predicates_expand.argtypes = [vp, i32, vp]
     lib.rh_predicates_compress.argtypes = [vp, i32, vp]
     lib.rh_calibrate_copy.argtypes = [vp, i32, i32, i32]
+    lib.rh_debug_swap_arenas.argtypes = [vp, vp]
     lib.rh_predicate_words.argtypes = [vp]
     lib.rh_predicate_words.restype = vp
     lib.rh_timing_summary.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -380,9 +392,9 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_set_lut_mlms", "rh_params_lateral",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
-    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_run_steps_dist",
+    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_run_steps_dist",
     "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_planes_held", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
 
@@ -632,6 +644,12 @@ class Context:
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
         self.comm_init(box[0], world, rank)
+
+    def comm_info(self):
+        """(ranks, this rank) of the communicator the context holds, as RCCL reports them (ncclCommCount, ncclCommUserRank)."""
+        n, r = C.c_int(), C.c_int()
+        self._check(self._lib.rh_comm_info(self._h, C.byref(n), C.byref(r)), "rh_comm_info")
+        return n.value, r.value
 
     def run_steps_dist(self, nsteps):
         self._check(self._lib.rh_run_steps_dist(self._h, int(nsteps)), "rh_run_steps_dist")

@@ -2901,6 +2901,17 @@ int rh_set_comm(rh_ctx *ctx, void *nccl_comm) {
     }
     return RH_OK;
 }
+int rh_comm_info(rh_ctx *ctx, int *nranks, int *rank) {
+    if (!ctx || !nranks || !rank) return ctx ? fail(ctx, RH_ERR_ARG, "rh_comm_info: null pointer") : RH_ERR_ARG;
+    *nranks = 1;
+    *rank = 0;
+    if (!ctx->comm) return RH_OK;
+    RcclApi *api = rccl_api();
+    if (!api->ok) return fail(ctx, RH_ERR_STATE, "rh_comm_info: " + api->why);
+    NCCLCHK(ctx, api->CommCount(ctx->comm, nranks));
+    NCCLCHK(ctx, api->CommUserRank(ctx->comm, rank));
+    return RH_OK;
+}
 int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
@@ -3093,6 +3104,19 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes) 
     }
     hipLaunchKernelGGL(k_calib_copy, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, probe, src_plane0, dst_plane0, nplanes);
     CHECK_LAUNCH(ctx);
+    return RH_OK;
+}
+
+// Experiment (tools/swap_levels.py): two contexts of the same shape exchange their arenas -- does the fused kernel's speed level follow the
+// arena or the rest of the context?  The caller has brought both to the same state (same steps from the same start).
+int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b) {
+    if (!a || !b || a->n != b->n || a->arena.stride != b->arena.stride || a->planes_held != b->planes_held) return RH_ERR_ARG;
+    HIPCHK(a, hipStreamSynchronize(a->stream));
+    HIPCHK(b, hipStreamSynchronize(b->stream));
+    std::swap(a->arena.base, b->arena.base);
+    std::swap(a->arena_alloc, b->arena_alloc);
+    std::swap(a->arena_offset, b->arena_offset);
+    std::swap(a->arena_pad, b->arena_pad);
     return RH_OK;
 }
 
