@@ -43,10 +43,11 @@ REFERENCE_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md sect
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def kernel_bytes_per_cell(model, lazy):
-    """(load, store) bytes one column moves per fused step: roger_amd/csrc/rh_step_bytes.json (tools/isa_census.py)."""
+def kernel_bytes_per_cell(model, variant):
+    """(load, store) bytes one column moves per fused step of that kernel variant ("eager", "lazy", "sparse"):
+    roger_amd/csrc/rh_step_bytes.json (tools/isa_census.py)."""
     rec = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))
-    r = rec[f"{'oned' if model == 'oned' else 'svat'}_{'lazy' if lazy else 'eager'}"]
+    r = rec[f"{'oned' if model == 'oned' else 'svat'}_{variant}"]
     return r["load_bytes"], r["store_bytes"]
 
 
@@ -574,6 +575,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.timing_summary()
     per_ms, per_dt = ctx.timing_detail()
+    sparse_steps = ctx.sparse_steps()   # of the timed call
     ctx.enable_timing(False)
     s1 = ctx.get_scalars()
     if world > 1:
@@ -585,12 +587,23 @@ def main():
 
     if rank == 0:
         value = world * n_local * args.steps / elapsed
-        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
         lazy, tail = ctx.step_mode()
-        ld_b, st_b = kernel_bytes_per_cell(args.model, lazy)
+        # Inside one rh_run_steps call every step but the last leaves out the stores of the planes the step only produces (sparse
+        # stores, include/roger_hip.h); the last step stores everything.  The roofline prices the DOMINANT launch -- the sparse
+        # variant, averaged over the launches that ran it -- with the bytes THAT variant moves; the full-store launch is reported beside it.
+        n_sparse = sparse_steps if sparse_steps == launches - 1 and launches == len(per_ms) else 0
+        kind = "sparse" if n_sparse else ("lazy" if lazy else "eager")
+        k_avg_s = (float(per_ms[:n_sparse].mean()) / 1e3) if n_sparse else kernel_ms / 1e3 / max(launches, 1)
+        ld_b, st_b = kernel_bytes_per_cell(args.model, kind)
         algo = (ld_b + st_b) * n_local
         achieved = algo / k_avg_s / 1e9
-        variant = f"k_step_{'oned' if args.model == 'oned' else 'svat'}_{'lazy' if lazy else 'eager'}"
+        variant = f"k_step_{'oned' if args.model == 'oned' else 'svat'}_{kind}"
+        full = None
+        if n_sparse:
+            fl, fs = kernel_bytes_per_cell(args.model, "lazy")
+            full = {"kernel": variant.replace("sparse", "lazy"), "launches": launches - n_sparse, "avg_kernel_ms": float(per_ms[n_sparse:].mean()),
+                    "algorithmic_bytes_per_cell": {"load": fl, "store": fs},
+                    "frac": (fl + fs) * n_local / (float(per_ms[n_sparse:].mean()) / 1e3) / 1e9 / HBM_PEAK_GBS}
         traffic, trec = measured_traffic(variant, n_local)
         ref_achieved = REFERENCE_BYTES_PER_CELL_STEP * n_local / k_avg_s / 1e9
         out = {
@@ -625,7 +638,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": variant + (", control part of the next step in its tail" if tail else ""),
+                "kernel": variant + (", control part of the next step in its tail" if tail or n_sparse else ""),
                 "note": "achieved = bytes the launch must move (per column the planes this kernel variant loads + stores once: "
                         f"{ld_b} + {st_b} B, roger_amd/csrc/rh_step_bytes.json from the ISA) / average kernel duration by HIP events; "
                         "traffic = HBM bytes per launch by PMC (profiles/traffic.json) if this variant was profiled at this size; "
@@ -644,8 +657,9 @@ def main():
                 "reference_equivalent": {"bytes_per_cell_step": REFERENCE_BYTES_PER_CELL_STEP, "achieved": ref_achieved,
                                          "ratio_to_peak": ref_achieved / HBM_PEAK_GBS},
                 "avg_kernel_ms": k_avg_s * 1e3,
-                "launches_timed": launches,
-                "outside_kernel_us_per_step": (elapsed / args.steps - k_avg_s) * 1e6,
+                "launches_timed": n_sparse if n_sparse else launches,
+                "full_store_launch": full,   # the call's last step (stores every plane), or null when no step ran with sparse stores
+                "outside_kernel_us_per_step": (elapsed - kernel_ms / 1e3) / args.steps * 1e6,
             },
             "clocks_mhz": {"before": clocks0, "after": device_clocks()},
         }

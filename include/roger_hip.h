@@ -123,6 +123,7 @@ int rh_planes_held(const rh_ctx *ctx);
  * step (adaptive_time_stepping.py:22-381 for the step to come), so that no control kernel runs in between. */
 #define RH_STEP_MODE_LAZY 1
 #define RH_STEP_MODE_TAIL 2
+#define RH_STEP_MODE_SPARSE 4   /* it did not store the planes the step only produces (never the last step of a call) */
 int rh_step_mode(const rh_ctx *ctx);
 
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s);
@@ -258,6 +259,16 @@ int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, c
 int rh_hooks_phase(rh_ctx *ctx);
 /* nsteps whole time steps, hooks included, enqueued back to back on the stream. */
 int rh_run_steps(rh_ctx *ctx, int64_t nsteps);
+/* Sparse stores inside rh_run_steps / rh_run_steps_dist (measurement, tests).  The reference overwrites its flux and diagnostic arrays
+ * every step (`vs.q_ss = update(...)`), and inside ONE call nothing but the next step looks at the planes; so every step of a call
+ * that another step follows leaves out the stores of the planes the step only PRODUCES -- planes no step reads before assigning
+ * them, derived from rh_physics.h by the flow analysis of tools/liveness.py (72 of the SVAT step's 124 stored planes).  The last step
+ * of a call stores everything: after the call every plane holds what n full steps leave.  Off when an accumulator
+ * (rh_diag_configure) was given such a plane, and with RH_NO_SPARSE_STORES=1.
+ *   rh_plane_is_pure_output  1 if the fused step of the SVAT (lateral = 0) / oneD (lateral = 1) model only produces the plane
+ *   rh_sparse_steps          steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores */
+int rh_plane_is_pure_output(int lateral, int plane);
+int64_t rh_sparse_steps(const rh_ctx *ctx);
 /* Device address of the 64-bit predicate words (uint64_t[4]); combine over ranks with OR. */
 void *rh_predicate_words(rh_ctx *ctx);
 /* RCCL has no bitwise reduction: spread predicate word `word` into 64 int32 0/1 values at the

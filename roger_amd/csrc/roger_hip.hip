@@ -139,6 +139,11 @@ struct rh_ctx {
     // lazy tau -> taum1 rotation (k_step<.,.,LAZY>): rot_consistent = the last thing that touched the planes was a complete
     // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
     bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
+    // sparse stores (k_step<.,.,LAZY,SPARSE>): sparse_next = the step being enqueued is followed by another step of the same
+    // rh_run_steps call; outputs_stale = the last fused step did not store the pure-output planes (only ever true INSIDE a call,
+    // or after a call that failed half-way); diag_reads_sparse = an accumulator was given one of those planes
+    bool sparse_ok = true, sparse_next = false, outputs_stale = false, diag_reads_sparse = false, last_sparse = false;
+    int64_t call_sparse_steps = 0;   // steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores
     bool agg_daily_stale;   // per-cell daily forcing sums must be re-formed (new weights; first use)
     bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
     double *diag_buf;
@@ -1101,6 +1106,10 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // pair of after_timestep.  Then the X_m1 planes are neither loaded (the register is filled from X's, AL) nor stored;
 // they are materialised from the X planes when somebody else needs them (materialise_m1).  Per column and step this
 // saves the 30 rotation stores and the 11 X_m1 loads of the step: 328 of 1 986 bytes.
+// SPARSE (with LAZY; every step of an rh_run_steps call that another step of the same call follows): the planes the step only
+// PRODUCES -- fluxes and diagnostics that no step reads back, RH_SPARSE_FIELDS_* from the flow analysis of tools/liveness.py -- are
+// not stored.  Nothing but the next step looks at the planes between two steps of one call, that step overwrites them as the
+// reference's arrays are overwritten, and the call's last step stores everything: what the caller can observe is unchanged.
 #define AL(xm1, x) c.xm1 = c.x;
 #define RH_LOADS(seq, rt)                                          \
     if constexpr (LAZY) {                                          \
@@ -1109,7 +1118,9 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
         RH_SEQ_##seq##_LOAD_##rt(LD)                               \
     }
 #define RH_STORES(seq, rt)                                               \
-    if constexpr (LAZY) {                                                \
+    if constexpr (LAZY && SPARSE) {                                      \
+        RH_SEQ_##seq##_SSTORE_##rt(ST)                                   \
+    } else if constexpr (LAZY) {                                         \
         RH_SEQ_##seq##_LSTORE_##rt(ST)                                   \
     } else {                                                             \
         RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)       \
@@ -1197,7 +1208,7 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 }
 
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
-template <bool MONTHLY, bool LATERAL, bool LAZY>
+template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE>
 RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep) {
     {
     const Consts K = D->K;
@@ -1238,7 +1249,7 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
 // flags: RH_TAIL_*; grp_shift: 2^grp_shift workgroups per completion group; dst64: the summary word for the exchange between
 // ranks, written by the tail (or null)
-template <int MODE, bool LATERAL, bool LAZY>
+template <int MODE, bool LATERAL, bool LAZY, bool SPARSE = false>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int flags, int grp_shift, int *dst64) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
     // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
@@ -1261,8 +1272,8 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     unsigned dep = 1;
     const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
     if (i < a.n) {
-        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY>(a, D, Xp, i, q, bad, dep);
-        else step_column<false, LATERAL, LAZY>(a, D, Xp, i, q, bad, dep);
+        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
+        else step_column<false, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
     } else {
         post_summary(D, 0ull, dep);
     }
@@ -1289,6 +1300,11 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     if (__shfl((int)last, 0)) step_tail(D, tail_lds, flags, dst64);
 #endif
 }
+
+#ifdef RH_CENSUS   // tools/isa_census.py: the sparse variant of the non-monthly pipeline on its own (the product launches MODE 2 only)
+template __global__ void k_step<0, false, true, true>(Arena, DevState *, int, int, int *);
+template __global__ void k_step<0, true, true, true>(Arena, DevState *, int, int, int *);
+#endif
 
 #define RH_CELL_KERNEL(kname, rt, call)                                       \
     __global__ __launch_bounds__(RH_BLOCK) void kname(Arena a, DevState *D) { \
@@ -1618,6 +1634,19 @@ static const unsigned char PLANE_IS_INT[] = {
 #undef RH_I2
 };
 
+// planes the fused step only produces (tools/liveness.py -> RH_SPARSE_FIELDS_* in rh_sets.inc), per model: [0] SVAT, [1] oneD
+static const std::vector<unsigned char> *pure_output_planes() {
+    static const std::vector<unsigned char> tab[2] = {
+        [] { std::vector<unsigned char> t(RH_NPLANES, 0);
+#define RH_MARK(name) t[RH_P_##name] = 1;
+             RH_SPARSE_FIELDS_SVAT(RH_MARK) return t; }(),
+        [] { std::vector<unsigned char> t(RH_NPLANES, 0);
+             RH_SPARSE_FIELDS_ONED(RH_MARK)
+#undef RH_MARK
+             return t; }()};
+    return tab;
+}
+
 static int fail(rh_ctx *ctx, int code, const std::string &msg) {
     if (ctx)
         ctx->err = msg;
@@ -1796,6 +1825,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->pred_daily_stale = true;
     ctx->diag_reads_m1 = false;
     ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
+    ctx->sparse_ok = std::getenv("RH_NO_SPARSE_STORES") == nullptr;
     for (auto &b : ctx->forc_cell_buf) b = nullptr;
     for (auto &b : ctx->weight_buf) b = nullptr;
     ctx->station_buf = nullptr;
@@ -2042,6 +2072,9 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_download: null host pointer");
+    if (ctx->outputs_stale && pure_output_planes()[ctx->cfg.enable_lateral_flow ? 1 : 0][plane])   // only after an rh_run_steps call that failed half-way
+        return fail(ctx, RH_ERR_STATE, "rh_download: the last rh_run_steps call ended before its final step; this flux / diagnostic plane holds an "
+                                       "earlier step's values (run one more step)");
     materialise_m1(ctx);
     if (elem == sizeof(double))
         hipLaunchKernelGGL(k_plane_gather<double>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, plane, (double *)ctx->stage_buf);
@@ -2435,9 +2468,16 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     // lazy rotation: the planes were last touched by a complete fused step (X_m1 == X) and nobody who reads X_m1 planes
     // follows inside this call (the accumulator kernel may, if it was given an X_m1 plane)
     const bool lazy = ctx->lazy_ok && ctx->rot_consistent && !ctx->diag_reads_m1;
+    // sparse stores: another step of the same rh_run_steps call follows and nothing in between reads what this one only produces
+    const bool sparse = lazy && ctx->sparse_next && monthly < 0 && !ctx->diag_reads_sparse;
+    ctx->sparse_next = false;
 #define RH_LAUNCH_STEP(MODE)                                          \
     do {                                                              \
-        if (lat && lazy)                                              \
+        if (MODE == 2 && lat && sparse)                               \
+            RH_LAUNCH_K((k_step<2, true, true, true>));               \
+        else if (MODE == 2 && sparse)                                 \
+            RH_LAUNCH_K((k_step<2, false, true, true>));              \
+        else if (lat && lazy)                                         \
             RH_LAUNCH_K((k_step<MODE, true, true>));                  \
         else if (lat)                                                 \
             RH_LAUNCH_K((k_step<MODE, true, false>));                 \
@@ -2451,6 +2491,8 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     else RH_LAUNCH_STEP(0);
     ctx->rot_consistent = true;   // a complete step: after_timestep's X_m1 = X holds, physically (eager) or logically (lazy)
     ctx->m1_stale = lazy;
+    ctx->outputs_stale = ctx->last_sparse = sparse;
+    ctx->call_sparse_steps += sparse ? 1 : 0;
 #undef RH_LAUNCH_STEP
 #undef RH_LAUNCH_K
     CHECK_LAUNCH(ctx);
@@ -2695,6 +2737,10 @@ int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, c
 }
 
 static void launch_hooks(rh_ctx *ctx) {
+    // the hook rewrites D->S (itt_forc, itt_day, the calendar), D->forc and D->monthly: a control part the previous fused kernel's
+    // tail formed for the next step (S_next / X_next) was formed BEFORE this hook ran and must not be used
+    ctx->pending_valid = false;
+    ctx->exch_valid = false;
     hipLaunchKernelGGL(k_set_forcing, dim3(1), dim3(RH_BLOCK), 0, ctx->stream, ctx->dev);
 }
 int rh_hooks_phase(rh_ctx *ctx) {
@@ -2850,6 +2896,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
 int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
+    ctx->call_sparse_steps = 0;
     for (int64_t k = 0; k < nsteps; ++k) {
         int rc;
         if (ctx->cfg.enable_routing_1D) {
@@ -2859,8 +2906,10 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
                 launch_hooks(ctx);
                 rc = rh_step_routed(ctx, -1);
             }
-        } else
+        } else {
+            ctx->sparse_next = ctx->sparse_ok && k + 1 < nsteps;   // the call's last step stores every plane
             rc = step_fused_launches(ctx, -1, 1);
+        }
         if (rc) return rc;
     }
     return RH_OK;
@@ -2916,6 +2965,7 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
+    ctx->call_sparse_steps = 0;
     if (ctx->cfg.enable_routing_1D) {   // the routed step exchanges its predicate words and edge columns itself
         for (int64_t k = 0; k < nsteps; ++k) {
             int rc;
@@ -2953,6 +3003,7 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
             NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
         LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv);
         CHECK_LAUNCH(ctx);
+        ctx->sparse_next = ctx->sparse_ok && k + 1 < nsteps;
         int rc = launch_fused_kernel(ctx, -1, 0, send);   // the tail spreads the next step's summary word into `send`
         if (rc) return rc;
     }
@@ -2969,6 +3020,9 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         if (planes[j] < 0 || planes[j] >= ctx->planes_held || PLANE_IS_INT[planes[j]])
             return fail(ctx, RH_ERR_ARG, "rh_diag_configure: plane ids must name float64 planes");
     }
+    ctx->diag_reads_sparse = false;   // an accumulated pure-output plane must be in memory after every step
+    for (int j = 0; j < n_rate + n_collect; ++j)
+        if (pure_output_planes()[ctx->cfg.enable_lateral_flow ? 1 : 0][planes[j]]) ctx->diag_reads_sparse = true;
     ctx->diag_reads_m1 = false;   // an accumulated X_m1 plane keeps the fused kernel from skipping its stores
     for (int j = 0; j < n_rate + n_collect; ++j) {
         const size_t len = std::strlen(PLANE_NAMES[planes[j]]);
@@ -3127,9 +3181,13 @@ int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
     return n;
 }
 
+int rh_plane_is_pure_output(int lateral, int plane) {
+    return (plane >= 0 && plane < RH_NPLANES) ? pure_output_planes()[lateral ? 1 : 0][plane] : -1;
+}
+int64_t rh_sparse_steps(const rh_ctx *ctx) { return ctx ? ctx->call_sparse_steps : 0; }
 int rh_step_mode(const rh_ctx *ctx) {
     if (!ctx) return 0;
-    return (ctx->m1_stale ? RH_STEP_MODE_LAZY : 0) | (ctx->pending_valid ? RH_STEP_MODE_TAIL : 0);
+    return (ctx->m1_stale ? RH_STEP_MODE_LAZY : 0) | (ctx->pending_valid ? RH_STEP_MODE_TAIL : 0) | (ctx->last_sparse ? RH_STEP_MODE_SPARSE : 0);
 }
 
 void *rh_predicate_words(rh_ctx *ctx) { return ctx ? (void *)ctx->dev->words : nullptr; }

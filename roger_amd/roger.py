@@ -282,6 +282,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
             if not neutral:   # eberbaechle/svat_distributed/svat.py:169-186, 276-296
                 ctx.set_forcing_weights(*weights)
         self._device_hooks = True
+        self._per_cell_forcing = bool(self.state.settings.enable_distributed_input or not neutral)
 
     def _stepper(self, one_exchange):
         key = "_stepper_one" if one_exchange else "_stepper_three"
@@ -295,7 +296,12 @@ class RogerSetup(metaclass=abc.ABCMeta):
         vs = self.state.variables
         vs.flush_to_device()
         ctx = self.state.backend_context
-        if rst.proc_num > 1:
+        if rst.proc_num > 1 and getattr(self, "_per_cell_forcing", False):
+            # per-cell forcing (station weights / several stations): every column forms its own prec / ta, so both predicate words are
+            # evaluated over the columns and exchanged -- the three-phase protocol (rh_run_steps_dist and the summary path need
+            # forcing shared by all columns and say so with RH_ERR_STATE)
+            self._stepper(one_exchange=False).run(nsteps)
+        elif rst.proc_num > 1:
             # several ranks: one exchange of the summary word per step -- from C over RCCL where the context offers it
             # (rh_comm_init + rh_run_steps_dist), through torch.distributed otherwise
             if hasattr(ctx, "run_steps_dist"):

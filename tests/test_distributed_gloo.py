@@ -301,3 +301,63 @@ def test_routing_on_two_ranks(tmp_path, oracle, device_hooks):
         np.testing.assert_array_equal(d["scal"], [gs[0], gs[1], gs[2], gs[3], gs[6]], err_msg=f"rank {r}")
         got[:, d["sel"]] = d["snap"]
     compare(got, ref, names, what=f"routing on 2 ranks, step {nsteps}")
+
+
+def _per_cell_worker(rank, world, port, case, nsteps, out_dir):
+    """run_device() on two ranks with per-cell forcing (station weights / several stations): the three-phase protocol, both
+    predicate words evaluated over every rank's columns and all-reduced (rh_run_steps_dist and the summary path refuse
+    per-cell forcing)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from roger_amd import runtime_settings
+
+    runtime_settings.update(num_proc=(world, 1))
+    import oracle_binding as ob
+    import oracle_context
+    import svat_scripts as S
+    from golden_util import load_case, load_stations, load_weights
+    from roger_amd import _native
+    from roger_amd.distributed import get_chunk_slices
+
+    _native.Context = oracle_context.OracleContext
+    _native.plane_table = lambda: list(zip(ob.plane_names(), ob.plane_is_int()))
+    g, names, forcing = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    (gx, gy), _ = get_chunk_slices(nx, ny, (world, 1), rank)
+    p = {k: v[gx, gy] for k, v in S.params_from_golden(g, names).items()}
+    w = load_weights(g)
+    weights = {k: v.reshape(nx, ny)[gx, gy] for k, v in w.items()} if w else None
+    stations = None
+    if load_stations(g) is not None:
+        stations = dict(station_ids=g["station_station_ids"], station_id=np.asarray(g["station_station_id"]).reshape(nx, ny)[gx, gy],
+                        PREC=g["station_PREC"], TA=g["station_TA"], PET=g["station_PET"])
+    model = S.make_model(p, forcing, len(forcing["PREC"]) // 144, global_shape=(nx, ny), weights=weights, stations=stations)
+    model.setup()
+    model.run_device(nsteps)
+    assert model._per_cell_forcing
+    vs = model.state.variables
+    sel = np.arange(nx * ny).reshape(nx, ny)[gx, gy].ravel()
+    np.savez(os.path.join(out_dir, f"percell{rank}.npz"), snap=S.snapshot_from_vs(vs, names), sel=sel,
+             scal=np.array([int(vs.itt), int(vs.time), int(vs.dt_secs), int(vs.itt_day)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,nsteps", [("svat_eberbaechle_weights", 100), ("svat_stations", 120)])
+def test_per_cell_forcing_on_two_ranks(tmp_path, oracle, case, nsteps):
+    """The distributed catchment setups (eberbaechle/svat_distributed/svat.py:276-296; svat_dist.py:274-322) with num_proc = (2, 1):
+    snow falls on part of the grid only, so the step length is decided by columns of BOTH ranks; the two-rank run_device() reproduces
+    the reference's single-domain run."""
+    from golden_util import compare, load_case
+
+    port = 29500 + (os.getpid() % 2000) + 31 + (case == "svat_stations")
+    mp.spawn(_per_cell_worker, args=(2, port, case, nsteps, str(tmp_path)), nprocs=2, join=True)
+    g, names, _ = load_case(case)
+    gs = g["scal"][nsteps - 1]
+    got = np.full_like(g[f"s{nsteps:05d}"], np.nan)
+    for r in range(2):
+        d = np.load(tmp_path / f"percell{r}.npz")
+        np.testing.assert_array_equal(d["scal"], [gs[0], gs[1], gs[2], gs[3]], err_msg=f"rank {r}")
+        got[:, d["sel"]] = d["snap"]
+    compare(got, g[f"s{nsteps:05d}"], names, what=f"{case} on 2 ranks, step {nsteps}")

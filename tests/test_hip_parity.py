@@ -686,3 +686,29 @@ def test_per_cell_forcing_keeps_the_rotation_pending(native, monkeypatch):
         ctx.close()
     np.testing.assert_array_equal(out["deferred"][0], out["stored"][0])
     assert np.array_equal(out["deferred"][1], out["stored"][1], equal_nan=True)
+
+
+def test_hooks_phase_between_fused_steps(native):
+    """rh_hooks_phase rewrites the control scalars (itt_forc, itt_day, the calendar) and the day's forcing: a control part that the
+    previous fused kernel's tail formed for the next step is stale after it.  [rh_hooks_phase; rh_svat_step] per step
+    equals rh_run_steps over several midnights and a month change."""
+    import hip_util as H
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    nsteps = int(g["nsteps"])
+    a = _ctx(native, g, names)
+    a.set_forcing_series(forcing)
+    a.run_steps(nsteps)
+    b = _ctx(native, g, names)
+    b.set_forcing_series(forcing)
+    days = set()
+    for _ in range(nsteps):
+        b.call("rh_hooks_phase")
+        b.step(-1)
+        days.add(b.get_scalars().time // 86400)
+    assert len(days) >= 10
+    np.testing.assert_array_equal(H.scalars_to_row(a.get_scalars()), H.scalars_to_row(b.get_scalars()))
+    np.testing.assert_array_equal(H.scalars_to_row(b.get_scalars()), g["scal"][nsteps - 1])
+    np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(b, names))
+    a.close()
+    b.close()

@@ -17,6 +17,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import liveness  # noqa: E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(REPO, "roger_amd", "csrc", "rh_physics.h")
@@ -195,6 +198,20 @@ def main():
         lines.append(f"#define RH_SET_LOAD_{name}(X) " + " ".join(f"X({n})" for n in ld))
         lines.append(f"#define RH_SET_STORE_{name}(X) " + " ".join(f"X({n})" for n in st))
         lines.append("")
+    # Pure outputs of the fused step per model (tools/liveness.py): planes no step ever needs from memory.  k_step<..., SPARSE>
+    # (every step of an rh_run_steps call but the last) does not store them.  A plane counts only if it is a pure output of BOTH
+    # pipelines the kernel holds (with and without the monthly surface parameters), is not the source of a deferred tau -> taum1
+    # copy whose X_m1 the step reads (the lazy kernel fills that register from the X PLANE), and is no X_m1 plane itself.
+    analyser = liveness.Analyser(funcs)
+    rotated_all = {xm1 for xm1, _ in pairs}
+
+    def sparse_of(stages):
+        pure, summ = liveness.pure_outputs(analyser, stages, pairs)
+        alias_src = {x for xm1, x in pairs if xm1 in summ.ue}
+        return (pure - rotated_all) - alias_src
+
+    sparse = {"svat": sparse_of(SEQUENCES["step"]) & sparse_of(SEQUENCES["step_monthly"]),
+              "oned": sparse_of(SEQUENCES["step_lateral"]) & sparse_of(SEQUENCES["step_lateral_monthly"])}
     for seq, stages in SEQUENCES.items():
         resident, all_m, all_w = set(), set(), set()
         lines.append(f"// sequence {seq}: " + " -> ".join(stages))
@@ -260,9 +277,10 @@ def main():
             resident_l |= need_l
             rec["lst"] = rec["st"] - rotated
             rec["alias"] = sorted(alias_at.get(i, []), key=lambda p: order.get(p[0]))
+            rec["sst"] = rec["lst"] - sparse["oned" if "lateral" in seq else "svat"]
         for rec in recs:
             rt = rec["rt"]
-            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st"), ("LLOAD", "lld"), ("LSTORE", "lst")):
+            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st"), ("LLOAD", "lld"), ("LSTORE", "lst"), ("SSTORE", "sst")):
                 lines.append(f"#define RH_SEQ_{seq}_{kind}_{rt}(X) " + " ".join(f"X({n})" for n in sorted(rec[key], key=order.get)))
             lines.append(f"#define RH_SEQ_{seq}_ALIAS_{rt}(A) " + " ".join(f"A({xm1}, {x})" for xm1, x in rec["alias"]))
         # the fused kernel samples the summary bits of the next step's predicates (roger_hip.hip, k_step): prec and ta
@@ -300,6 +318,10 @@ def main():
             if all_m != ref_m or all_w != ref_w:
                 sys.exit(f"sequence {seq} does not match {PLAIN_CHECK[seq]}")
         lines.append("")
+    for model in ("svat", "oned"):
+        lines.append(f"// planes the fused {model} step only produces ({len(sparse[model])}): not stored by the steps of an rh_run_steps call that another step follows")
+        lines.append(f"#define RH_SPARSE_FIELDS_{model.upper()}(X) " + " ".join(f"X({n})" for n in sorted(sparse[model], key=order.get)))
+    lines.append("")
     # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x
     lines.append("// tau -> taum1 rotation of after_timestep (h_rotate): " + str(len(pairs)) + " pairs")
     lines.append("#define RH_ROTATION_FIELDS(X) " + " ".join(f"X({x})" for _, x in sorted(pairs, key=lambda p: order.get(p[1]))))

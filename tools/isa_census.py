@@ -39,7 +39,7 @@ def census():
             st = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "store")
             out["mode0_" + mr.group(1)] = {"load_bytes": ld, "store_bytes": st, "in_loops": 0}
             continue
-        m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])EEv", fn)
+        m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])ELb([01])EEv", fn)
         if not m:
             continue
         body = fn[: fn.find("s_endpgm")]
@@ -50,8 +50,8 @@ def census():
             else:
                 st += WIDTH[w]
         in_loop = 0
-        mode, lateral, lazy = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
-        out[f"mode{mode}_{'oned' if lateral else 'svat'}_{'lazy' if lazy else 'eager'}"] = {"load_bytes": ld, "store_bytes": st, "in_loops": in_loop}
+        mode, lateral, lazy, sparse = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
+        out[f"mode{mode}_{'oned' if lateral else 'svat'}_{'sparse' if sparse else ('lazy' if lazy else 'eager')}"] = {"load_bytes": ld, "store_bytes": st, "in_loops": in_loop}
     return out
 
 

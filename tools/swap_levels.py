@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """Does the fused kernel's speed level belong to the arena or to the rest of the context?  K contexts alive in one process (the
-staircase of tools/arena_levels.py); per context the level of the fused step and of the calibration copy on its arena; then the first
+staircase of tools/arena_levels.py); per context the level of the fused step; then the first
 and the last context exchange their arenas (rh_debug_swap_arenas) and everything is measured again.
     python tools/swap_levels.py [contexts=6]"""
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -27,16 +26,6 @@ def level(c, steps=60):
     return v
 
 
-def copy_ms(c, reps=20):
-    c.calibrate_copy(0, 100, 96)
-    c.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        c.calibrate_copy(0, 100, 96)
-    c.sync()
-    return (time.perf_counter() - t0) / reps * 1e3
-
-
 ctxs = []
 for _ in range(k):
     c = create_svat(1000, 1000)
@@ -47,7 +36,6 @@ for _ in range(k):
 addr = lambda c: c._lib.rh_plane_device_ptr(c._h, 0)   # noqa: E731
 print("arena addresses      : " + " ".join(f"{addr(c):x}" for c in ctxs))
 print("fused step, ms       : " + " ".join(f"{level(c):.4f}" for c in ctxs), flush=True)
-# the copy overwrites planes: measure it on scratch contexts' state AFTER the step levels, then restore nothing (levels only)
 print("fused step, ms       : " + " ".join(f"{level(c):.4f}" for c in ctxs), flush=True)
 a, b = ctxs[0], ctxs[-1]
 assert a._lib.rh_debug_swap_arenas(a._h, b._h) == 0
@@ -55,5 +43,3 @@ print("first <-> last arena swapped")
 print("arena addresses      : " + " ".join(f"{addr(c):x}" for c in ctxs))
 print("fused step, ms       : " + " ".join(f"{level(c):.4f}" for c in ctxs), flush=True)
 print("fused step, ms       : " + " ".join(f"{level(c):.4f}" for c in ctxs), flush=True)
-print("calibration copy, ms : " + " ".join(f"{copy_ms(c):.4f}" for c in ctxs), flush=True)
-print("calibration copy, ms : " + " ".join(f"{copy_ms(c):.4f}" for c in ctxs), flush=True)
