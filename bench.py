@@ -384,6 +384,81 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
     ctx.close()
 
 
+def bench_setup(args, torch, device):
+    """`--stepping setup | hooks`: the SVAT / oneD benchmark as a RogerSetup SCRIPT calling plain `run()` (roger/roger.py:523-580), one
+    GPU.  setup: the script leaves the per-step hooks to the model class -- run() then advances through rh_run_steps under
+    rh_set_time_limit, a few rounds per run.  hooks: the script brings a per-step hook of its own (here a read_data that does
+    nothing), so run() keeps the reference's loop: set_forcing / set_parameters / after_timestep on the host and three native calls
+    per step (rh_adaptive_dt, rh_step_core, rh_after_timestep).  One step = one model time step; the run covers `--days` days
+    after `--warmup-days` untimed ones, the steps are counted from vs.itt."""
+    from roger_amd import roger_routine
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.models.oned import ONEDSetup
+    from roger_amd.models.svat import SVATSetup
+    from roger_amd.svat import BENCHMARK_PARAMS
+
+    nx, ny = args.size
+    p = {k: v for k, v in BENCHMARK_PARAMS.items() if k not in ("theta_rz", "theta_ss")}
+    if args.model == "oned":
+        p.update(z_soil=1000.0, lmpv=600.0, slope=0.05, dmph=50.0)
+    base = ONEDSetup if args.model == "oned" else SVATSetup
+
+    class Benchmark(base):
+        initial_theta = dict(theta_rz=BENCHMARK_PARAMS["theta_rz"], theta_ss=BENCHMARK_PARAMS["theta_ss"])
+
+    if args.stepping == "hooks":
+        class Benchmark(Benchmark):   # noqa: F811
+            @roger_routine
+            def read_data(self, state):   # a per-step hook of the script's own: run() must keep calling it
+                pass
+
+    total_days = args.warmup_days + args.days
+    model = Benchmark(forcing=combo_forcing(ndays=total_days + 2), nx=nx, ny=ny, ndays=total_days, parameters=p)
+    model.setup()
+    state = model.state
+    assert model.device_run_possible() is (args.stepping == "setup")
+    ctx = state.backend_context
+
+    def run_days(days):
+        with state.settings.unlock():
+            state.settings.runlen = days * 86400
+        vs = state.variables
+        itt0 = int(vs.itt)
+        ctx.sync()
+        t0 = time.perf_counter()
+        model.run()
+        ctx.sync()
+        return time.perf_counter() - t0, int(vs.itt) - itt0
+
+    run_days(args.warmup_days)
+    elapsed, steps = run_days(args.days)
+    n = nx * ny
+    out = {
+        "metric": "cell-timesteps/sec on SVAT_benchmark grid",
+        "value": n * steps / elapsed,
+        "unit": "cell-timesteps/s",
+        "n_gpus": 1,
+        "steps": steps,
+        "warmup": args.warmup_days,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{'oneD' if args.model == 'oned' else 'SVAT'}_benchmark as a RogerSetup script calling run(): nx*ny={n} ({nx}x{ny}), uniform benchmark "
+                        f"parameters, combo forcing (seed 42), {args.days} days after {args.warmup_days} untimed ones",
+            "cells_per_gpu": n,
+            "stepping": "RogerSetup.run(): " + ("stock per-step hooks, rh_run_steps under rh_set_time_limit (rounds)" if args.stepping == "setup"
+                                                else "a per-step hook of the script's own: the reference's loop, hooks on the host, rh_adaptive_dt + rh_step_core + rh_after_timestep per step"),
+            "wall_s": elapsed,
+        },
+    }
+    print(json.dumps(out))
+    ctx.close()
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start N ranks of this script, one per GPU of this node, as CHILD processes
     (never exec: the parent stays the process the caller waits for), hand them the rendezvous through RANK / LOCAL_RANK / WORLD_SIZE /
@@ -467,6 +542,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
+    ap.add_argument("--stepping", choices=("device", "setup", "hooks"), default="device",
+                    help="device: rh_run_steps driven by this script (the headline line); setup / hooks: the benchmark as a RogerSetup "
+                         "script calling plain run() with the model class's stock hooks / with a per-step hook of its own (one GPU)")
+    ap.add_argument("--days", type=int, default=20, help="--stepping setup | hooks: days of the timed run()")
+    ap.add_argument("--warmup-days", type=int, default=2, help="--stepping setup | hooks: days of the untimed run() in front")
     ap.add_argument("--launch-check", action="store_true",
                     help="the launcher's own test: start the ranks, form the process group over gloo, all-reduce the rank ids and print "
                          "one line -- no GPU work, no model (tests/test_bench_launcher.py)")
@@ -500,6 +580,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+
+    if args.stepping != "device":
+        if world != 1 or args.model == "sas":
+            raise SystemExit("--stepping setup | hooks: one GPU, --model svat | oned")
+        return bench_setup(args, torch, device)
 
     if args.model == "sas":
         bench_sas(args, torch, dist, rank, local_rank, world, device)

@@ -268,6 +268,13 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps);
  *   rh_plane_is_pure_output  1 if the fused step of the SVAT (lateral = 0) / oneD (lateral = 1) model only produces the plane
  *   rh_sparse_steps          steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores */
 int rh_plane_is_pure_output(int lateral, int plane);
+/* "Run until": the reference's driver loop is `while vs.time - start_time < runlen: step()` (roger/roger.py:548-556), and the length
+ * of a step is decided on the device.  With a limit set, the control part of a step (on the device) finds the run over once the model
+ * time has reached t_end: that launch and every later one do nothing (the accumulators included), so a caller may enqueue more steps
+ * than the run has left -- rh_run_steps(ctx, n) then runs min(n, steps until t_end) -- and read the time afterwards.  The step that
+ * reaches the limit stores every plane.  t_end < 0 clears the limit.  Observed by the summary path (forcing shared by all columns, no
+ * routing); rh_run_steps / rh_run_steps_dist report RH_ERR_STATE otherwise.  Synchronises. */
+int rh_set_time_limit(rh_ctx *ctx, int64_t t_end);
 int64_t rh_sparse_steps(const rh_ctx *ctx);
 /* Device address of the 64-bit predicate words (uint64_t[4]); combine over ranks with OR. */
 void *rh_predicate_words(rh_ctx *ctx);

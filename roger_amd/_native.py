@@ -126,6 +126,7 @@ def load():
     lib.rh_placement_report.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.rh_step_mode.argtypes = [vp]
     lib.rh_plane_is_pure_output.argtypes = [i32, i32]
+    lib.rh_set_time_limit.argtypes = [vp, i64]
     lib.rh_sparse_steps.argtypes = [vp]
     lib.rh_sparse_steps.restype = i64
     lib.rh_set_forcing_stations.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
@@ -397,7 +398,7 @@ DECLARED_SYMBOLS = (
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
-    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_run_steps_dist",
+    "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_set_time_limit", "rh_run_steps_dist",
     "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_planes_held", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
 
@@ -633,6 +634,10 @@ class Context:
         that another step follows)."""
         lat = int(self.lateral)
         return [nm for nm, p in self.index.items() if self._lib.rh_plane_is_pure_output(lat, p) == 1]
+
+    def set_time_limit(self, t_end):
+        """No step begins at or beyond model time t_end (None / negative: no limit): rh_run_steps(n) then runs at most n steps."""
+        self._check(self._lib.rh_set_time_limit(self._h, -1 if t_end is None else int(t_end)), "rh_set_time_limit")
 
     def sparse_steps(self):
         return int(self._lib.rh_sparse_steps(self._h))

@@ -125,6 +125,9 @@ struct StepCtx {
     int64_t itt_day;
     int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 2: from the per-cell aggregates; 0: k_select did
     int forc_exhausted;   // the device-side set_forcing hook found midnight beyond the end of the resident series
+    // rh_set_time_limit (RogerSetup.run(): `while vs.time - start_time < runlen`, roger/roger.py:548-556, decided on the device):
+    int halt;             // the time limit was reached before this step: the launch does nothing
+    int last;             // this step reaches the limit: it stores every plane (never the sparse variant)
 };
 
 // predicate bit positions, word 0 (start of step) and word 1 (after prec/ta selection)

@@ -96,6 +96,8 @@ struct DevState {
     const double *series[3];
     const int64_t *calendar[3];
     int64_t nitt_forc;
+    long long t_end;                   // rh_set_time_limit: no step begins at or beyond this model time (< 0: no limit)
+    int skipped;                       // the last fused launch found its step halted and did nothing (read by k_diag)
     int monthly;                       // set_parameters' month-change test, evaluated on the device
     const double *weights[3];          // per-cell prec_weight, ta_offset, pet_weight (rh_set_forcing_weights) or null
     // several meteorological stations (settings.enable_distributed_input, roger/variables.py:6383-6402): the resident series are
@@ -143,6 +145,7 @@ struct rh_ctx {
     // rh_run_steps call; outputs_stale = the last fused step did not store the pure-output planes (only ever true INSIDE a call,
     // or after a call that failed half-way); diag_reads_sparse = an accumulator was given one of those planes
     bool sparse_ok = true, sparse_next = false, outputs_stale = false, diag_reads_sparse = false, last_sparse = false;
+    int64_t t_end = -1;              // rh_set_time_limit (host copy of DevState::t_end)
     int64_t call_sparse_steps = 0;   // steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores
     bool agg_daily_stale;   // per-cell daily forcing sums must be re-formed (new weights; first use)
     bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
@@ -692,6 +695,8 @@ RH_DEV double agg_pick(const StepCtx &X, int sel, int off) {
 // the bookkeeping itself, on copies of the scalars and of the step context
 RH_DEV int64_t scalars_update(rh_scalars &S, StepCtx &X, unsigned long long w, int do_finish, int apply_sel, bool per_cell, int64_t ee) {
     X.apply_sel = apply_sel;
+    X.halt = 0;   // (the time limit is the summary path's, ctrl_wave: it sets `last` after this bookkeeping)
+    X.last = 0;
     const bool ev_start = bit(w, PC_RAIN) || bit(w, PC_SNOWMELT);
     const bool ev_end = !bit(w, PC_PREC_NOT_LE0) || !bit(w, PC_NOT_PGT0_TALE) || (bit(w, PC_SWEM1_GT0) && !bit(w, PC_SWE_NOT_LE0));
     int64_t dts = X.dt_secs_prelim;
@@ -839,6 +844,10 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
     Kf.hpi = hpi_i;
     Kf.ta_fm = ta_fm;
     bool fresh_day = false;
+    const long long t_end = D->t_end;
+    X.halt = (t_end >= 0 && S.time >= t_end) ? 1 : 0;   // the run is over (roger/roger.py:548): nothing is formed, S stays as it is
+    X.last = 0;
+    if (X.halt) return;
     X.forc_exhausted = 0;
     if (do_hooks) {   // hooks_set_forcing: benchmarks/SVAT_benchmark.py:105-110, 151-171
         const bool midnight = (S.time % 86400 == 0);
@@ -936,6 +945,7 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         }
     }
     const int64_t dts = scalars_update(S, X, derive_word1(cells, X, Kf), 1, 1, false, end_event);
+    X.last = (t_end >= 0 && S.time >= t_end) ? 1 : 0;   // (S.time is the END of the step that is being formed)
     if (lane == 0) {
         D->words[0] = 0;
         D->words[1] = 0;
@@ -965,10 +975,10 @@ __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src,
     ctrl_wave(D, L, S, X, cells, do_hooks);
     if (lane == 0) {
         D->words[3] = cells;
-        D->sanity_last = 0;
+        if (!X.halt) D->sanity_last = 0;
         D->S = S;
         D->X = X;
-        if (X.forc_exhausted) D->err_flags |= RH_DEVERR_FORCING;
+        if (X.forc_exhausted && !X.halt) D->err_flags |= RH_DEVERR_FORCING;
     }
 }
 // The tail of the fused kernel, run by the wavefront that finishes last: folds the summary words into words[3] (and, for the
@@ -1026,7 +1036,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
 // the control kernel before the fused kernel ran.
 __global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    if (i >= a.n) return;
+    if (i >= a.n || D->skipped) return;   // (skipped: the fused launch in front found the run over, rh_set_time_limit)
     const int64_t t0 = D->S.time - D->S.dt_secs, iv = D->diag_interval;
     const int64_t slot = (t0 / iv) % D->diag_slots;
     const bool first = (t0 % iv) == 0;   // steps never straddle an interval boundary they do not start on (adaptive_time_stepping)
@@ -1265,15 +1275,31 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #endif
     __shared__ unsigned wg_done;      // wavefronts of this workgroup that are through
     __shared__ CtrlLds tail_lds;      // scratch of the tail (one wavefront of the whole grid uses it)
+    const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
+    // rh_set_time_limit: the control part found the run over before this step (uniform over the grid).  Nothing runs, the tail
+    // included: S_next / X_next keep saying so to every launch that follows.
+    const bool halted = Xp->halt != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        D->skipped = halted ? 1 : 0;
+        if (halted) log_dt(D, 0);     // (timing: a launch that did nothing is logged with dt = 0)
+    }
+    if (halted) return;
     if (threadIdx.x == 0) wg_done = 0;
     __syncthreads();                  // (at the start, where all waves are in step; the kernel has no closing barrier)
     unsigned long long q = 0;
     bool bad = false;
     unsigned dep = 1;
-    const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
     if (i < a.n) {
-        if (MODE == 1 || (MODE == 2 && D->monthly != 0)) step_column<true, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
-        else step_column<false, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
+        const bool monthly = MODE == 1 || (MODE == 2 && D->monthly != 0);
+        // the SPARSE kernel holds the full-store pipeline too: the step that reaches the time limit is the run's last one
+        // (X.last, decided by the control part on the device) and stores every plane -- a wave-uniform branch
+        if (SPARSE && !Xp->last) {
+            if (monthly) step_column<true, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
+            else step_column<false, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
+        } else {
+            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
+            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
+        }
     } else {
         post_summary(D, 0ull, dep);
     }
@@ -1942,6 +1968,11 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
     if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    {
+        static const long long no_limit = -1;
+        if ((e = hipMemcpyAsync(&ctx->dev->t_end, &no_limit, sizeof(no_limit), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return bail(e, "hipMemcpy(t_end)");
+    }
     Consts K;
     K.pi = cfg->pi; K.r_mp = cfg->r_mp; K.l_sc = cfg->l_sc; K.sf = cfg->sf; K.ta_fm = cfg->ta_fm; K.rmax = cfg->rmax;
     K.transp_water_stress = cfg->transp_water_stress; K.atol = cfg->atol; K.rtol = cfg->rtol;
@@ -2893,10 +2924,38 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     return RH_OK;
 }
 
+int rh_set_time_limit(rh_ctx *ctx, int64_t t_end) {
+    if (!ctx) return RH_ERR_ARG;
+    const long long v = t_end < 0 ? -1 : (long long)t_end;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->t_end, &v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (v is a stack local)
+    ctx->t_end = v;
+    ctx->pending_valid = false;   // a control part formed under the old limit (possibly "halt") is not the next step's
+    return RH_OK;
+}
+// with a time limit: 1 if the limit is reached already (nothing to enqueue), 0 if the first launch of the call will run a step --
+// the host-side flags that a fused launch leaves behind (rotation, summary, pending control part) are those of a launch that RAN,
+// which holds for every later launch of the call too once the first one did (a halted launch changes nothing on the device)
+static int limit_reached(rh_ctx *ctx, bool *reached) {
+    *reached = false;
+    if (ctx->t_end < 0) return RH_OK;
+    if (ctx->cfg.enable_routing_1D || ctx->per_cell)
+        return fail(ctx, RH_ERR_STATE, "rh_set_time_limit: the limit is observed by the summary path's control part (forcing shared by all columns, "
+                                       "no routing); clear it (rh_set_time_limit(ctx, -1)) and bound the steps from the host");
+    int64_t now = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&now, &ctx->dev->S.time, sizeof(now), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *reached = now >= ctx->t_end;
+    return RH_OK;
+}
+
 int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     ctx->call_sparse_steps = 0;
+    bool over = false;
+    if (int rc = limit_reached(ctx, &over)) return rc;
+    if (over) return RH_OK;
     for (int64_t k = 0; k < nsteps; ++k) {
         int rc;
         if (ctx->cfg.enable_routing_1D) {
@@ -2966,6 +3025,9 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
     ctx->call_sparse_steps = 0;
+    bool over = false;
+    if (int rc = limit_reached(ctx, &over)) return rc;
+    if (over) return RH_OK;
     if (ctx->cfg.enable_routing_1D) {   // the routed step exchanges its predicate words and edge columns itself
         for (int64_t k = 0; k < nsteps; ++k) {
             int rc;

@@ -32,6 +32,9 @@ class ONEDSetup(SVATSetup):
         vs.update(after_timestep_kernel(state))
 
 
+ONEDSetup.after_timestep.device_equivalent = True   # the oneD rotation is the fused oneD kernel's (see models/svat.py)
+
+
 @roger_kernel
 def after_timestep_kernel(state):
     """models/oneD/oneD.py: tau -> taum1 rotation (no snapping of the pore storages); native."""

@@ -132,6 +132,13 @@ class SVATSetup(RogerSetup):
         vs.update(after_timestep_kernel(state))
 
 
+# The per-step hooks above are what the device-side control part performs itself (roger_hip.hip: hooks_set_forcing / ctrl_wave, the
+# monthly pipeline of k_step, the rotation inside the fused kernel): RogerSetup.run() advances on the device as long as a setup
+# script does not override them (roger_amd/roger.py: device_run_possible).
+for _hook in (SVATSetup.read_data, SVATSetup.set_boundary_conditions, SVATSetup.set_forcing, SVATSetup.set_parameters, SVATSetup.after_timestep):
+    _hook.device_equivalent = True
+
+
 @roger_kernel
 def after_timestep_kernel(state):
     """tau -> taum1 rotation of the prognostic variables (roger/models/svat/svat.py:187-384);

@@ -240,6 +240,63 @@ class RogerSetup(metaclass=abc.ABCMeta):
             state.sas_context.sync()
             logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
 
+    # the per-step user hooks; when all of them are the stock ones of the ready-made models (marked `device_equivalent`: the
+    # device-side control part performs exactly these, roger_hip.hip ctrl_wave), run() needs no host code between two steps
+    STEP_HOOKS = ("read_data", "set_boundary_conditions", "set_forcing", "set_parameters", "after_timestep")
+
+    def device_run_possible(self):
+        """True if `run()` may advance on the device without returning to the host between steps: the setup script left the
+        per-step hooks to the model class (SVATSetup / ONEDSetup: forcing series sliced at midnight, monthly surface parameters,
+        tau -> taum1 rotation), and nothing was asked for that needs the host after every step."""
+        settings = self.state.settings
+        if settings.enable_offline_transport or rs.profile_mode or settings.restart_frequency > 0:
+            return False
+        if not all(getattr(getattr(type(self), h, None), "device_equivalent", False) for h in self.STEP_HOOKS):
+            return False
+        return hasattr(self.state.backend_context, "run_steps")
+
+    def _run_on_device(self, start_time, runlen):
+        """`while vs.time - start_time < runlen: step()` (roger/roger.py:548-556) without the host in the loop.  The step length is
+        decided on the device, so the number of steps is not known beforehand.  The device is given the end of the run
+        (rh_set_time_limit): the control part of a step finds the run over and the launches behind it do nothing, so rounds of steps
+        may be enqueued generously -- the first one ceil(remaining / day) steps (a step covers at most a day), the following ones what
+        the mean step length so far suggests plus a margin -- with the time read back after each round: a handful of
+        synchronisations per run instead of three native calls per step.  Output intervals are fetched before their slots on the
+        device are reused.  Without a time limit (per-cell forcing, routing: their control parts do not observe it) every round is
+        ceil(remaining / day) steps, which can never overshoot."""
+        state = self.state
+        vs = state.variables
+        ctx = state.backend_context
+        if not getattr(self, "_device_hooks", False):
+            self.enable_device_hooks()
+        t_stop = start_time + runlen
+        slots = iv = None
+        if getattr(state, "_diag_active", None) and not getattr(state, "_diag_transport", False):
+            slots, iv = state._diag_slots, state._diag_interval   # output intervals resident on the device; their length
+        limit = hasattr(ctx, "set_time_limit") and not getattr(self, "_per_cell_forcing", False) and not state.settings.enable_routing_1D
+        try:
+            steps0, first = int(vs.itt), True
+            while True:
+                now = int(vs.time)
+                if now >= t_stop:
+                    break
+                # a round ends where the run ends, or where the output intervals it may start would not fit the device's slots
+                t_round = t_stop if slots is None else min(t_stop, (now // iv + slots - 1) * iv)
+                n = -(-(t_round - now) // 86400)          # a step covers at most a day: this many steps never overshoot
+                if limit:
+                    vs.flush_to_device()
+                    ctx.set_time_limit(t_round)
+                    done = int(vs.itt) - steps0
+                    if not first and done > 0:             # what the mean step length so far suggests, and a margin
+                        n = max(n, int((t_round - now) / max(600.0, (now - start_time) / done) * 1.1) + 8)
+                elif slots is not None:
+                    n = min(n, max(1, slots - 1))          # (a step starts at most one output interval)
+                self.run_device(int(n), final=False)
+                first = False
+        finally:
+            if limit:
+                ctx.set_time_limit(None)
+
     def run(self, show_progress_bar=None):
         """roger/roger.py:523-580"""
         self._ensure_setup_done()
@@ -248,8 +305,11 @@ class RogerSetup(metaclass=abc.ABCMeta):
         runlen = settings.runlen if settings.warmup_done else settings.runlen_warmup   # roger/roger.py:541-546
         start_time = vs.time
         try:
-            while vs.time - start_time < runlen:
-                self.step(self.state)
+            if self.device_run_possible():
+                self._run_on_device(int(start_time), int(runlen))
+            else:
+                while vs.time - start_time < runlen:
+                    self.step(self.state)
         finally:
             if settings.write_restart and not settings.enable_offline_transport:   # roger/roger.py:577-579
                 restart.write_restart(self.state, force=True)
@@ -290,7 +350,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
             setattr(self, key, distributed.PhasedStepper(distributed.phases_for(self.state.backend_context, one_exchange=one_exchange)))
         return getattr(self, key)
 
-    def run_device(self, nsteps):
+    def run_device(self, nsteps, final=True):
         if not getattr(self, "_device_hooks", False):
             self.enable_device_hooks()
         vs = self.state.variables
@@ -315,4 +375,4 @@ class RogerSetup(metaclass=abc.ABCMeta):
             ctx.run_steps(nsteps)
         vs.mark_device_newer()
         if getattr(self.state, "_diag_active", None):
-            diagnostics.output(self.state, final=True)
+            diagnostics.output(self.state, final=final)

@@ -274,8 +274,13 @@ class OracleContext:
         self._after_adt(m, False, w1)
         return w0, w1, w1_local
 
+    def set_time_limit(self, t_end):
+        self._t_end = None if t_end is None or int(t_end) < 0 else int(t_end)
+
     def run_steps(self, nsteps):
         for _ in range(int(nsteps)):
+            if getattr(self, "_t_end", None) is not None and int(self.st.scal.time) >= self._t_end:
+                return   # rh_set_time_limit: the launches that would follow do nothing
             self._hooks()
             self.step(-1)
 

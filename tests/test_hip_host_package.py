@@ -283,3 +283,29 @@ def test_routing_example_from_text_inputs(tmp_path):
         assert f.variables["Time"].shape == (26,)
     assert out[1:].sum() > 0
     np.testing.assert_allclose(inn[1:, 1:], out[1:, :-1], rtol=1e-9, atol=1e-12)   # every cell drains into the next one along y
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "oned_hetero_heavyrain"])
+def test_run_with_stock_hooks_on_the_device(case, tmp_path):
+    """`RogerSetup.run()` of a setup that leaves the per-step hooks to the model class (SVATSetup / ONEDSetup) advances through
+    rh_run_steps under rh_set_time_limit -- a few rounds, no host code between steps -- and ends in the reference's state at the
+    end of the run with the reference's step count (tests/test_host_package.py runs the same against the hook-preserving loop)."""
+    import svat_scripts as S
+    from test_host_package import _stock_model
+
+    ndays = min(12, len(load_case(case)[2]["PREC"]) // 144)
+    g, names, m = _stock_model(case, ndays)
+    m.setup()
+    assert m.device_run_possible()
+    rounds = []
+    inner = m.run_device
+    m.run_device = lambda n, final=True: (rounds.append(n), inner(n, final=final))[1]
+    m.run()
+    vs = m.state.variables
+    nsteps = int(np.sum(g["scal"][:, 1] <= ndays * 86400))
+    assert (int(vs.itt), int(vs.time)) == (nsteps, ndays * 86400) and len(rounds) <= 6
+    key = f"s{nsteps:05d}"
+    if key in g.files:
+        compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case}: run() on the device, step {nsteps}")
+    gs = g["scal"][nsteps - 1]
+    assert (int(vs.dt_secs), int(vs.itt_day), int(vs.event_id_counter)) == (gs[2], gs[3], gs[6])

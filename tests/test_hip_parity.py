@@ -712,3 +712,47 @@ def test_hooks_phase_between_fused_steps(native):
     np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(b, names))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "oned_hetero_heavyrain"])
+def test_time_limit_stops_the_run_on_the_device(native, case):
+    """rh_set_time_limit: `while vs.time - start_time < runlen: step()` (roger/roger.py:548-556) decided by the control part on the
+    device.  More steps are enqueued than the run has left; exactly the reference's steps run, the step that reaches the limit
+    stores every plane (the others of the call ran with sparse stores), the launches behind it change nothing -- accumulators
+    included --, and a later limit continues the run."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    stops = sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit())
+    stop = next(s for s in stops if s >= 40)     # a stored step: its end time is the limit
+    t_stop = int(g["scal"][stop - 1][1])
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_series(forcing)
+    ctx.diag_configure(rate=["S_fp_rz"], collect=["S_lp_rz"], n_slots=64)   # (state planes: sparse stores stay on)
+    ctx.set_time_limit(t_stop)
+    ctx.enable_timing(True)
+    ctx.run_steps(stop + 37)
+    ms, dts = ctx.timing_detail()
+    ctx.enable_timing(False)
+    assert len(ms) == stop + 37 and (dts[:stop] > 0).all() and (dts[stop:] == 0).all()   # the launches behind the limit did nothing
+    assert ctx.sparse_steps() >= stop - 2
+    s = ctx.get_scalars()
+    np.testing.assert_array_equal(H.scalars_to_row(s), g["scal"][stop - 1])
+    snap = H.download_snapshot(ctx, names)
+    compare(snap, g[f"s{stop:05d}"], names, what=f"{case}: stopped by the time limit at step {stop}")
+    day = (t_stop - 1) // 86400     # the output interval the last step belongs to
+    acc = ctx.diag_download("S_fp_rz", day % 64), ctx.diag_steps(day % 64)
+    ctx.run_steps(5)                                                   # over: nothing is even enqueued
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][stop - 1])
+    np.testing.assert_array_equal(H.download_snapshot(ctx, names), snap)
+    np.testing.assert_array_equal(ctx.diag_download("S_fp_rz", day % 64), acc[0])
+    assert ctx.diag_steps(day % 64) == acc[1]
+    nxt = next(s for s in stops if s > stop)
+    ctx.set_time_limit(int(g["scal"][nxt - 1][1]))                     # the run goes on to the next stored step
+    ctx.run_steps(10 * (nxt - stop) + 100)
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][nxt - 1])
+    compare(H.download_snapshot(ctx, names), g[f"s{nxt:05d}"], names, what=f"{case}: second limit, step {nxt}")
+    ctx.set_time_limit(None)
+    ctx.run_steps(3)
+    np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][nxt + 2])
+    ctx.close()

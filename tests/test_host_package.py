@@ -448,3 +448,86 @@ def test_routed_setup_reproduces_reference(oracle_backend):
     fast.setup()
     fast.run_device(nsteps)
     compare(S.snapshot_from_vs(fast.state.variables, names), g[f"s{nsteps:05d}"], names, what="run_device")
+
+
+def _stock_model(case, ndays, tmp_path=None, override_hook=False):
+    """The ready-made model class with its stock per-step hooks (SVATSetup / ONEDSetup), parameters and forcing of a golden case."""
+    import svat_scripts as S
+    from golden_util import is_lateral
+    from roger_amd.models.oned import ONEDSetup
+    from roger_amd.models.svat import SVATSetup
+    from roger_amd.routines import roger_routine
+
+    g, names, forcing = load_case(case)
+    nx, ny = (int(v) for v in g["nx_ny"])
+    p = {k: np.asarray(v).reshape(nx, ny) for k, v in S.params_from_golden(g, names).items()}
+    theta = {"theta_rz": p.pop("theta_rz0")[:, :, None], "theta_ss": p.pop("theta_ss0")[:, :, None]}   # both time levels
+    base = ONEDSetup if is_lateral(g) else SVATSetup
+
+    class Model(base):
+        initial_theta = theta
+
+        @roger_routine
+        def set_diagnostics(self, state):
+            if tmp_path is not None:
+                d = state.diagnostics
+                d["rate"].output_variables = ["prec", "aet", "q_ss"]
+                d["collect"].output_variables = ["S_rz", "theta"]
+                for k in ("rate", "collect"):
+                    d[k].output_frequency, d[k].sampling_frequency, d[k].base_output_path = 86400, 1, str(tmp_path)
+
+    if override_hook:   # a setup script with a per-step hook of its own: run() must keep calling it
+        calls = []
+
+        class Model(Model):   # noqa: F811
+            @roger_routine
+            def read_data(self, state):
+                calls.append(int(state.variables.itt))
+
+        Model.calls = calls
+    m = Model(forcing=forcing, nx=nx, ny=ny, ndays=ndays, parameters=p)
+    return g, names, m
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "oned_hetero_heavyrain"])
+def test_run_with_stock_hooks_stays_on_the_device(oracle_backend, case, tmp_path):
+    """`RogerSetup.run()` (roger/roger.py:523-580) of a setup script that leaves the per-step hooks to the model class advances
+    through rh_run_steps in rounds of ceil(remaining / day) steps -- no host code between two steps -- and ends in the same state,
+    step count and output files as the hook-preserving loop, which a script with a hook of its own still gets."""
+    import svat_scripts as S
+    from roger_amd import runtime_settings as rs
+
+    ndays = min(6, len(load_case(case)[2]["PREC"]) // 144)
+    prev = rs.diskless_mode
+    object.__setattr__(rs, "diskless_mode", False)
+    try:
+        out = {}
+        for tag, override in (("device", False), ("hooks", True)):
+            d = tmp_path / tag
+            d.mkdir()
+            g, names, m = _stock_model(case, ndays, d, override_hook=override)
+            m.setup()
+            assert m.device_run_possible() is (not override)
+            rounds = []
+            if not override:
+                inner = m.run_device
+                m.run_device = lambda n, final=True: (rounds.append(n), inner(n, final=final))[1]
+            m.run()
+            vs = m.state.variables
+            out[tag] = (int(vs.itt), int(vs.time), S.snapshot_from_vs(vs, names), d, rounds, getattr(type(m), "calls", None))
+    finally:
+        object.__setattr__(rs, "diskless_mode", prev)
+    a, b = out["device"], out["hooks"]
+    assert a[0] == b[0] and a[1] == b[1] == ndays * 86400
+    assert a[4][0] == ndays and len(a[4]) <= 8 and sum(a[4]) >= a[0]          # a few generous rounds (the device stops at the end of the run)
+    assert b[5] == list(range(a[0]))                                          # the script's own hook ran before every step
+    np.testing.assert_array_equal(a[2], b[2])
+    from scipy.io import netcdf_file
+
+    for kind, keys in (("rate", ("prec", "aet", "q_ss")), ("collect", ("S_rz", "theta"))):
+        ident = m.state.settings.identifier
+        with netcdf_file(str(a[3] / f"{ident}.{kind}.nc"), "r", mmap=False) as fa, netcdf_file(str(b[3] / f"{ident}.{kind}.nc"), "r", mmap=False) as fb:
+            assert fa.variables["Time"].shape == (ndays + 1,)
+            np.testing.assert_array_equal(fa.variables["Time"][:], fb.variables["Time"][:])
+            for k in keys:
+                np.testing.assert_allclose(fa.variables[k][:], fb.variables[k][:], rtol=1e-13, atol=1e-13, err_msg=f"{kind} {k}")
