@@ -1409,6 +1409,30 @@ RH_PASS_KERNEL(k_routed_c_after,
                RH_PSTAGE(routed_c_after, rt_storage, rt_storage(c, X))
                RH_PSTAGE(routed_c_after, rt_num_error_routed, bad = rt_num_error_routed(c, K))
                RH_PSTAGE(routed_c_after, rt_after_timestep_oned, rt_after_timestep_oned(c)))
+// The step core of the hook-preserving flow (rh_step_core: RogerSetup.step() with the user hooks on the host) as ONE staged pass -- the
+// fused kernel's pipeline without its selection, rotation and control parts.  k_step_core / k_step_core_lateral, which load every
+// plane up front, need 256 VGPRs + 92 / 118 AGPRs and run at one wave per SIMD; kept for A/B (RH_STEP_CORE_UNSTAGED).
+#define RH_CORE_HEAD(seq)                                                                          \
+    RH_PSTAGE(seq, rt_interception, rt_interception(c, K))                                         \
+    RH_PSTAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                             \
+    RH_PSTAGE(seq, rt_snow, rt_snow(c, K, X))                                                      \
+    RH_PSTAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                          \
+    RH_PSTAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                          \
+    RH_PSTAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                  \
+    RH_PSTAGE(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                          \
+    RH_PSTAGE(seq, rt_inf_finish, rt_inf_finish(c, K, X))
+RH_PASS_KERNEL(k_core_staged,
+               RH_CORE_HEAD(core)
+               RH_PSTAGE(core, rt_subsurface_runoff, rt_subsurface_runoff(c, X))
+               RH_PSTAGE(core, rt_capillary_rise, rt_capillary_rise(c, X))
+               RH_PSTAGE(core, rt_storage, rt_storage(c, X))
+               RH_PSTAGE(core, rt_num_error, bad = rt_num_error(c, K)))
+RH_PASS_KERNEL(k_core_staged_lateral,
+               RH_CORE_HEAD(core_lateral)
+               RH_PSTAGE(core_lateral, rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X))
+               RH_PSTAGE(core_lateral, rt_capillary_rise, rt_capillary_rise(c, X))
+               RH_PSTAGE(core_lateral, rt_storage, rt_storage(c, X))
+               RH_PSTAGE(core_lateral, rt_num_error_lateral, bad = rt_num_error_lateral(c, K)))
 // Device-driven stepping (rh_run_steps / rh_run_steps_dist on a routing context): the first pass with the step's forcing selection [and
 // the monthly surface parameters, D->monthly] in front, as the fused kernel has them, and the columns' summary bits for the NEXT step's
 // control kernel posted as soon as they are final (k_ctrl reads them from sumw: no predicate passes over the arena between two steps).
@@ -2275,10 +2299,14 @@ static int routed_core(rh_ctx *ctx, bool with_after);
 int rh_step_core(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     if (ctx->cfg.enable_routing_1D) return routed_core(ctx, false);   // the columns are coupled: routine by routine with the two gathers
-    if (ctx->cfg.enable_lateral_flow)
-        LAUNCH_CELLS(ctx, k_step_core_lateral);
-    else
-        LAUNCH_CELLS(ctx, k_step_core);
+    static const bool unstaged = std::getenv("RH_STEP_CORE_UNSTAGED") != nullptr;   // A/B, tests: the single-function kernels
+    if (ctx->cfg.enable_lateral_flow) {
+        if (unstaged) LAUNCH_CELLS(ctx, k_step_core_lateral);
+        else LAUNCH_CELLS(ctx, k_core_staged_lateral);
+    } else {
+        if (unstaged) LAUNCH_CELLS(ctx, k_step_core);
+        else LAUNCH_CELLS(ctx, k_core_staged);
+    }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     // the output accumulators follow every step, also in the hook-preserving flow (itt / time were just advanced)
     if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);

@@ -3,10 +3,12 @@ file layout -- an HDF5 file whose group "core" holds one dataset per variable un
 array shape (2-cell ghost frame included, trailing `timesteps` axis for the two-level variables, 0-d datasets for the scalars;
 roger/restart.py:32-67, 129-174), so that states can go back and forth between the two implementations.
 
-* What is written: every `write_to_restart` variable of the reference that this path holds (`REFERENCE_RESTART_VARIABLES`, read off
-  roger/variables.py) AND every other variable of the arena: the reference's own list does not carry the whole state of a step
-  (`prec`, `ta`, the event bookkeeping of the wetting fronts ... are missing from it), with the rest of the planes a restarted run
-  continues BIT FOR BIT (tests/test_hip_restart.py).  The reference's reader looks datasets up by name and ignores the others.
+* What is written: group "core" = every `write_to_restart` variable of the reference that this path holds
+  (`REFERENCE_RESTART_VARIABLES`, read off roger/variables.py) and nothing else -- the reference's reader walks every dataset of
+  "core" and fails on a name that is not on its list (roger/restart.py:15-16); group "hip_core" = every other variable of the arena:
+  the reference's own list does not carry the whole state of a step (`prec`, `ta`, the event bookkeeping of the wetting fronts ... are
+  missing from it), with the rest of the planes a restarted run continues BIT FOR BIT (tests/test_hip_restart.py).  Exchanged with
+  the reference in both directions: tests/test_restart_interchange.py.
 * The device-side output accumulators (rh_diag_*) go into the group "hip_diag": a restart in the middle of an output interval keeps
   the partial sums.
 * Several ranks (num_proc = (N, 1)): the slabs are gathered to rank 0, which writes ONE file with the global arrays like the
@@ -43,8 +45,32 @@ REFERENCE_RESTART_VARIABLES = (
     "inf_mat_event_csum", "inf_mp_event_csum", "inf_sc_event_csum", "evap_int", "prec_event_csum", "t_event_csum", "c_int",
     # scalars (0-d datasets)
     "time", "time_event0", "itt", "itt_day", "itt_forc", "year", "month", "doy", "dt", "dt_secs", "event_id", "event_id_counter",
+    # the forcing series and the grid (the reference restarts them too)
+    "PREC", "TA", "PET", "YEAR", "MONTH", "DOY", "x", "y",
 )
+# ... and the rest of the reference's list for these models: variables of modules outside this path (crops, film flow, radiation) and
+# registry constants.  The reference's reader insists on finding EVERY variable of its list (roger/restart.py:93-97), so a file that
+# the reference is to accept carries them with the values the reference itself writes for an SVAT / oneD run: its initial values
+# (read off a restart file of the reference, tests/golden/restart/reference_restart.h5).  name: (dims, dtype, value)
+REFERENCE_ONLY_RESTART_VARIABLES = {
+    **{k: (("x", "y"), "float64", 0.0) for k in (
+        "Fs_t1", "c1_mak", "c2_mak", "dmpv_crop", "frac_fp", "frac_lp", "lmpv_crop", "t_sat_t0", "t_sat_t1", "theta_ac_ss", "theta_d_rel_t1",
+        "theta_eff", "theta_fp", "theta_lp", "theta_pc", "theta_water_stress", "water_stress_fp")},
+    "zroot_to_zsoil_max": (("x", "y"), "float64", 0.75),
+    "maskUrban": (("x", "y"), "bool", 0),
+    "RS": (("t_forc",), "float64", 0.0),
+    **{k: ((), "int64", v) for k, v in dict(itt_cr=0, itt_substep=0, tau=1, taum1=0, taup1=2, tau_event=0, time_for_diag=86400).items()},
+    "z": (("z",), "float64", 0.0),
+}
+# on the reference's list only with settings.enable_lateral_flow (oneD model)
+_LATERAL_ONLY = ("dmph",) + tuple(f"z_sat_layer_{i}" for i in range(1, 9))
 _NOT_STATE = ("tau", "taup1", "taum1")   # constants of the registry
+MORE_GROUP = "hip_core"   # the variables of the arena that are not on the reference's restart list
+# inputs that set_forcing_setup puts back at setup(), not state: the station series and the calendar (at 10^6 columns the series of a
+# distributed setup and the per-cell day arrays below are gigabytes)
+_FORCING_SERIES = ("PREC_DIST", "TA_DIST", "PET_DIST")   # (the single station's series are on the reference's own list: kept)
+# the day's 144 slots per cell: set_forcing re-derives them from itt_forc at midnight, so they are state only in the middle of a day
+_FORCING_DAY = ("prec_day", "ta_day", "pet_day")
 
 
 def _h5py():
@@ -111,14 +137,28 @@ def collect(state):
     vs = state.variables
     core = {}
     multi = rst.proc_num > 1
+    midnight = int(np.asarray(vs.time)) % 86400 == 0
+    more = {}
     for key, var in state.var_meta.items():
-        if key in _NOT_STATE:
+        if key in _NOT_STATE or key in _FORCING_SERIES or (midnight and key in _FORCING_DAY):
             continue
         val = np.asarray(getattr(vs, key))
         if multi and var.dims is not None and tuple(var.dims[:2]) == ("x", "y"):
             val = _gather_global(state, key, val)
-        core[key] = val
-    groups = {"core": core}
+        # the reference's reader walks EVERY dataset of "core" and looks it up in its own restart list (roger/restart.py:15-16:
+        # a KeyError for anything else), so "core" holds exactly that list; the rest of the arena goes into a group of its own,
+        # which the reference never opens
+        on_list = key in REFERENCE_RESTART_VARIABLES and (state.settings.enable_lateral_flow or key not in _LATERAL_ONLY)
+        (core if on_list else more)[key] = val
+    sizes = dict(x=state.settings.nx + 4, y=state.settings.ny + 4, t_forc=state.settings.nitt_forc, z=1)
+    for key, (dims, dtype, value) in REFERENCE_ONLY_RESTART_VARIABLES.items():
+        core.setdefault(key, np.full(tuple(sizes[d] for d in dims), value, dtype=dtype))
+    groups = {"core": core, MORE_GROUP: more}
+    # one group per diagnostic of the reference that has restart variables (roger/restart.py:100-126 opens every one of them): the
+    # counters of the monitors and of the average diagnostic, as the reference writes them when those diagnostics are not in use
+    groups.update({"average": {"average_nitts": np.float64(0.0)}, "snapshot": {},
+                   "tracer_monitor": {"C_s": np.float64(0.0), "M_S": np.float64(0.0)},
+                   "water_monitor": {"S_s": np.float64(0.0), "S_sur": np.float64(0.0)}})
     ctx = state.backend_context
     active = getattr(state, "_diag_active", None)
     if active and not getattr(state, "_diag_transport", False) and not multi and hasattr(ctx, "diag_slot_times"):
@@ -168,7 +208,8 @@ def read_restart(state, filename=None):
     groups = _read_file(fname)
     if "core" not in groups:
         raise RuntimeError(f"{fname} has no group 'core': not a RoGeR restart file")
-    core = groups["core"]
+    core = dict(groups["core"])
+    core.update(groups.get(MORE_GROUP, {}))   # a file of the reference has "core" only: the rest keeps what setup() left
     vs = state.variables
     missing = [k for k in REFERENCE_RESTART_VARIABLES if k in state.var_meta and k not in core and k not in ("dmph",) + tuple(
         f"z_sat_layer_{i}" for i in range(1, 9)) + ("slope", "slope_per")]

@@ -310,8 +310,15 @@ class RogerSetup(metaclass=abc.ABCMeta):
             else:
                 while vs.time - start_time < runlen:
                     self.step(self.state)
+        except BaseException:
+            # the forced restart below is a collective on several ranks (the slabs are gathered to rank 0): a rank that leaves run() on
+            # an exception would wait there for peers that are still stepping -- the job would hang instead of failing
+            failed = True
+            raise
+        else:
+            failed = False
         finally:
-            if settings.write_restart and not settings.enable_offline_transport:   # roger/roger.py:577-579
+            if settings.write_restart and not settings.enable_offline_transport and not (failed and rst.proc_num > 1):   # roger/roger.py:577-579
                 restart.write_restart(self.state, force=True)
         (self.state.sas_context or self.state.backend_context).sync()
         diagnostics.close(self.state)

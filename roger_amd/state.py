@@ -284,8 +284,10 @@ class RogerVariables(Lockable):
             object.__setattr__(self, "_scalars_dirty", False)
         if self._forcing_dirty:
             days = [self._host[k][2:-2, 2:-2, :] for k in ("prec_day", "ta_day", "pet_day")]
-            first = [d.reshape(-1, 144)[0] for d in days]
-            if all(np.array_equal(d.reshape(-1, 144), np.broadcast_to(f, (d.shape[0] * d.shape[1], 144)), equal_nan=True)
+            first = [np.array(d[0, 0]) for d in days]
+            # one series for all columns: known from the strides when the hook assigned a broadcast value (operators.update),
+            # compared otherwise (a hook that filled the interior column by column with the same series)
+            if all((d.strides[0] == 0 and d.strides[1] == 0) or bool((np.isnan(d) & np.isnan(f) | (d == f)).all())
                    for d, f in zip(days, first)):
                 self._ctx.set_forcing_day(*first)  # one station series broadcast to all cells
             else:

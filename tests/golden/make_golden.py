@@ -307,7 +307,7 @@ ROUTINES = (
 
 
 def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine_steps, outdir, lateral=False,
-             pair_every=0, weights=None, stations=None, routing=None):
+             pair_every=0, weights=None, stations=None, routing=None, store_forcing=True):
     import importlib
 
     model = make_model(roger, params, forcing, ndays, lateral=lateral, weights=weights, stations=stations, routing=routing)
@@ -381,7 +381,8 @@ def run_case(roger, name, params, forcing, ndays, max_steps, snap_every, routine
         if lateral:
             rec["lut_mlms"] = np.asarray(vs.lut_mlms, dtype=np.float64)[:200]  # slopes 1..200 %
         for k, v in forcing.items():
-            rec[f"forc_{k}"] = v
+            if store_forcing:
+                rec[f"forc_{k}"] = v
         if weights is not None:
             for k, v in weights.items():
                 rec[f"weight_{k}"] = np.asarray(v, dtype=np.float64).ravel()
@@ -463,6 +464,21 @@ def main():
 
         run_case(roger, "svat_eberbaechle_weights", hetero_params(nx, ny, seed=2019), forcing_from_txt(EBERBAECHLE_INPUT, ndays=nd),
                  nd, 100000, 100, {1, 2, 3, 300, 301}, args.out, weights=weights)
+    if args.only == "svat_eberbaechle_full":
+        # BASELINE configs[4] AS WRITTEN: the same twelve columns and weights over the station's FULL series, 2019-11-01 .. 2022-10-31
+        # (157 824 ten-minute records = 1 096 days; the three input files are shipped whole as tests/golden/eberbaechle_full_input).
+        # About 40 minutes of the reference: generated on request only (--only svat_eberbaechle_full).  A snapshot every 1 000 steps,
+        # the scalars of every step; the forcing arrays are not stored (the test reads the text files).
+        nx, ny = 4, 3
+        rng = np.random.default_rng(2019)
+        weights = dict(prec_weight=rng.uniform(0.8, 1.3, (nx, ny)), ta_offset=rng.uniform(-5.5, 1.5, (nx, ny)),
+                       pet_weight=rng.uniform(0.85, 1.15, (nx, ny)))
+        from roger_amd.forcing import forcing_from_txt
+
+        F = forcing_from_txt(EBERBAECHLE_INPUT)
+        nd = len(F["PREC"]) // 144
+        run_case(roger, "svat_eberbaechle_full", hetero_params(nx, ny, seed=2019), F, nd, 10 ** 7, 1000, set(), args.out, weights=weights,
+                 store_forcing=False)
     if not args.only or args.only == "svat_stations":
         # settings.enable_distributed_input: three meteorological stations, every cell mapped to one of them by vs.station_id (one
         # cell to none: it sees zeros), per-cell weights on top (roger/bmimodels/svat_dist/svat_dist.py:274-322)

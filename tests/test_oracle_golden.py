@@ -173,3 +173,30 @@ def test_threads_do_not_change_results():
     assert results[0][1:] == results[1][1:]
     np.testing.assert_array_equal(results[0][0], results[1][0])
     np.testing.assert_array_equal(results[0][0][:, :16], results[0][0][:, 16:32])   # the tiles stay identical
+
+
+def test_eberbaechle_full_series(oracle):
+    """BASELINE configs[4] as written: the Eberbaechle setup's per-cell weighted forcing over the station's FULL series, 2019-11-01 ..
+    2022-10-31 (157 824 ten-minute records shipped whole as tests/golden/eberbaechle_full_input; 1 096 days), twelve heterogeneous
+    columns.  The reference took 14 622 steps (569 daily, 12 367 hourly, 1 686 ten-minute); the oracle takes the same ones -- the
+    integer scalars of EVERY step are the reference's -- and meets every stored state (every 1 000 steps and the last one)."""
+    import os
+
+    from golden_util import GOLDEN_DIR
+    from roger_amd.forcing import forcing_from_txt
+
+    g, names, _ = load_case("svat_eberbaechle_full")
+    forcing = forcing_from_txt(os.path.join(GOLDEN_DIR, "eberbaechle_full_input"))
+    assert len(forcing["PREC"]) == 157824
+    st = _start(oracle, g, names)
+    drv = oracle.ForcingDriver(forcing, weights=load_weights(g))
+    nsteps = int(g["nsteps"])
+    for step in range(1, nsteps + 1):
+        pd, td, ed, monthly = drv.before_step(st)
+        st.step(pd, td, ed, monthly)
+        if not np.array_equal(st.scalars_row(), g["scal"][step - 1]):
+            np.testing.assert_array_equal(st.scalars_row(), g["scal"][step - 1], err_msg=f"scalars step {step}")
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(st.snapshot(), g[key], names, what=f"Eberbaechle full series, step {step}")
+    assert st.scal.time == 1096 * 86400 and st.scal.sanity_ok == 1

@@ -162,11 +162,15 @@ PLAIN_SEQUENCES = {
     "routed_a2_monthly": ["rt_select_prec", "rt_select_pet", "rt_params_surface", "rt_interception", "rt_evapotranspiration", "rt_snow",
                           "rt_inf_events", "rt_inf_matrix", "rt_inf_macropores", "rt_inf_cracks", "rt_inf_finish_routed",
                           "rt_route_surface_out"],
+    # the step core of the hook-preserving flow (rh_step_core: everything between the set_parameters and after_timestep hooks), staged
+    "core": _COMMON_HEAD + ["rt_subsurface_runoff", "rt_capillary_rise", "rt_storage", "rt_num_error"],
+    "core_lateral": _COMMON_HEAD + ["rt_subsurface_runoff_lateral", "rt_capillary_rise", "rt_storage", "rt_num_error_lateral"],
     "routed_b": ["rt_route_surface_in", "rt_subsurface_runoff_lateral", "rt_route_subsurface_out"],
     "routed_c": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed"],
     "routed_c_after": ["rt_route_subsurface_in", "rt_capillary_rise", "rt_storage", "rt_num_error_routed", "rt_after_timestep_oned"],
 }
-PLAIN_CHECK = {"routed_a": "rt_routed_a", "routed_b": "rt_routed_b", "routed_c": "rt_routed_c", "routed_c_after": "rt_routed_c_after"}
+PLAIN_CHECK = {"routed_a": "rt_routed_a", "routed_b": "rt_routed_b", "routed_c": "rt_routed_c", "routed_c_after": "rt_routed_c_after",
+               "core": "rt_step_core", "core_lateral": "rt_step_core_lateral"}
 # stages before which long-lived, momentarily unused planes are evicted from registers (see main())
 EVICT_BEFORE = set(filter(None, os.environ.get("RH_EVICT", "").split(",")))
 # each sequence must cover exactly what the corresponding single-function routine does
