@@ -36,8 +36,14 @@ struct Col {
 #ifndef RH_TILED
 #define RH_TILED 1
 #endif
+// RH_TILE_CELLS: columns per tile, 64 (a wavefront's) or a multiple of it up to the workgroup's 256 -- then a plane's slot holds the
+// columns of 2 or 4 consecutive wavefronts of a workgroup (1 / 2 KiB contiguous per plane and workgroup instead of 512-byte pieces).
+#ifndef RH_TILE_CELLS
 #define RH_TILE_CELLS 64
-#define RH_SLOT_BYTES 512
+#endif
+#define RH_TILE_SHIFT (RH_TILE_CELLS == 64 ? 6 : (RH_TILE_CELLS == 128 ? 7 : 8))
+#define RH_SLOT_BYTES (RH_TILE_CELLS * 8)
+static_assert(RH_TILE_CELLS == 64 || RH_TILE_CELLS == 128 || RH_TILE_CELLS == 256, "RH_TILE_CELLS: 64, 128 or 256");
 
 struct Arena {
     char *base;
@@ -51,8 +57,10 @@ struct Arena {
 template <typename T>
 RH_DEV T *rh_cell(const Arena &a, int plane, int64_t i) {
 #if RH_TILED
-    const int tile = __builtin_amdgcn_readfirstlane((int)(i >> 6));
-    return reinterpret_cast<T *>(a.base + (size_t)tile * a.stride + (size_t)plane * RH_SLOT_BYTES) + (int)(i & (RH_TILE_CELLS - 1));
+    // (uniform over the wavefront: the tile index and, inside a tile of several wavefronts, the wavefront's 64-column piece)
+    const int tile = __builtin_amdgcn_readfirstlane((int)(i >> RH_TILE_SHIFT));
+    const int piece = __builtin_amdgcn_readfirstlane((int)(i & (RH_TILE_CELLS - 1)) & ~63);
+    return reinterpret_cast<T *>(a.base + (size_t)tile * a.stride + (size_t)plane * RH_SLOT_BYTES) + piece + (int)(i & 63);
 #else
     return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
 #endif
@@ -61,7 +69,7 @@ RH_DEV T *rh_cell(const Arena &a, int plane, int64_t i) {
 template <typename T>
 RH_DEV T *rh_cell_any(const Arena &a, int plane, int64_t i) {
 #if RH_TILED
-    return reinterpret_cast<T *>(a.base + (size_t)(i >> 6) * a.stride + (size_t)plane * RH_SLOT_BYTES) + (int)(i & (RH_TILE_CELLS - 1));
+    return reinterpret_cast<T *>(a.base + (size_t)(i >> RH_TILE_SHIFT) * a.stride + (size_t)plane * RH_SLOT_BYTES) + (int)(i & (RH_TILE_CELLS - 1));
 #else
     return reinterpret_cast<T *>(a.base + (size_t)plane * a.stride) + i;
 #endif

@@ -1278,12 +1278,14 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
     // rh_set_time_limit: the control part found the run over before this step (uniform over the grid).  Nothing runs, the tail
     // included: S_next / X_next keep saying so to every launch that follows.
+#ifndef RH_CENSUS   // (tools/isa_census.py counts the per-column memory instructions of ONE pipeline: no halt prologue, no tail)
     const bool halted = Xp->halt != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         D->skipped = halted ? 1 : 0;
         if (halted) log_dt(D, 0);     // (timing: a launch that did nothing is logged with dt = 0)
     }
     if (halted) return;
+#endif
     if (threadIdx.x == 0) wg_done = 0;
     __syncthreads();                  // (at the start, where all waves are in step; the kernel has no closing barrier)
     unsigned long long q = 0;
@@ -1293,7 +1295,11 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
         const bool monthly = MODE == 1 || (MODE == 2 && D->monthly != 0);
         // the SPARSE kernel holds the full-store pipeline too: the step that reaches the time limit is the run's last one
         // (X.last, decided by the control part on the device) and stores every plane -- a wave-uniform branch
+#ifdef RH_CENSUS
+        if (SPARSE) {
+#else
         if (SPARSE && !Xp->last) {
+#endif
             if (monthly) step_column<true, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
             else step_column<false, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
         } else {

@@ -23,7 +23,7 @@ ctx = create_svat(nx, ny, params=hetero_params(n, seed=42))
 ctx.set_forcing_series(F)
 rng = np.random.default_rng(7)
 ctx.set_forcing_weights(rng.uniform(0.8, 1.3, n), rng.uniform(-5.5, 1.5, n), rng.uniform(0.85, 1.15, n))
-ctx.set_time_limit(ndays * 86400) if False else None   # (per-cell forcing: the limit is the summary path's; bounded from the host below)
+# (per-cell forcing: rh_set_time_limit is the summary path's; the rounds are bounded from the host: a step covers at most a day)
 ctx.enable_timing(True)
 t0 = time.perf_counter()
 steps = 0

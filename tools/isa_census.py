@@ -34,7 +34,7 @@ def census():
     for fn in re.split(r"\n(?=_Z\w+:)", txt):
         mr = re.match(r"_Z\d+k_(routed_\w+?)5ArenaP8DevState:", fn)
         if mr:   # the staged passes of the routed step (settings.enable_routing_1D): k_routed_a / _b / _c / _c_after
-            body = fn[: fn.find("s_endpgm")]
+            body = fn[: fn.find(".Lfunc_end")]   # (the whole function: the kernel has early exits)
             ld = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "load")
             st = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "store")
             out["mode0_" + mr.group(1)] = {"load_bytes": ld, "store_bytes": st, "in_loops": 0}
@@ -42,7 +42,7 @@ def census():
         m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])ELb([01])EEv", fn)
         if not m:
             continue
-        body = fn[: fn.find("s_endpgm")]
+        body = fn[: fn.find(".Lfunc_end")]   # (the whole function: the kernel has early exits)
         ld = st = 0
         for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M):
             if op == "load":

@@ -5,7 +5,7 @@
 # SAS bench, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated) of every benched kernel variant and size, and the VALU
 # instruction counters of the SAS kernel.  rocprofv3 is always given the program itself (python3 ...), never a wrapper.
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 export RH_TAG=$tag
 what=${2:-all}
 out=gpurun_out/profiles
@@ -30,16 +30,18 @@ pmc_pair() {   # key, kernel substring, n_cells, calib_cells, program args... (e
 }
 
 if [ "$what" = all ] || [ "$what" = svat ]; then
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 1000000 1000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=oned RH_PMC_SIZE=1000x1000
-  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 1000000 1000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=3200x3125
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 10000000 10000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=oned RH_PMC_SIZE=3200x3125
-  pmc_pair k_step_oned_lazy "k_step<2, true, true>" 10000000 10000000 python3 tools/pmc_workload.py
-  export RH_PMC_MODEL=svat RH_PMC_SIZE=80x53
-  pmc_pair k_step_svat_lazy "k_step<2, false, true>" 4240 4240 python3 tools/pmc_workload.py
+  # the sparse variant (every step of an rh_run_steps call but the last) and, with RH_NO_SPARSE_STORES=1, the full-store lazy variant
+  svat_pairs() {   # model, size, n
+    export RH_PMC_MODEL=$1 RH_PMC_SIZE=$2
+    local lat=false; [ $1 = oned ] && lat=true
+    pmc_pair k_step_$1_sparse "k_step<2, $lat, true, true>" $3 $3 python3 tools/pmc_workload.py
+    RH_NO_SPARSE_STORES=1 pmc_pair k_step_$1_lazy "k_step<2, $lat, true, false>" $3 $3 python3 tools/pmc_workload.py
+  }
+  svat_pairs svat 1000x1000 1000000
+  svat_pairs oned 1000x1000 1000000
+  svat_pairs svat 3200x3125 10000000
+  svat_pairs oned 3200x3125 10000000
+  svat_pairs svat 80x53 4240
   unset RH_PMC_MODEL RH_PMC_SIZE
   cp $out/traffic.json profiles/   # the bench lines take roofline.traffic from the records just written
   bench svat_1e6 --steps 200 --warmup 10
@@ -52,6 +54,17 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   bench svat_80x53 --size 80 53 --params hetero --steps 2000 --warmup 50 --no-cpu-baseline
   bench svat_80x53_station_weights --size 80 53 --params hetero --station-weights --steps 2000 --warmup 50 --no-cpu-baseline
   RH_BENCH_FORCE_DIST=1 bench svat_1e6_rccl_one_rank --steps 200 --warmup 10 --no-cpu-baseline
+  bench svat_1e6_driver_command --gpus 1 --steps 20 --warmup 5
+  RH_NO_SPARSE_STORES=1 bench svat_1e6_full_stores --steps 200 --warmup 10 --no-cpu-baseline
+  # the benchmark as a RogerSetup script calling plain run(): stock hooks (on the device) and a hook of the script's own (the reference's loop)
+  for st in setup hooks; do
+    python3 bench.py --stepping $st --days 20 --warmup-days 2 > $scratch/svat_1e6_$st.out 2> $scratch/svat_1e6_$st.err && last $scratch/svat_1e6_$st.out > $out/${tag}_bench_svat_1e6_run_$st.json && echo "run() $st ok"
+    python3 bench.py --stepping $st --size 80 53 --days 60 --warmup-days 2 > $scratch/svat_80x53_$st.out 2> $scratch/svat_80x53_$st.err && last $scratch/svat_80x53_$st.out > $out/${tag}_bench_svat_80x53_run_$st.json
+  done
+  # BASELINE configs[4] as written: the Eberbaechle shape over the station's full 2019-2022 series
+  python3 tools/eberbaechle_full.py > $out/${tag}_eberbaechle_full_80x53.json 2> $scratch/eberbaechle_full.err && echo "eberbaechle full ok"
+  # what bounds the fused step: SQ counters per launch of every k_step variant
+  tools/svat_pmc.sh svat 1000x1000 > $out/${tag}_svat_sq_counters_1e6.txt 2>&1 && echo "sq counters ok"
   # the default bench command under rocprofv3 --kernel-trace --stats: the kernel's average duration there must agree with the HIP events
   rm -rf $scratch/stats_svat
   rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats_svat -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > $scratch/stats_svat.out 2> $scratch/stats_svat.err \
