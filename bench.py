@@ -536,9 +536,10 @@ def main():
     ap.add_argument("--placement-probes", type=int, default=8,
                     help="svat / oned: candidate arenas rh_create times a streaming copy on before keeping the fastest (DESIGN.md section 5; "
                          "the library's default too; 1 = take the first)")
-    ap.add_argument("--prewarm-ms", type=float, default=0.0,
-                    help="keep the device busy with a plain copy for this long right before the timed region (untimed; the memory-side "
-                         "clocks fall back while the host reads rocm-smi between warm-up and timing)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="keep the device busy with a plain device-to-device copy for this long right before the timed region (untimed, not "
+                         "model steps): a 20-step run is over in 5 ms, before the device has left its idle clocks -- the same 20 steps take "
+                         "7 %% longer without it (profiles/r03_warm_ab.txt); 0 switches it off")
     ap.add_argument("--spinup", type=int, default=107,
                     help="svat / oned, device stepping: untimed steps in FRONT of the warm-up that bring the model to the end of the forcing's "
                          "first heavy-rain event (step 112 with the default --warmup 5), so that the timed steps of even a 20-step run "
@@ -652,9 +653,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    clocks0 = device_clocks() if rank == 0 else None   # (a child process that takes half a second: BEFORE the warm-up, not between it and the timed region)
     run(args.spinup + args.warmup)
     s0 = ctx.get_scalars()
-    clocks0 = device_clocks() if rank == 0 else None
     prewarm(torch, device, args.prewarm_ms)
     ctx.enable_timing(True)
     fence()

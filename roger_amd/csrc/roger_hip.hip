@@ -1505,9 +1505,7 @@ struct RouteHalo {
     const int *flow_dir[2];
     const int *mask[2];
 };
-__global__ __launch_bounds__(RH_BLOCK) void k_route_gather(Arena a, int nx, int ny, int src_plane, int dst_plane, RouteHalo H) {
-    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    if (i >= a.n) return;
+RH_DEV double route_gather_value(const Arena &a, int nx, int ny, int src_plane, int64_t i, const RouteHalo &H) {
     const int ix = (int)(i / ny), iy = (int)(i % ny);
     const int CODE[8] = {64, 128, 1, 2, 4, 8, 16, 32};
     const int DX[8] = {0, -1, 1, 1, 0, -1, -1, -1};
@@ -1535,7 +1533,57 @@ __global__ __launch_bounds__(RH_BLOCK) void k_route_gather(Arena a, int nx, int 
         }
         v[d] = (fd == CODE[d] ? q : 0.0) * (double)mk;
     }
-    *rh_cell_any<double>(a, dst_plane, i) = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+__global__ __launch_bounds__(RH_BLOCK) void k_route_gather(Arena a, int nx, int ny, int src_plane, int dst_plane, RouteHalo H) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    *rh_cell_any<double>(a, dst_plane, i) = route_gather_value(a, nx, ny, src_plane, i, H);
+}
+// Device-driven routed stepping: the second and third pass with the gather in front of them folded in -- a column reads its eight
+// neighbours' q_out (own columns from the arena, the x-neighbour ranks' edge columns from the halo buffers) instead of a q_in plane
+// that a kernel of its own wrote: 4 launches per step instead of 6 (k_ctrl, k_routed_a2, k_routed_bg, k_routed_cg[_after]).
+template <int P, int WHICH, typename T>
+RH_DEV void ld_or_gather(const Arena &a, int64_t i, T &dst, int nx, int ny, const RouteHalo &H) {
+    if constexpr (P == (WHICH == 0 ? (int)RH_P_q_sur_in : (int)RH_P_q_sub_in))
+        dst = route_gather_value(a, nx, ny, WHICH == 0 ? (int)RH_P_q_sur_out : (int)RH_P_q_sub_out, i, H);
+    else
+        rh_ld(a, P, i, dst);
+}
+#define RH_PSTAGE_G(which, seq, rt, call) RH_SEQ_##seq##_LOAD_##rt(LDG##which) call; RH_SEQ_##seq##_STORE_##rt(ST)
+#define LDG0(name) ld_or_gather<RH_P_##name, 0>(a, i, c.name, nx, ny, H);
+#define LDG1(name) ld_or_gather<RH_P_##name, 1>(a, i, c.name, nx, ny, H);
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_bg(Arena a, DevState *D, int nx, int ny, RouteHalo H) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const Consts K = D->K;
+    const StepCtx X = D->X;
+    Col c;
+    RH_PSTAGE_G(0, routed_b, rt_route_surface_in, rt_route_surface_in(c))
+    RH_PSTAGE_G(0, routed_b, rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X))
+    RH_PSTAGE_G(0, routed_b, rt_route_subsurface_out, rt_route_subsurface_out(c))
+}
+template <bool AFTER>
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_cg(Arena a, DevState *D, int nx, int ny, RouteHalo H) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const Consts K = D->K;
+    const StepCtx X = D->X;
+    Col c;
+    bool bad = false;
+    if constexpr (AFTER) {
+        RH_PSTAGE_G(1, routed_c_after, rt_route_subsurface_in, rt_route_subsurface_in(c))
+        RH_PSTAGE_G(1, routed_c_after, rt_capillary_rise, rt_capillary_rise(c, X))
+        RH_PSTAGE_G(1, routed_c_after, rt_storage, rt_storage(c, X))
+        RH_PSTAGE_G(1, routed_c_after, rt_num_error_routed, bad = rt_num_error_routed(c, K))
+        RH_PSTAGE_G(1, routed_c_after, rt_after_timestep_oned, rt_after_timestep_oned(c))
+    } else {
+        RH_PSTAGE_G(1, routed_c, rt_route_subsurface_in, rt_route_subsurface_in(c))
+        RH_PSTAGE_G(1, routed_c, rt_capillary_rise, rt_capillary_rise(c, X))
+        RH_PSTAGE_G(1, routed_c, rt_storage, rt_storage(c, X))
+        RH_PSTAGE_G(1, routed_c, rt_num_error_routed, bad = rt_num_error_routed(c, K))
+    }
+    if (bad) atomicOr(&D->words[2], 1ull);
 }
 // the rank's own edge columns (x = 0 and x = nx - 1) of a plane into two contiguous rows of ny (what the neighbours' halos take)
 template <typename T>
@@ -2406,9 +2454,7 @@ int rh_route_set_halo(rh_ctx *ctx, int side, const double *q, const int32_t *flo
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RH_OK;
 }
-static int rh_route_gather_only(rh_ctx *ctx, int which) {
-    int rc = route_check(ctx, which, "rh_route_in");
-    if (rc) return rc;
+static RouteHalo route_halo_of(rh_ctx *ctx) {
     const size_t ny = (size_t)ctx->cfg.ny;
     RouteHalo H;
     for (int side = 0; side < 2; ++side) {
@@ -2417,6 +2463,12 @@ static int rh_route_gather_only(rh_ctx *ctx, int which) {
         H.flow_dir[side] = have ? ctx->route_i + (4 + side) * ny : nullptr;
         H.mask[side] = have ? ctx->route_i + (6 + side) * ny : nullptr;
     }
+    return H;
+}
+static int rh_route_gather_only(rh_ctx *ctx, int which) {
+    int rc = route_check(ctx, which, "rh_route_in");
+    if (rc) return rc;
+    const RouteHalo H = route_halo_of(ctx);
     planes_touched(ctx);
     hipLaunchKernelGGL(k_route_gather, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, (int)ctx->cfg.nx, (int)ctx->cfg.ny,
                        which == 0 ? (int)RH_P_q_sur_out : (int)RH_P_q_sub_out, which == 0 ? (int)RH_P_q_sur_in : (int)RH_P_q_sub_in, H);
@@ -2892,19 +2944,29 @@ static int routed_step_device(rh_ctx *ctx) {
         hipExtLaunchKernelGGL(k_routed_a2, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
         if (ctx->timing) ctx->ev_used += 2;
     }
+    static const bool separate_gathers = std::getenv("RH_ROUTED_SEPARATE_GATHERS") != nullptr;   // A/B, tests: the 6-launch step
+    const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
+    const int nx = (int)ctx->cfg.nx, ny = (int)ctx->cfg.ny;
+    if ((rc = route_check(ctx, 0, "routed step"))) return rc;
     if (ranks && (rc = route_exchange(ctx, 0))) return rc;
-    if ((rc = rh_route_gather_only(ctx, 0))) return rc;
-    LAUNCH_CELLS(ctx, k_routed_b);
+    if (separate_gathers) {
+        if ((rc = rh_route_gather_only(ctx, 0))) return rc;
+        LAUNCH_CELLS(ctx, k_routed_b);
+    } else
+        hipLaunchKernelGGL(k_routed_bg, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
     if (ranks && (rc = route_exchange(ctx, 1))) return rc;
-    if ((rc = rh_route_gather_only(ctx, 1))) return rc;
+    if (separate_gathers && (rc = rh_route_gather_only(ctx, 1))) return rc;
     // (the control kernel has advanced itt / time and rotated the scalars, scalars_update; the sanity word stays in words[2], where
     // rh_get_scalars reads it)
     if (ctx->diag_n) {   // the accumulators read the planes between the numerics and the rotation
-        LAUNCH_CELLS(ctx, k_routed_c);
+        if (separate_gathers) LAUNCH_CELLS(ctx, k_routed_c);
+        else hipLaunchKernelGGL(k_routed_cg<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
         hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
         LAUNCH_CELLS(ctx, k_after_timestep_oned);
-    } else
+    } else if (separate_gathers)
         LAUNCH_CELLS(ctx, k_routed_c_after);
+    else
+        hipLaunchKernelGGL(k_routed_cg<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
     CHECK_LAUNCH(ctx);
     ctx->routed_summary = true;   // k_routed_a2 left the summary bits of the state the step ends in
     return RH_OK;

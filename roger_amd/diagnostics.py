@@ -15,9 +15,9 @@ with `time_origin`, record 0 holding the initial values, one record per output i
 runs on the device (`rate += var` after every step is a 24-byte-per-cell kernel, nothing is downloaded between outputs);
 one output interval -- a day, an hour or ten minutes -- serves all diagnostics (the accumulators are indexed by the
 interval of a step's start); the offline transport model,
-whose step is a day, is read after every step instead (`output_transport`); the file is classic netCDF
-(64-bit offset, scipy.io.netcdf_file) because neither h5py nor h5netcdf is part of this environment -- xarray / netCDF4
-read it all the same; long names and units come from a short table here, not from the reference's variable registry.
+whose step is a day, is read after every step instead (`output_transport`); the files are netCDF-4 like the reference's
+(dimension scales, unlimited Time, one chunk per record), written by `roger_amd.nc4lite` because neither h5py nor h5netcdf is part
+of this environment; long names and units come from a short table here, not from the reference's variable registry.
 """
 import datetime
 import os
@@ -240,42 +240,37 @@ def output(state, final=False):
 
 
 def _write(state, d):
-    """The whole file from the records held in memory (classic netCDF has no cheap append through scipy)."""
+    """The whole file from the records held in memory, as netCDF-4 in the reference's layout (roger/io_tools/netcdf.py:22-72, 121-165):
+    dimensions x, y and the unlimited Time as dimension scales, variables (Time, y, x) chunked by record with `_FillValue`, the global
+    attributes of `initialize_file`.  Written by roger_amd.nc4lite (h5netcdf is not part of this image)."""
     if not d._path:
         return
-    from scipy.io import netcdf_file
+    from . import nc4lite
 
     vs, settings = state.variables, state.settings
     os.makedirs(os.path.dirname(os.path.abspath(d._path)), exist_ok=True)
-    with netcdf_file(d._path, "w", version=2) as f:
-        f.date_created = datetime.datetime.today().isoformat()
-        f.roger_version = "roger_amd (hip backend)"
-        f.comment = ("First timestep (t=0) contains initial values. Simulations start are written from second timestep "
-                     "(t=1) to last timestep (t=N).")
-        f.setup_identifier = settings.identifier
-        x, y = np.asarray(vs.x)[2:-2], np.asarray(vs.y)[2:-2]
-        f.createDimension("Time", None)   # (scipy: the unlimited dimension is created first)
-        f.createDimension("x", len(x))
-        f.createDimension("y", len(y))
-        for name, data in (("x", x), ("y", y)):
-            v = f.createVariable(name, "d", (name,))
-            v[:] = data
-            v.long_name, v.units = name, "m"
-        t = f.createVariable("Time", "d", ("Time",))
-        t.long_name, t.units, t.time_origin = "Time", "days", str(settings.time_origin)
-        t[:] = np.asarray(d._times)
-        for name in d.output_variables:
-            rec = d._records[name]
-            extra = ()
-            if rec and rec[0].ndim == 3:   # (ages | nages, y, x)
-                dim = "ages" if rec[0].shape[0] == settings.ages else "nages"
-                if dim not in f.dimensions:
-                    f.createDimension(dim, rec[0].shape[0])
-                extra = (dim,)
-            v = f.createVariable(name, "d", ("Time",) + extra + ("y", "x"))
-            v.long_name, v.units = name, _UNITS.get(name, "")
-            if rec:
-                v[:] = np.stack(rec)
+    x, y = np.asarray(vs.x)[2:-2], np.asarray(vs.y)[2:-2]
+    dims = {"x": len(x), "y": len(y), "Time": None}
+    variables = {
+        "x": (("x",), x, {"long_name": "x", "units": "m"}),
+        "y": (("y",), y, {"long_name": "y", "units": "m"}),
+        "Time": (("Time",), np.asarray(d._times, dtype=np.float64), {"long_name": "Time", "units": "days", "time_origin": str(settings.time_origin)}),
+    }
+    for name in d.output_variables:
+        rec = d._records[name]
+        extra = ()
+        if rec and rec[0].ndim == 3:   # (ages | nages, y, x)
+            dim = "ages" if rec[0].shape[0] == settings.ages else "nages"
+            dims.setdefault(dim, rec[0].shape[0])
+            extra = (dim,)
+        data = np.stack(rec) if rec else np.zeros((0,) + tuple(dims[k] for k in extra) + (len(y), len(x)))
+        variables[name] = (("Time",) + extra + ("y", "x"), np.asarray(data, dtype=np.float64),
+                           {"_FillValue": np.float64(-9999.0), "long_name": name, "units": _UNITS.get(name, "")})
+    nc4lite.write(d._path, dims, variables, {
+        "date_created": datetime.datetime.today().isoformat(), "roger_version": "roger_amd (hip backend)",
+        "comment": ("First timestep (t=0) contains initial values. Simulations start are written from second timestep "
+                    "(t=1) to last timestep (t=N)."),
+        "setup_identifier": str(settings.identifier)})
 
 
 def close(state):

@@ -152,7 +152,7 @@ def test_tutorial_example_from_text_inputs(tmp_path):
 
     from golden_util import GOLDEN_DIR
     from roger_amd import runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     spec = importlib.util.spec_from_file_location("svat_tutorial_example", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "svat_tutorial.py"))
     ex = importlib.util.module_from_spec(spec)
@@ -182,7 +182,7 @@ def test_output_diagnostics_hourly_on_device(tmp_path):
     the host (one per hour while stepping hourly or finer, one per daily step)."""
     import svat_scripts as S
     from roger_amd import diagnostics, roger_routine, runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     g, names, forcing = load_case("svat_hetero_combo")
 
@@ -262,7 +262,7 @@ def test_routing_example_from_text_inputs(tmp_path):
     import svat_scripts as S
     from golden_util import GOLDEN_DIR
     from roger_amd import runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     spec = importlib.util.spec_from_file_location("oned_routing_example", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "oned_routing_tutorial.py"))
     ex = importlib.util.module_from_spec(spec)

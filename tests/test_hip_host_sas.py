@@ -113,7 +113,7 @@ def test_svat_to_transport_example(tmp_path):
 
     from golden_util import GOLDEN_DIR
     from roger_amd import runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     path = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "examples", "svat_oxygen18_tutorial.py")
     spec = importlib.util.spec_from_file_location("svat_oxygen18_example", path)

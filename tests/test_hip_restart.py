@@ -62,7 +62,7 @@ def test_restart_round_trip_on_the_device(tmp_path, monkeypatch):
         base = nm[:-3] if nm.endswith("_m1") else nm
         np.testing.assert_array_equal(np.asarray(getattr(va, base)), np.asarray(getattr(vc, base)), err_msg=base)
     # the daily sums of the day the restart fell into come out the same (partial sums were carried over)
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     for kind, var in (("rate", "aet"), ("rate", "prec"), ("collect", "S_rz")):
         with netcdf_file(str(tmp_path / "a" / f"GoldenSVAT.{kind}.nc"), "r", mmap=False) as fa, \

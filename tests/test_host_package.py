@@ -292,7 +292,7 @@ def _diagnostics_model(case, ndays, tmp_path, device_hooks=False):
 
 
 def check_diagnostics_files(model, tmp_path, ndays, nx, ny, reference_sums=None):
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     ident = model.state.settings.identifier
     with netcdf_file(str(tmp_path / f"{ident}.rate.nc"), "r", mmap=False) as f:
@@ -392,7 +392,7 @@ def test_output_diagnostics_hourly(oracle_backend, tmp_path):
     file's sums and carry the reference's time stamps."""
     import svat_scripts as S
     from roger_amd import diagnostics, roger_routine, runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     g, names, forcing = load_case("svat_hetero_combo")
     base = S.make_model(S.params_from_golden(g, names), forcing, 4)
@@ -526,7 +526,7 @@ def test_run_with_stock_hooks_stays_on_the_device(oracle_backend, case, tmp_path
     assert a[4][0] == ndays and len(a[4]) <= 8 and sum(a[4]) >= a[0]          # a few generous rounds (the device stops at the end of the run)
     assert b[5] == list(range(a[0]))                                          # the script's own hook ran before every step
     np.testing.assert_array_equal(a[2], b[2])
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     for kind, keys in (("rate", ("prec", "aet", "q_ss")), ("collect", ("S_rz", "theta"))):
         ident = m.state.settings.identifier

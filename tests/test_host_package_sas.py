@@ -193,7 +193,7 @@ def test_transport_output_diagnostics(oracle_sas, tmp_path):
     """state.diagnostics of the offline transport model: nothing during the warm-up, record 0 = the rescaled initial state,
     then a record per day with the step's values -- concentrations, age statistics and an age-resolved distribution."""
     from roger_amd import roger_routine, runtime_settings as rs
-    from scipy.io import netcdf_file
+    from nc_util import netcdf_file
 
     g = sb.SasGolden("sas_warmup_a30")
     svat, sas = golden_inputs(g)
