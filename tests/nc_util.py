@@ -1,8 +1,6 @@
 """Reading the output files of roger_amd.diagnostics in tests: netCDF-4 through roger_amd.nc4lite (h5py / netCDF4 are not part of the
 image), with the small part of scipy.io.netcdf_file's interface the tests use (`f.dimensions`, `f.variables[name][:]`, `.shape`,
 `.dimensions`, `.units` ... as bytes like scipy returns them)."""
-import contextlib
-
 from roger_amd import h5lite, nc4lite
 
 
@@ -28,7 +26,16 @@ class _File:
             setattr(self, k, v.encode() if isinstance(v, str) else v)
 
 
-@contextlib.contextmanager
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def netcdf_file(path, mode="r", mmap=False):
     assert mode == "r"
-    yield _File(path)
+    return _File(path)
