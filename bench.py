@@ -303,7 +303,7 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
     by_routine = bool(os.environ.get("RH_ROUTED_BY_ROUTINE"))   # A/B: the routine-by-routine control part (17 launches per step)
     first = "routed_a" if by_routine else "routed_a2"
     run, stepping = ctx.run_steps, ("rh_run_steps (routed, rh_step_routed per step: 17 launches)" if by_routine else
-                                    "rh_run_steps (routed: control kernel on the posted summary bits, three passes, two gathers: 6 launches per step)")
+                                    "rh_run_steps (routed: control kernel on the posted summary bits, three passes with the gathers folded in: 4 launches per step)")
     if world > 1:
         ctx.comm_init_torch()
         run, stepping = ctx.run_steps_dist, "rh_run_steps_dist (routed; summary word and edge columns over RCCL from C)"
@@ -323,6 +323,8 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.timing_summary()
+    per_ms, _ = ctx.timing_detail() if not by_routine else (None, None)
+    sparse_steps = ctx.sparse_steps()
     ctx.enable_timing(False)
     s1 = ctx.get_scalars()
     if world > 1:
@@ -333,9 +335,16 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
         raise SystemExit(f"bench: step bookkeeping failed (itt {s0.itt}->{s1.itt})")
     if rank == 0:
         census = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))   # bytes per column from the ISA (tools/isa_census.py)
-        passes = {seq: (census[seq]["load_bytes"], census[seq]["store_bytes"]) for seq in (first, "routed_b", "routed_c_after")}
+        # device-driven: the gathers are folded into the second and third pass (k_routed_bg / k_routed_cg), and every step of the call
+        # but the last leaves out the stores of the planes the routed step only produces (sparse stores)
+        sparse = (not by_routine) and sparse_steps == launches - 1 and per_ms is not None and len(per_ms) == launches
+        sfx = "_sparse" if sparse else ""
+        names = (first, "routed_b", "routed_c_after") if by_routine or os.environ.get("RH_ROUTED_SEPARATE_GATHERS") else \
+            (first + sfx, "routed_bg" + sfx, "routed_cg_after" + sfx)
+        passes = {seq: (census[seq]["load_bytes"], census[seq]["store_bytes"]) for seq in names}
+        first = names[0]
         ld_b, st_b = passes[first]
-        k_avg_s = kernel_ms / 1e3 / max(launches, 1)
+        k_avg_s = (float(per_ms[:-1].mean()) / 1e3) if sparse else kernel_ms / 1e3 / max(launches, 1)
         achieved = (ld_b + st_b) * n_local / k_avg_s / 1e9
         step_bytes = sum(sum(v) for v in passes.values())
         traffic, _ = measured_traffic("k_" + first, n_local)
@@ -359,14 +368,15 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, " + ("one summary all-reduce and two edge-column exchanges per step" if world > 1
                                                               else "single GPU: no exchange"),
-                "stepping": stepping,
+                "stepping": stepping + (f"; {sparse_steps} of {launches} steps with sparse stores" if sparse_steps else ""),
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": f"k_{first} (" + ("" if by_routine else "forcing selection, ") + "interception ... infiltration + the surface outflow: the longest of the step's three passes)",
                 "note": f"achieved = the bytes this pass loads + stores per column ({ld_b} + {st_b} B, roger_amd/csrc/rh_step_bytes.json from "
                         "the ISA) / its average duration by HIP events; the whole routed step moves "
-                        f"{step_bytes} B per column in its three passes (fused oneD step: 2040 B), plus the gathers and the adaptive time stepping",
+                        f"{step_bytes} B per column in its three passes, the folded gathers' neighbour reads (cache hits mostly) included "
+                        "(fused oneD step: 1240 B sparse / 2040 B), plus the adaptive time stepping",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -265,9 +265,10 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps);
  * them, derived from rh_physics.h by the flow analysis of tools/liveness.py (72 of the SVAT step's 124 stored planes).  The last step
  * of a call stores everything: after the call every plane holds what n full steps leave.  Off when an accumulator
  * (rh_diag_configure) was given such a plane, and with RH_NO_SPARSE_STORES=1.
- *   rh_plane_is_pure_output  1 if the fused step of the SVAT (lateral = 0) / oneD (lateral = 1) model only produces the plane
+ *   rh_plane_is_pure_output  1 if the step of the model only produces the plane: model 0 = SVAT, 1 = oneD (fused steps), 2 = the routed
+ *                            step (settings.enable_routing_1D: there a pass also keeps what a later pass of the same step loads)
  *   rh_sparse_steps          steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores */
-int rh_plane_is_pure_output(int lateral, int plane);
+int rh_plane_is_pure_output(int model, int plane);
 /* "Run until": the reference's driver loop is `while vs.time - start_time < runlen: step()` (roger/roger.py:548-556), and the length
  * of a step is decided on the device.  With a limit set, the control part of a step (on the device) finds the run over once the model
  * time has reached t_end: that launch and every later one do nothing (the accumulators included), so a caller may enqueue more steps

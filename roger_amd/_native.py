@@ -441,6 +441,7 @@ class Context:
         self.index = {nm: i for i, (nm, _) in enumerate(self.planes)}
         self.planes_held = int(lib.rh_planes_held(h))   # (the routing's planes exist in routing contexts only)
         self.lateral = bool(cfg.enable_lateral_flow)
+        self.routing = bool(cfg.enable_routing_1D)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -632,8 +633,8 @@ class Context:
     def pure_output_planes(self):
         """Names of the planes the fused step of this context's model only produces (not stored by the steps of an rh_run_steps call
         that another step follows)."""
-        lat = int(self.lateral)
-        return [nm for nm, p in self.index.items() if self._lib.rh_plane_is_pure_output(lat, p) == 1]
+        model = 2 if self.routing else int(self.lateral)
+        return [nm for nm, p in self.index.items() if self._lib.rh_plane_is_pure_output(model, p) == 1]
 
     def set_time_limit(self, t_end):
         """No step begins at or beyond model time t_end (None / negative: no limit): rh_run_steps(n) then runs at most n steps."""

@@ -1379,6 +1379,12 @@ RH_CELL_KERNEL(k_num_error_routed, rt_num_error_routed, if (rt_num_error_routed(
 // ... staged like the fused step (tools/gen_sets.py PLAIN_SEQUENCES): every plane is loaded right before the first stage that mentions it
 // and stored right after the last one that assigns it (short live ranges instead of all loads up front)
 #define RH_PSTAGE(seq, rt, call) RH_SEQ_##seq##_LOAD_##rt(LD) call; RH_SEQ_##seq##_STORE_##rt(ST)
+// ... in a kernel with a template parameter SPARSE (the device-driven routed step inside rh_run_steps: every step of a call but the last
+// leaves out the stores of the planes the routed step only produces and no later pass of the step loads, RH_SEQ_*_SSTORE_*, tools/gen_sets.py)
+#define RH_PSTAGE_S(seq, rt, call)                            \
+    RH_SEQ_##seq##_LOAD_##rt(LD) call;                        \
+    if constexpr (SPARSE) { RH_SEQ_##seq##_SSTORE_##rt(ST) }  \
+    else { RH_SEQ_##seq##_STORE_##rt(ST) }
 #define RH_PASS_KERNEL(kname, body)                                                                        \
     __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void kname(Arena a, DevState *D) {               \
         const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;                                    \
@@ -1443,17 +1449,18 @@ RH_PASS_KERNEL(k_core_staged_lateral,
 // the monthly surface parameters, D->monthly] in front, as the fused kernel has them, and the columns' summary bits for the NEXT step's
 // control kernel posted as soon as they are final (k_ctrl reads them from sumw: no predicate passes over the arena between two steps).
 #define RH_ROUTED_A2_TAIL(seq)                                                                                  \
-    RH_PSTAGE(seq, rt_interception, rt_interception(c, K))                                                      \
-    RH_PSTAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                          \
-    RH_PSTAGE(seq, rt_snow, rt_snow(c, K, X))                                                                   \
+    RH_PSTAGE_S(seq, rt_interception, rt_interception(c, K))                                                      \
+    RH_PSTAGE_S(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                          \
+    RH_PSTAGE_S(seq, rt_snow, rt_snow(c, K, X))                                                                   \
     q = summary_bits_sw(q, c.swe, c.swe_top);                                                                   \
     post_summary(D, q, dep);                                                                                    \
-    RH_PSTAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                       \
-    RH_PSTAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                       \
-    RH_PSTAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                               \
-    RH_PSTAGE(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                                       \
-    RH_PSTAGE(seq, rt_inf_finish_routed, rt_inf_finish_routed(c, K, X))                                         \
-    RH_PSTAGE(seq, rt_route_surface_out, rt_route_surface_out(c, K, X, (double)D->S.dt_secs))
+    RH_PSTAGE_S(seq, rt_inf_events, rt_inf_events(c, K, X))                                                       \
+    RH_PSTAGE_S(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                       \
+    RH_PSTAGE_S(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                               \
+    RH_PSTAGE_S(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                                       \
+    RH_PSTAGE_S(seq, rt_inf_finish_routed, rt_inf_finish_routed(c, K, X))                                         \
+    RH_PSTAGE_S(seq, rt_route_surface_out, rt_route_surface_out(c, K, X, (double)D->S.dt_secs))
+template <bool SPARSE>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_a2(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     if (i >= a.n) return;
@@ -1472,14 +1479,14 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_a2(Arena a, 
 #else
     if (D->monthly != 0) {
 #endif
-        RH_PSTAGE(routed_a2_monthly, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
-        RH_PSTAGE(routed_a2_monthly, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
+        RH_PSTAGE_S(routed_a2_monthly, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
+        RH_PSTAGE_S(routed_a2_monthly, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
         q = summary_bits_pt(c.prec, c.ta, K);
-        RH_PSTAGE(routed_a2_monthly, rt_params_surface, rt_params_surface(c, D->L, X))
+        RH_PSTAGE_S(routed_a2_monthly, rt_params_surface, rt_params_surface(c, D->L, X))
         RH_ROUTED_A2_TAIL(routed_a2_monthly)
     } else {
-        RH_PSTAGE(routed_a2, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
-        RH_PSTAGE(routed_a2, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
+        RH_PSTAGE_S(routed_a2, rt_select_prec, rt_select_prec(c, X, X.prec_sel, X.ta_sel))
+        RH_PSTAGE_S(routed_a2, rt_select_pet, rt_select_pet(c, X, pet_v, ta_v))
         q = summary_bits_pt(c.prec, c.ta, K);
         RH_ROUTED_A2_TAIL(routed_a2)
     }
@@ -1550,9 +1557,13 @@ RH_DEV void ld_or_gather(const Arena &a, int64_t i, T &dst, int nx, int ny, cons
     else
         rh_ld(a, P, i, dst);
 }
-#define RH_PSTAGE_G(which, seq, rt, call) RH_SEQ_##seq##_LOAD_##rt(LDG##which) call; RH_SEQ_##seq##_STORE_##rt(ST)
+#define RH_PSTAGE_G(which, seq, rt, call)                     \
+    RH_SEQ_##seq##_LOAD_##rt(LDG##which) call;                \
+    if constexpr (SPARSE) { RH_SEQ_##seq##_SSTORE_##rt(ST) }  \
+    else { RH_SEQ_##seq##_STORE_##rt(ST) }
 #define LDG0(name) ld_or_gather<RH_P_##name, 0>(a, i, c.name, nx, ny, H);
 #define LDG1(name) ld_or_gather<RH_P_##name, 1>(a, i, c.name, nx, ny, H);
+template <bool SPARSE>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_bg(Arena a, DevState *D, int nx, int ny, RouteHalo H) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     if (i >= a.n) return;
@@ -1563,7 +1574,7 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_bg(Arena a, 
     RH_PSTAGE_G(0, routed_b, rt_subsurface_runoff_lateral, rt_subsurface_runoff_lateral(c, K, X))
     RH_PSTAGE_G(0, routed_b, rt_route_subsurface_out, rt_route_subsurface_out(c))
 }
-template <bool AFTER>
+template <bool AFTER, bool SPARSE>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_cg(Arena a, DevState *D, int nx, int ny, RouteHalo H) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     if (i >= a.n) return;
@@ -1577,11 +1588,13 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_routed_cg(Arena a, 
         RH_PSTAGE_G(1, routed_c_after, rt_storage, rt_storage(c, X))
         RH_PSTAGE_G(1, routed_c_after, rt_num_error_routed, bad = rt_num_error_routed(c, K))
         RH_PSTAGE_G(1, routed_c_after, rt_after_timestep_oned, rt_after_timestep_oned(c))
-    } else {
-        RH_PSTAGE_G(1, routed_c, rt_route_subsurface_in, rt_route_subsurface_in(c))
-        RH_PSTAGE_G(1, routed_c, rt_capillary_rise, rt_capillary_rise(c, X))
-        RH_PSTAGE_G(1, routed_c, rt_storage, rt_storage(c, X))
-        RH_PSTAGE_G(1, routed_c, rt_num_error_routed, bad = rt_num_error_routed(c, K))
+    } else {   // (with the output accumulators between the numerics and the rotation: never sparse)
+#define RH_PSTAGE_GF(seq, rt, call) RH_SEQ_##seq##_LOAD_##rt(LDG1) call; RH_SEQ_##seq##_STORE_##rt(ST)
+        RH_PSTAGE_GF(routed_c, rt_route_subsurface_in, rt_route_subsurface_in(c))
+        RH_PSTAGE_GF(routed_c, rt_capillary_rise, rt_capillary_rise(c, X))
+        RH_PSTAGE_GF(routed_c, rt_storage, rt_storage(c, X))
+        RH_PSTAGE_GF(routed_c, rt_num_error_routed, bad = rt_num_error_routed(c, K))
+#undef RH_PSTAGE_GF
     }
     if (bad) atomicOr(&D->words[2], 1ull);
 }
@@ -1739,13 +1752,15 @@ static const unsigned char PLANE_IS_INT[] = {
 };
 
 // planes the fused step only produces (tools/liveness.py -> RH_SPARSE_FIELDS_* in rh_sets.inc), per model: [0] SVAT, [1] oneD
-static const std::vector<unsigned char> *pure_output_planes() {
-    static const std::vector<unsigned char> tab[2] = {
+static const std::vector<unsigned char> *pure_output_planes() {   // [0] SVAT, [1] oneD (fused steps), [2] the routed step
+    static const std::vector<unsigned char> tab[3] = {
         [] { std::vector<unsigned char> t(RH_NPLANES, 0);
 #define RH_MARK(name) t[RH_P_##name] = 1;
              RH_SPARSE_FIELDS_SVAT(RH_MARK) return t; }(),
         [] { std::vector<unsigned char> t(RH_NPLANES, 0);
-             RH_SPARSE_FIELDS_ONED(RH_MARK)
+             RH_SPARSE_FIELDS_ONED(RH_MARK) return t; }(),
+        [] { std::vector<unsigned char> t(RH_NPLANES, 0);
+             RH_SPARSE_FIELDS_ROUTED(RH_MARK)
 #undef RH_MARK
              return t; }()};
     return tab;
@@ -2181,7 +2196,7 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
     int rc = plane_bytes(ctx, plane, bytes, &elem);
     if (rc) return rc;
     if (!host) return fail(ctx, RH_ERR_ARG, "rh_download: null host pointer");
-    if (ctx->outputs_stale && pure_output_planes()[ctx->cfg.enable_lateral_flow ? 1 : 0][plane])   // only after an rh_run_steps call that failed half-way
+    if (ctx->outputs_stale && pure_output_planes()[ctx->cfg.enable_routing_1D ? 2 : (ctx->cfg.enable_lateral_flow ? 1 : 0)][plane])   // only after an rh_run_steps call that failed half-way
         return fail(ctx, RH_ERR_STATE, "rh_download: the last rh_run_steps call ended before its final step; this flux / diagnostic plane holds an "
                                        "earlier step's values (run one more step)");
     materialise_m1(ctx);
@@ -2917,8 +2932,10 @@ static int routed_core(rh_ctx *ctx, bool with_after) {
 }
 // One routed step of rh_run_steps / rh_run_steps_dist (forcing shared by all columns): control kernel on the summary word (all-reduced
 // between the ranks), three passes around the two gathers -- 6 launches instead of 17.
-static int routed_step_device(rh_ctx *ctx) {
+static int routed_step_device(rh_ctx *ctx, bool sparse_wanted = false) {
     int rc;
+    // sparse stores: another step of the same rh_run_steps call follows and no accumulator reads the planes in between
+    const bool sparse = sparse_wanted && ctx->sparse_ok && !ctx->diag_n && std::getenv("RH_ROUTED_SEPARATE_GATHERS") == nullptr;
     RcclApi *api = nullptr;
     const bool ranks = ctx->comm && ctx->comm_nranks > 1;
     if (ctx->comm) {
@@ -2941,7 +2958,8 @@ static int routed_step_device(rh_ctx *ctx) {
     {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (ctx->timing && (rc = timing_pair(ctx, &ev0, &ev1))) return rc;
-        hipExtLaunchKernelGGL(k_routed_a2, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
+        if (sparse) hipExtLaunchKernelGGL(k_routed_a2<true>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
+        else hipExtLaunchKernelGGL(k_routed_a2<false>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev);
         if (ctx->timing) ctx->ev_used += 2;
     }
     static const bool separate_gathers = std::getenv("RH_ROUTED_SEPARATE_GATHERS") != nullptr;   // A/B, tests: the 6-launch step
@@ -2952,23 +2970,29 @@ static int routed_step_device(rh_ctx *ctx) {
     if (separate_gathers) {
         if ((rc = rh_route_gather_only(ctx, 0))) return rc;
         LAUNCH_CELLS(ctx, k_routed_b);
-    } else
-        hipLaunchKernelGGL(k_routed_bg, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
+    } else if (sparse)
+        hipLaunchKernelGGL(k_routed_bg<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
+    else
+        hipLaunchKernelGGL(k_routed_bg<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
     if (ranks && (rc = route_exchange(ctx, 1))) return rc;
     if (separate_gathers && (rc = rh_route_gather_only(ctx, 1))) return rc;
     // (the control kernel has advanced itt / time and rotated the scalars, scalars_update; the sanity word stays in words[2], where
     // rh_get_scalars reads it)
     if (ctx->diag_n) {   // the accumulators read the planes between the numerics and the rotation
         if (separate_gathers) LAUNCH_CELLS(ctx, k_routed_c);
-        else hipLaunchKernelGGL(k_routed_cg<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
+        else hipLaunchKernelGGL((k_routed_cg<false, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
         hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
         LAUNCH_CELLS(ctx, k_after_timestep_oned);
     } else if (separate_gathers)
         LAUNCH_CELLS(ctx, k_routed_c_after);
+    else if (sparse)
+        hipLaunchKernelGGL((k_routed_cg<true, true>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
     else
-        hipLaunchKernelGGL(k_routed_cg<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
+        hipLaunchKernelGGL((k_routed_cg<true, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
     CHECK_LAUNCH(ctx);
     ctx->routed_summary = true;   // k_routed_a2 left the summary bits of the state the step ends in
+    ctx->outputs_stale = ctx->last_sparse = sparse;
+    ctx->call_sparse_steps += sparse ? 1 : 0;
     return RH_OK;
 }
 int rh_step_routed(rh_ctx *ctx, int monthly) {
@@ -3056,7 +3080,7 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
         int rc;
         if (ctx->cfg.enable_routing_1D) {
             if (!ctx->per_cell && ctx->routed_device_ok)
-                rc = routed_step_device(ctx);
+                rc = routed_step_device(ctx, k + 1 < nsteps);
             else {   // the hooks, then the step routine by routine (rh_step_routed)
                 launch_hooks(ctx);
                 rc = rh_step_routed(ctx, -1);
@@ -3128,7 +3152,7 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
         for (int64_t k = 0; k < nsteps; ++k) {
             int rc;
             if (!ctx->per_cell && ctx->routed_device_ok)
-                rc = routed_step_device(ctx);
+                rc = routed_step_device(ctx, k + 1 < nsteps);
             else {
                 launch_hooks(ctx);
                 rc = rh_step_routed(ctx, -1);
@@ -3339,8 +3363,8 @@ int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
     return n;
 }
 
-int rh_plane_is_pure_output(int lateral, int plane) {
-    return (plane >= 0 && plane < RH_NPLANES) ? pure_output_planes()[lateral ? 1 : 0][plane] : -1;
+int rh_plane_is_pure_output(int model, int plane) {
+    return (plane >= 0 && plane < RH_NPLANES && model >= 0 && model <= 2) ? pure_output_planes()[model][plane] : -1;
 }
 int64_t rh_sparse_steps(const rh_ctx *ctx) { return ctx ? ctx->call_sparse_steps : 0; }
 int rh_step_mode(const rh_ctx *ctx) {

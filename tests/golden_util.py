@@ -119,6 +119,44 @@ def deviating_columns(got, ref, rtol=RTOL, atol=ATOL):
 # the device the same three (first at step 2); one more is allowed.
 ONED_TIE_COLUMNS = {"oned_hetero_combo": 3}
 
+# Round 3: WHICH columns may part is decided by the data, not by a count.  A column is "tie-exposed" from the first
+# stored step at which one of its water stores holds a rounding residue -- a value that is not zero but smaller than 1e-9 mm in
+# magnitude (a store is either empty or holds physically meaningful water; -4.4e-16 or 1.1e-18 is what `x - x * (y / y)` leaves) -- in the
+# reference's state or in the implementation's.  From then on its trajectory depends on the last bit of every `pow` (the next `> 0` or
+# `< theta_ac` test sees the residue's sign).  Every column that is NOT exposed must meet the tolerance at every stored step of the
+# whole trajectory; measured on oned_hetero_combo: columns 13 (step 2), 3 (step 17 / 20), 2 (step 48 / 49) -- exactly the three that part.
+TIE_STATE_PLANES = ("S_fp_rz", "S_lp_rz", "S_fp_ss", "S_lp_ss", "z_sat", "S_zsat", "z0", "S_dep", "S_int_top", "S_int_ground", "swe", "S_snow",
+                    "swe_top", "swe_ground") + tuple(f"z_sat_layer_{k}" for k in range(1, 9))
+
+
+def residue_columns(snap, names, eps=1e-9):
+    """Columns in which a water store holds a rounding residue (0 < |x| < eps)."""
+    rows = [names.index(nm) for nm in TIE_STATE_PLANES if nm in names]
+    sub = np.asarray(snap, dtype=np.float64)[rows]
+    with np.errstate(all="ignore"):
+        r = (sub != 0) & (np.abs(sub) < eps)
+    return set(np.unique(np.argwhere(r)[:, 1]).tolist())
+
+
+class TieTracker:
+    """Compares trajectories column by column: tie-exposed columns (residue_columns of either side, from the step they show one) are
+    left alone, every other column must meet the tolerance."""
+
+    def __init__(self, names, n_columns, max_exposed_fraction=1 / 3):
+        self.names, self.n, self.cap = names, n_columns, max_exposed_fraction
+        self.exposed = {}     # column -> first stored step with a residue
+
+    def check(self, got, ref, step, what=""):
+        for c in sorted(residue_columns(got, self.names) | residue_columns(ref, self.names)):
+            self.exposed.setdefault(c, step)
+        bad = deviating_columns(got, ref) - set(self.exposed)
+        if bad:
+            c = sorted(bad)[0]
+            rows = [(self.names[p], float(np.asarray(got)[p, c]), float(np.asarray(ref)[p, c])) for p in range(len(self.names))
+                    if not (np.asarray(got)[p, c] == np.asarray(ref)[p, c] or abs(np.asarray(got)[p, c] - np.asarray(ref)[p, c]) <= ATOL + RTOL * abs(np.asarray(ref)[p, c]))][:6]
+            raise AssertionError(f"{what} step {step}: columns {sorted(bad)} deviate without a residue in any store; column {c}: {rows}")
+        assert len(self.exposed) <= self.cap * self.n, f"{what}: {len(self.exposed)} of {self.n} columns tie-exposed: {self.exposed}"
+
 
 def compare_bulk(got, ref, names, what="", rtol_bulk=RTOL, atol_bulk=ATOL, frac_bulk=0.999, rtol_max=1e-3, atol_max=1e-6):
     """Stress-set comparison: at least `frac_bulk` of all values within the golden tolerance and

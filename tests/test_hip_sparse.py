@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import CASES, ONED_TIE_COLUMNS, compare, deviating_columns, load_case
+from golden_util import CASES, ONED_TIE_COLUMNS, TieTracker, compare, deviating_columns, load_case
 from test_hip_parity import _ctx, native  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ def test_pure_output_planes_are_never_read(native, case):  # noqa: F811
     assert len(poison) >= 60
     nan = np.full(ctx.n, np.nan)
     drv = H.HipForcingDriver(ctx, forcing)
-    off, checked = set(), 0
+    ties, checked = (TieTracker(names, ctx.n) if case in ONED_TIE_COLUMNS else None), 0
     for step in range(1, int(g["nsteps"]) + 1):
         for nm in poison:
             ctx.upload(nm, nan)
@@ -38,9 +38,8 @@ def test_pure_output_planes_are_never_read(native, case):  # noqa: F811
         assert s.sanity_ok == 1
         key = f"s{step:05d}"
         if key in g.files:
-            if case in ONED_TIE_COLUMNS:
-                off |= deviating_columns(H.download_snapshot(ctx, names), g[key])
-                assert len(off) <= ONED_TIE_COLUMNS[case] + 1, f"{case} step {step}: columns {sorted(off)} deviate"
+            if ties:
+                ties.check(H.download_snapshot(ctx, names), g[key], step, what=case)
             else:
                 compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}, pure outputs poisoned before the step")
             checked += 1
@@ -79,14 +78,13 @@ def test_run_steps_in_pieces_leaves_every_plane_as_full_steps_do(native, case): 
     a, used = _pieces(native, g, names, forcing, stops, sparse=True)
     b, none = _pieces(native, g, names, forcing, stops, sparse=False)
     assert used > 0 and none == 0
-    off = set()
+    ties = TieTracker(names, int(np.prod(g["nx_ny"]))) if case in ONED_TIE_COLUMNS else None
     for stop, (sa, pa), (sb, pb) in zip(stops, a, b):
         np.testing.assert_array_equal(sa, sb, err_msg=f"{case} scalars after step {stop}")
         np.testing.assert_array_equal(pa, pb, err_msg=f"{case} planes after step {stop}: sparse stores changed what the caller sees")
         np.testing.assert_array_equal(sa, g["scal"][stop - 1], err_msg=f"{case} scalars step {stop}")
-        if case in ONED_TIE_COLUMNS:
-            off |= deviating_columns(pa, g[f"s{stop:05d}"])
-            assert len(off) <= ONED_TIE_COLUMNS[case] + 1
+        if ties:
+            ties.check(pa, g[f"s{stop:05d}"], stop, what=case)
         else:
             compare(pa, g[f"s{stop:05d}"], names, what=f"{case} step {stop} (rh_run_steps in pieces)")
 
@@ -103,3 +101,65 @@ def test_an_accumulated_pure_output_plane_switches_the_option_off(native):  # no
     ctx.run_steps(30)
     assert ctx.sparse_steps() == 0
     ctx.close()
+
+
+# ---- the routed step (settings.enable_routing_1D): three passes, a pass also keeps what a later pass of the same step loads --------
+@pytest.mark.parametrize("case", ["oned_routing", "oned_routing_tutorial"])
+def test_routed_pure_output_planes_are_never_read(native, case):  # noqa: F811
+    """The planes the routed step only produces (RH_SPARSE_FIELDS_ROUTED: the flow analysis over the three passes with the gathers
+    as assignments of q_*_in) poisoned with NaN before every step: the reference's routed trajectory still comes out."""
+    import hip_util as H
+    from test_hip_routing import routed_ctx
+
+    g, names, forcing = load_case(case)
+    ctx = routed_ctx(native, g, names)
+    poison = [nm for nm in ctx.pure_output_planes() if ctx.index[nm] < ctx.planes_held]
+    assert len(poison) >= 100 and "q_sur_out" not in poison and "q_sub_out" not in poison and "q_ss" in poison and "S_rz" in poison
+    nan = np.full(ctx.n, np.nan)
+    drv = H.HipForcingDriver(ctx, forcing)
+    checked = 0
+    for step in range(1, int(g["nsteps"]) + 1):
+        for nm in poison:
+            ctx.upload(nm, nan)
+        ctx.step_routed(drv.before_step())
+        np.testing.assert_array_equal(H.scalars_to_row(ctx.get_scalars()), g["scal"][step - 1], err_msg=f"{case} scalars step {step}")
+        key = f"s{step:05d}"
+        if key in g.files:
+            compare(H.download_snapshot(ctx, names), g[key], names, what=f"{case} step {step}, pure outputs poisoned before the step")
+            checked += 1
+    assert checked >= 3
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["oned_routing", "oned_routing_tutorial"])
+def test_routed_run_steps_in_pieces_leaves_every_plane_as_full_steps_do(native, case):  # noqa: F811
+    import hip_util as H
+    from test_hip_routing import routed_ctx
+
+    g, names, forcing = load_case(case)
+    stops = sorted(int(k[1:]) for k in g.files if k.startswith("s") and k[1:].isdigit())
+    runs = {}
+    for sparse in (True, False):
+        if not sparse:
+            os.environ["RH_NO_SPARSE_STORES"] = "1"
+        try:
+            ctx = routed_ctx(native, g, names)
+        finally:
+            os.environ.pop("RH_NO_SPARSE_STORES", None)
+        ctx.set_forcing_series(forcing)
+        out, done, used = [], 0, 0
+        for stop in stops:
+            ctx.run_steps(stop - done)
+            used += ctx.sparse_steps()
+            if sparse and stop - done >= 2:
+                assert ctx.sparse_steps() == stop - done - 1
+            done = stop
+            out.append((H.scalars_to_row(ctx.get_scalars()), H.download_snapshot(ctx, names)))
+        runs[sparse] = (out, used)
+        ctx.close()
+    assert runs[True][1] > 0 and runs[False][1] == 0
+    for stop, (sa, pa), (sb, pb) in zip(stops, runs[True][0], runs[False][0]):
+        np.testing.assert_array_equal(sa, sb)
+        assert np.array_equal(pa, pb, equal_nan=True), f"{case} step {stop}: sparse stores changed what the caller sees"
+        np.testing.assert_array_equal(sa, g["scal"][stop - 1])
+        compare(pa, g[f"s{stop:05d}"], names, what=f"{case} step {stop} (routed rh_run_steps in pieces)")

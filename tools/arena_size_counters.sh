@@ -6,8 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out/arena_pmc
 export RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000
 pass=0
-# (a pass with the TCP latency counters -- TCP_PENDING_STALL_CYCLES_sum, TCP_TCC_*_REQ_LATENCY_sum -- aborted inside rocprofv3 on this
-# image and hung the call: not repeated)
+# (Round 2 ran a pass with TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum ... together; rocprofv3
+# aborted and the call hung.  Cause, from that pass's own log: rocprofiler_create_counter_config failed with "error code 38:
+# Request exceeds the capabilities of the hardware to collect" -- more TCP counters than the block has slots in ONE pass -- and the tool
+# turns that into a fatal check (signal 6) at the first HIP call of the workload (inside rh_create, before any kernel had run): nothing
+# to do with the fused kernel or its tail.  tools/arena_latency_counters.sh collects those counters ONE per pass.)
 for counters in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"; do
   pass=$((pass + 1))
   for v in base pad9; do

@@ -297,6 +297,31 @@ def main():
         if all_m != ref_m or all_w != ref_w:
             sys.exit(f"sequence {seq} does not match {SEQUENCE_CHECK[seq]}")
         lines.append("")
+    # Sparse stores of the device-driven ROUTED step (three passes: routed_a2 [_monthly], routed_b, routed_c_after, the gathers folded
+    # into the second and third): a plane may be left out by a pass if the whole step only produces it (flow analysis over the
+    # concatenated passes, the gathers as assignments of q_*_in from the neighbours' q_*_out), no LATER pass of the same step loads it
+    # (the passes hand their intermediates over through memory) and it is not what the neighbours gather.
+    gather_src = {"q_sur_out", "q_sub_out"}
+    rfuncs = dict(funcs)
+    rfuncs["rt_gather_surface"] = dict(body="c.q_sur_in = c.q_sur_out + c.flow_dir_topo + c.maskCatch;", refpos=[], colpos=[0])
+    rfuncs["rt_gather_subsurface"] = dict(body="c.q_sub_in = c.q_sub_out + c.flow_dir_topo + c.maskCatch;", refpos=[], colpos=[0])
+    ranalyser = liveness.Analyser(rfuncs)
+    routed_passes = ("routed_b", "routed_c_after")
+
+    def routed_pure(first):
+        seq = (PLAIN_SEQUENCES[first] + ["rt_gather_surface"] + PLAIN_SEQUENCES["routed_b"] + ["rt_gather_subsurface"]
+               + PLAIN_SEQUENCES["routed_c_after"])
+        summ = ranalyser.sequence(seq)
+        return summ.deff - summ.ue
+
+    routed_sparse = (routed_pure("routed_a2") & routed_pure("routed_a2_monthly")) - gather_src
+    mention_of = lambda names: set().union(*[sets[r][0] for r in names])   # noqa: E731
+    routed_skip = {
+        "routed_a2": routed_sparse - mention_of(PLAIN_SEQUENCES["routed_b"] + PLAIN_SEQUENCES["routed_c_after"]),
+        "routed_a2_monthly": routed_sparse - mention_of(PLAIN_SEQUENCES["routed_b"] + PLAIN_SEQUENCES["routed_c_after"]),
+        "routed_b": routed_sparse - mention_of(PLAIN_SEQUENCES["routed_c_after"]),
+        "routed_c_after": routed_sparse,
+    }
     for seq, stages in PLAIN_SEQUENCES.items():
         lines.append(f"// sequence {seq}: " + " -> ".join(stages))
         resident, all_m, all_w = set(), set(), set()
@@ -309,6 +334,8 @@ def main():
             all_w |= write
             lines.append(f"#define RH_SEQ_{seq}_LOAD_{rt}(X) " + " ".join(f"X({n})" for n in sorted(ld, key=order.get)))
             lines.append(f"#define RH_SEQ_{seq}_STORE_{rt}(X) " + " ".join(f"X({n})" for n in sorted(st, key=order.get)))
+            if seq in routed_skip:
+                lines.append(f"#define RH_SEQ_{seq}_SSTORE_{rt}(X) " + " ".join(f"X({n})" for n in sorted(st - routed_skip[seq], key=order.get)))
         if seq.startswith("routed_a2"):
             # k_routed_a2 samples the summary bits of the next step's predicates like the fused kernel: prec / ta after rt_select_pet, swe /
             # swe_top after rt_snow -- no later stage of this pass and no stage of the passes behind it may assign them
@@ -322,6 +349,8 @@ def main():
             if all_m != ref_m or all_w != ref_w:
                 sys.exit(f"sequence {seq} does not match {PLAIN_CHECK[seq]}")
         lines.append("")
+    lines.append(f"// planes the routed step only produces ({len(routed_sparse)}): left out by the last pass that assigns them unless a later pass loads them")
+    lines.append("#define RH_SPARSE_FIELDS_ROUTED(X) " + " ".join(f"X({n})" for n in sorted(routed_sparse, key=order.get)))
     for model in ("svat", "oned"):
         lines.append(f"// planes the fused {model} step only produces ({len(sparse[model])}): not stored by the steps of an rh_run_steps call that another step follows")
         lines.append(f"#define RH_SPARSE_FIELDS_{model.upper()}(X) " + " ".join(f"X({n})" for n in sorted(sparse[model], key=order.get)))

@@ -32,12 +32,20 @@ def census():
         txt = open(os.path.join(tmp, "k.s")).read()
     out = {}
     for fn in re.split(r"\n(?=_Z\w+:)", txt):
-        mr = re.match(r"_Z\d+k_(routed_\w+?)5ArenaP8DevState:", fn)
-        if mr:   # the staged passes of the routed step (settings.enable_routing_1D): k_routed_a / _b / _c / _c_after
+        # the staged passes of the routed step (settings.enable_routing_1D): k_routed_a / _b / _c / _c_after (host-driven), and the
+        # device-driven ones k_routed_a2<SPARSE>, k_routed_bg<SPARSE>, k_routed_cg<AFTER, SPARSE> (the gathers folded in: their eight
+        # neighbour reads of q_out, flow direction and mask count as loads of the pass)
+        mr = re.match(r"_Z\d+k_(routed_[a-z0-9_]+?)(?:ILb([01])E(?:Lb([01])E)?Ev)?5ArenaP8DevState\w*:", fn)
+        if mr:
+            name = mr.group(1)
+            if mr.group(3) is not None:      # k_routed_cg<AFTER, SPARSE>
+                name += ("_after" if mr.group(2) == "1" else "") + ("_sparse" if mr.group(3) == "1" else "")
+            elif mr.group(2) is not None:    # <SPARSE>
+                name += "_sparse" if mr.group(2) == "1" else ""
             body = fn[: fn.find(".Lfunc_end")]   # (the whole function: the kernel has early exits)
             ld = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "load")
             st = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "store")
-            out["mode0_" + mr.group(1)] = {"load_bytes": ld, "store_bytes": st, "in_loops": 0}
+            out["mode0_" + name] = {"load_bytes": ld, "store_bytes": st, "in_loops": 0}
             continue
         m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])ELb([01])EEv", fn)
         if not m:
