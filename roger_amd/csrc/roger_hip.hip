@@ -46,7 +46,12 @@
 #define RH_SRC_WORD3 0       // the summary word sits in words[3] (a fused kernel ran last)
 #define RH_SRC_SUMW 1        // ... in sumw[] (k_summary rebuilt it from the arena)
 #ifndef RH_STEP_PREFETCH
-#define RH_STEP_PREFETCH 0  // 1: request the next stage's planes before computing the current one (measured slower: spills)
+// 0: a stage's planes are requested right in front of it.  1: the NEXT stage's planes are requested before the current stage computes
+// -- in the source; the compiler sinks the loads back to their first use (no difference measured).  2 (default since round 3): the same
+// with a scheduling barrier behind the requests (__builtin_amdgcn_sched_barrier), so that a stage's arithmetic runs under the next
+// stage's loads: 197 VGPRs as before, nothing spilled, 2 - 3 % per step (10^6 columns 0.2294 -> 0.2228 ms, 10^7 2.047 -> 2.000 ms, oneD
+// 0.2413 -> 0.2354 ms; library variants alternating inside one call, tools/ab_variants.sh).
+#define RH_STEP_PREFETCH 2
 #endif
 #ifndef RH_STEP_WAVES
 #define RH_STEP_WAVES 2     // waves per SIMD the fused kernel is compiled for (register budget 512 / waves)
@@ -1136,36 +1141,41 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
         RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)       \
     }
 #if RH_STEP_PREFETCH
+#if RH_STEP_PREFETCH >= 2
+#define RH_PIN __builtin_amdgcn_sched_barrier(0);
+#else
+#define RH_PIN
+#endif
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
-    RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception)  \
+    RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception) RH_PIN  \
     rt_select_prec(c, X, prec_s, ta_s); RH_STORES(seq, rt_select_prec)                                                \
     rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
     q = summary_bits_pt(c.prec, c.ta, K);                                                                \
     MON_RUN                                                                                              \
-    RH_LOADS(seq, rt_evapotranspiration)                                                                 \
+    RH_LOADS(seq, rt_evapotranspiration) RH_PIN                                                                 \
     rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
-    RH_LOADS(seq, rt_snow)                                                                               \
+    RH_LOADS(seq, rt_snow) RH_PIN                                                                               \
     rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)                                   \
-    RH_LOADS(seq, rt_inf_events)                                                                         \
+    RH_LOADS(seq, rt_inf_events) RH_PIN                                                                         \
     rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
     q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
-    RH_LOADS(seq, rt_inf_matrix)                                                                         \
+    RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                         \
     rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
-    RH_LOADS(seq, rt_inf_macropores)                                                                     \
+    RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                                     \
     rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                                                \
-    RH_LOADS(seq, rt_inf_cracks)                                                                         \
+    RH_LOADS(seq, rt_inf_cracks) RH_PIN                                                                         \
     rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)                                        \
-    RH_LOADS(seq, rt_inf_finish)                                                                         \
+    RH_LOADS(seq, rt_inf_finish) RH_PIN                                                                         \
     rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
-    RH_LOADS(seq, sub_rt)                                                                                \
+    RH_LOADS(seq, sub_rt) RH_PIN                                                                                \
     rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
-    RH_LOADS(seq, rt_capillary_rise)                                                                     \
+    RH_LOADS(seq, rt_capillary_rise) RH_PIN                                                                     \
     sub_call; RH_STORES(seq, sub_rt)                                                                     \
-    RH_LOADS(seq, rt_storage)                                                                            \
+    RH_LOADS(seq, rt_storage) RH_PIN                                                                            \
     rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
-    RH_LOADS(seq, ne_rt)                                                                                 \
+    RH_LOADS(seq, ne_rt) RH_PIN                                                                                 \
     rt_storage(c, X); RH_STORES(seq, rt_storage)                                                         \
-    RH_LOADS(seq, at_rt)                                                                                 \
+    RH_LOADS(seq, at_rt) RH_PIN                                                                                 \
     bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
     at_call; RH_STORES(seq, at_rt)
 #else
