@@ -78,3 +78,56 @@ def test_comm_through_torch_process_group():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_time_limit_with_the_multi_gpu_stepping():
+    """rh_set_time_limit under rh_run_steps_dist (the all-reduce and the control kernel run in front of every step; the control
+    kernel finds the run over): the same stop, the same state as rh_run_steps under the limit, and the communicator is reported."""
+    import hip_util as H
+    from roger_amd import _native as native
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    a, b = _ctx(native, g, names), _ctx(native, g, names)
+    for c in (a, b):
+        c.set_forcing_series(forcing)
+    b.comm_init(native.comm_unique_id(), 1, 0)
+    assert b.comm_info() == (1, 0) and a.comm_info() == (1, 0)
+    stop = 80
+    t_stop = int(g["scal"][stop - 1][1])
+    for c in (a, b):
+        c.set_time_limit(t_stop)
+    a.run_steps(stop + 25)
+    b.run_steps_dist(stop + 25)
+    for c in (a, b):
+        np.testing.assert_array_equal(H.scalars_to_row(c.get_scalars()), g["scal"][stop - 1])
+    sa, sb = H.download_snapshot(a, names), H.download_snapshot(b, names)
+    np.testing.assert_array_equal(sa, sb)
+    compare(sb, g[f"s{stop:05d}"], names, what="rh_run_steps_dist stopped by the time limit")
+    b.set_time_limit(None)
+    a.set_time_limit(None)
+    a.run_steps(9)
+    b.run_steps_dist(9)
+    np.testing.assert_array_equal(H.download_snapshot(a, names), H.download_snapshot(b, names))
+    np.testing.assert_array_equal(H.scalars_to_row(b.get_scalars()), g["scal"][stop + 8])
+    a.close()
+    b.close()
+
+
+def test_time_limit_is_refused_where_the_control_part_does_not_observe_it():
+    """Per-cell forcing takes the predicate-kernel control path, which does not look at the limit: rh_run_steps says so instead of
+    running past it."""
+    from golden_util import load_weights
+    from roger_amd import _native as native
+
+    g, names, forcing = load_case("svat_eberbaechle_weights")
+    w = load_weights(g)
+    ctx = _ctx(native, g, names)
+    ctx.set_forcing_series(forcing)
+    ctx.set_forcing_weights(w["prec_weight"], w["ta_offset"], w["pet_weight"])
+    ctx.run_steps(3)
+    ctx.set_time_limit(10 * 86400)
+    with pytest.raises(native.NativeError, match="rh_set_time_limit"):
+        ctx.run_steps(5)
+    ctx.set_time_limit(None)
+    ctx.run_steps(5)
+    ctx.close()
