@@ -349,6 +349,9 @@ int rh_timing_detail(rh_ctx *ctx, double *kernel_ms, int32_t *dt_secs, int64_t c
  * the access shape of the fused kernel (8 bytes per lane and plane); moves a known
  * 2 * nplanes * n_cells * 8 bytes, used to calibrate the HBM counters.  Overwrites the planes. */
 int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes);
+/* x[i] ** y[i] by the power function the kernels use (roger_amd/csrc/rh_pow.h), evaluated on the device: tests compare it bit for bit
+ * with the host's compilation of the same header, whose accuracy is established against the C library's pow. */
+int rh_selftest_pow(const double *x, const double *y, double *out, int64_t n);
 /* Measurement aid: two contexts of the same shape and state exchange their arenas (does a speed level belong to the allocation?). */
 int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b);
 

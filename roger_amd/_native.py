@@ -160,6 +160,7 @@ def load():
     lib.rh_predicates_expand.argtypes = [vp, i32, vp]
     lib.rh_predicates_compress.argtypes = [vp, i32, vp]
     lib.rh_calibrate_copy.argtypes = [vp, i32, i32, i32]
+    lib.rh_selftest_pow.argtypes = [vp, vp, vp, i64]
     lib.rh_debug_swap_arenas.argtypes = [vp, vp]
     lib.rh_predicate_words.argtypes = [vp]
     lib.rh_predicate_words.restype = vp
@@ -396,11 +397,23 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_set_lut_mlms", "rh_params_lateral",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_selftest_pow", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_set_time_limit", "rh_run_steps_dist",
     "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_planes_held", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
+
+
+def selftest_pow(x, y):
+    """x ** y by the kernels' own power function (rh_pow.h) on the device."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty_like(x)
+    rc = lib.rh_selftest_pow(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), x.size)
+    if rc != 0:
+        raise NativeError(f"rh_selftest_pow failed ({rc})")
+    return out
 
 
 def comm_unique_id():

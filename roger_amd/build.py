@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # translation units and what each depends on (besides its own .hip): compiled side by side, objects cached in roger_amd/_obj
 _SAS_DEPS = ("rh_sas_dev.h", "rh_sas_tables.inc", "include/roger_hip_sas.h", "include/rh_sas_arrays.def", "include/roger_hip.h")
 UNITS = {
-    "roger_hip": ("rh_physics.h", "rh_col.h", "rh_sets.inc", "include/roger_hip.h", "include/rh_fields.def"),
+    "roger_hip": ("rh_physics.h", "rh_pow.h", "rh_col.h", "rh_sets.inc", "include/roger_hip.h", "include/rh_fields.def"),
     "rh_sas": _SAS_DEPS,                                            # the SAS C ABI
     "rh_sas_det_iso": _SAS_DEPS + ("rh_sas_kernels.h",),            # the deterministic SAS kernels: isotopes ...
     "rh_sas_det_anion": _SAS_DEPS + ("rh_sas_kernels.h",),          # ... and anions

@@ -15,6 +15,17 @@
 
 #include "rh_col.h"
 
+// The power function of the physics: rh_pow (rh_pow.h: ~80 instructions instead of the library's 230, within 1 ulp of a correctly rounded
+// pow, the same bits on host and device); -DRH_POW_LIBRARY selects the library's pow (A/B, and what rounds 1 - 2 ran).
+#define RH_POW_FN __device__ __forceinline__
+#define RH_POW_CONST static __constant__
+#include "rh_pow.h"
+#ifdef RH_POW_LIBRARY
+#define RH_POW(x, y) pow(x, y)
+#else
+#define RH_POW(x, y) rh_pow(x, y)
+#endif
+
 RH_DEV double h_b(bool x) { return x ? 1.0 : 0.0; }
 
 // ---------------------------------------------------------------------------------------------
@@ -156,7 +167,7 @@ RH_DEV void rt_evapotranspiration(Col &c, const Consts &K) {
         const bool anoxia = (lu > 500) && (lu < 599) && (c.theta_rz >= 0.8 * c.theta_sat);
         if (anoxia) {  // only crops; keeps the pow off the common path
             const double r = c.S_lp_rz / c.S_ac_rz;
-            c.transp_coeff = ((r >= 0) && (r <= 1) ? 1 - pow(r, 1.5) : 1.0);
+            c.transp_coeff = ((r >= 0) && (r <= 1) ? 1 - RH_POW(r, 1.5) : 1.0);
         }
         c.transp_coeff = c.transp_coeff * mk;
         const double pt0 = (c.pevap_soil < c.pet ? c.pet - c.pevap_soil : 0.0) * mk;
@@ -468,7 +479,7 @@ RH_DEV void h_inf_mp(Col &c, const Consts &K, double dt, int substeps, double mk
         double b2 = (r * td2) * (12 * cc - a + b1) * mk;
         b2 = (isnan(b2) ? 0.0 : b2) * mk;
         b2 = (b2 <= 0 ? 0.0 : b2) * mk;
-        const double cb = pow(b2, 1.0 / 3);
+        const double cb = RH_POW(b2, 1.0 / 3);
         const double y1 = (cb / c.theta_d) * 0.5 * mk;
         const double y2 = (a / cb) * 0.5 * mk;
         y = (y1 + y2 + ym1) * mk;
@@ -645,8 +656,8 @@ RH_DEV void rt_infiltration_routed(Col &c, const Consts &K, const StepCtx &X) {
 // Salvucci capillary term shared by percolation and capillary rise:
 // (p1 - p2) / (1 + p2 + (n - 1) p1), p1 = (z / (-ha 10.2))^-n, p2 = (-h / -ha)^-n
 RH_DEV double h_salvucci(double z, double hpot, double ha, double n) {
-    const double p1 = pow(z / (-ha * 10.2), -n);
-    const double p2 = pow(-hpot / -ha, -n);
+    const double p1 = RH_POW(z / (-ha * 10.2), -n);
+    const double p2 = RH_POW(-hpot / -ha, -n);
     return (p1 - p2) / (1 + p2 + (n - 1) * p1);
 }
 
@@ -886,9 +897,9 @@ RH_DEV void rt_capillary_rise(Col &c, const StepCtx &X) {
 // storages: surface.py:8-37, root_zone.py:7-166, subsoil.py:6-137, soil.py:9-140,
 // numerics.py:125-214
 // ---------------------------------------------------------------------------------------------
-RH_DEV double h_k_bc(double ks, double theta, double theta_sat, double m_bc) { return ks / (1 + pow(theta / theta_sat, -m_bc)); }
+RH_DEV double h_k_bc(double ks, double theta, double theta_sat, double m_bc) { return ks / (1 + RH_POW(theta / theta_sat, -m_bc)); }
 RH_DEV double h_h_bc(double ha, double theta, double theta_sat, double lambda_bc) {
-    return ha / pow(theta / theta_sat, 1 / lambda_bc);
+    return ha / RH_POW(theta / theta_sat, 1 / lambda_bc);
 }
 
 RH_DEV void rt_storage(Col &c, const StepCtx &X) {
@@ -972,7 +983,7 @@ RH_DEV void rt_route_surface_out(Col &c, const Consts &K, const StepCtx &X, doub
     const double perimeter = 2 * (c.z0 / 1000) + K.dx * mk;
     const double radius = area / perimeter * mk;
     // Manning-Strickler, m3/s to mm per step
-    c.q_sur = c.k_st * pow(c.slope, 0.5) * pow(radius, 2.0 / 3.0) * area * (dt_secs / (K.dx * K.dy * 1000)) * mk;
+    c.q_sur = c.k_st * RH_POW(c.slope, 0.5) * RH_POW(radius, 2.0 / 3.0) * area * (dt_secs / (K.dx * K.dy * 1000)) * mk;
     c.q_sur = (c.q_sur > c.z0 ? c.z0 : c.q_sur) * mk;
     c.q_sur_out = h_d8_out(c.q_sur, c.flow_dir_topo, mk);
 }
@@ -1124,21 +1135,21 @@ RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     c.theta_sat = por * mk;
     c.theta_fc = fc * mk;
     c.lambda_bc = ((log(c.theta_fc / c.theta_sat) - log(c.theta_pwp / c.theta_sat)) / (log(15850.0) - log(63.0))) * mk;
-    c.ha = (pow(c.theta_pwp / c.theta_sat, 1.0 / c.lambda_bc) * (-15850)) * mk;
+    c.ha = (RH_POW(c.theta_pwp / c.theta_sat, 1.0 / c.lambda_bc) * (-15850)) * mk;
     const double nb = K.a_bc + K.b_bc * c.lambda_bc;
     c.m_bc = (nb / c.lambda_bc) * mk;
     c.n_salv = nb * mk;
     c.wfs = (((2 + 3 * c.lambda_bc) / (1 + 3 * c.lambda_bc) * c.ha / 2) * (-10)) * mk;
-    c.theta_27 = (pow(c.ha / (-501.18723362727246), c.lambda_bc) * c.theta_sat) * mk;  // 10**2.7
-    c.theta_4 = (pow(c.ha / (-10000.0), c.lambda_bc) * c.theta_sat) * mk;
-    c.theta_6 = (pow(c.ha / (-1000000.0), c.lambda_bc) * c.theta_sat) * mk;
+    c.theta_27 = (RH_POW(c.ha / (-501.18723362727246), c.lambda_bc) * c.theta_sat) * mk;  // 10**2.7
+    c.theta_4 = (RH_POW(c.ha / (-10000.0), c.lambda_bc) * c.theta_sat) * mk;
+    c.theta_6 = (RH_POW(c.ha / (-1000000.0), c.lambda_bc) * c.theta_sat) * mk;
     double s = (1 * (c.theta_ac / 0.24)) * mk;
     s = (s < 0 ? 0.0 : s) * mk;
     c.sand = (s > 1 ? 1.0 : s) * mk;
     double cl = (K.clay_max * (c.theta_6 - K.clay_min) / 0.3) * mk;
     c.clay = (cl < K.clay_min ? K.clay_min : cl) * mk;
     c.z_sc_max = (c.clay * 700) * mk;
-    c.mp_drain_area = 1 - exp((-1) * pow(c.dmpv / 82, 0.887)) * mk;
+    c.mp_drain_area = 1 - exp((-1) * RH_POW(c.dmpv / 82, 0.887)) * mk;
 
     double rew = (c.theta_pwp < K.theta_rew_min ? K.rew_min : c.rew) * mk;
     rew = ((c.theta_pwp >= K.theta_rew_min) && (c.theta_pwp <= K.theta_rew_max) ? c.theta_pwp / K.theta_rew_max : rew) * mk;

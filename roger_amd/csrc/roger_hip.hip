@@ -3366,6 +3366,29 @@ int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b) {
     return RH_OK;
 }
 
+// rh_pow on the device for n argument pairs (tests: the same bits as the host's compilation of rh_pow.h)
+__global__ void k_selftest_rh_pow(const double *x, const double *y, double *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rh_pow(x[i], y[i]);
+}
+int rh_selftest_pow(const double *x, const double *y, double *out, int64_t n) {
+    if (!x || !y || !out || n <= 0) return RH_ERR_ARG;
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)) != hipSuccess) return RH_ERR_HIP;
+    int rc = RH_OK;
+    if (hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = RH_ERR_HIP;
+    if (rc == RH_OK) {
+        hipLaunchKernelGGL(k_selftest_rh_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = RH_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
     if (!ctx) return 0;
     const int n = (int)ctx->probe_ms.size();
