@@ -182,7 +182,13 @@ struct Blk {
     unsigned phase;        // alternates the double-buffered LDS scratch; one barrier per use
     double (*red)[W][8];   // [2][W][8]
     double (*xch)[W][2];   // [2][W][2]
+    double *park;          // LDS parking area of the eight-class shapes ([2][8][W * 64] doubles), else null
+    const double *scal;    // LDS copy of the column's scalars of the day (SasScal), the deterministic kernels only
 };
+// The column's scalars of the day -- the five fluxes, the three infiltration terms, the input signal, seven SAS parameters per flux --
+// fetched in ONE batch of independent loads at the start of the kernel and kept in LDS: read where they are needed, each is a dependent
+// round trip to HBM in front of a branch (flux > 0?  which family?), two or three per flux, while both waves of the column wait.
+enum SasScal { SC_FLUX = 0, SC_INF = 5, SC_CIN = 8, SC_PAR = 9, SC_COUNT = SC_PAR + 5 * 7 };
 
 // Cross-lane moves as DPP (data-parallel primitive) modifiers on VALU moves instead of LDS-crossbar
 // shuffles: a DPP move costs one VALU issue, a ds_bpermute a round trip through the LDS pipeline, and
@@ -196,14 +202,24 @@ SAS_DEV double dpp_move(double ident, double v) {
     const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(iv >> 32), (int)(unsigned)(sv >> 32), CTRL, ROW_MASK, 0xf, false);
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+// the same with 0 for the lanes without a source (bound_ctrl: the hardware supplies the zero, no register has to be cleared first);
+// only for controls that write every row (row mask 0xf)
+template <int CTRL>
+SAS_DEV double dpp_move0(double v) {
+    const unsigned long long sv = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)sv, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(sv >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 // value of the previous lane; lane 0 gets `first`
 SAS_DEV double lane_prev(double v, double first) { return dpp_move<0x138, 0xf>(first, v); }
+SAS_DEV double lane_prev0(double v) { return dpp_move0<0x138>(v); }   // ... gets 0
 // inclusive prefix sum over the 64 lanes (earlier lanes + own)
 SAS_DEV double wave_scan_sum(double v) {
-    v = dpp_move<0x111, 0xf>(0.0, v) + v;
-    v = dpp_move<0x112, 0xf>(0.0, v) + v;
-    v = dpp_move<0x114, 0xf>(0.0, v) + v;
-    v = dpp_move<0x118, 0xf>(0.0, v) + v;
+    v = dpp_move0<0x111>(v) + v;
+    v = dpp_move0<0x112>(v) + v;
+    v = dpp_move0<0x114>(v) + v;
+    v = dpp_move0<0x118>(v) + v;
     v = dpp_move<0x142, 0xa>(0.0, v) + v;
     v = dpp_move<0x143, 0xc>(0.0, v) + v;
     return v;
@@ -226,6 +242,29 @@ SAS_DEV double wave_max(double v) {
 }
 // sum over the 64 lanes, in every lane
 SAS_DEV double wave_sum(double v) { return lane63(wave_scan_sum(v)); }
+
+// Parking: two age vectors of a thread leave the register file for LDS while the kernel works on the other compartment (the eight-class
+// shapes: the state of a column is 64 registers per thread, the sub-step loop needs only the StorAge it works on).  Every thread reads back
+// what it wrote itself -- no barrier; slot [a][j][tid], so the lanes of a wave touch consecutive words.  Without a parking area (B.park == null:
+// the other shapes) both calls do nothing and the vectors stay in registers.
+template <int W, int E>
+SAS_DEV void park2(const Blk<W> &B, const double (&a)[E], const double (&b)[E]) {
+    if (!B.park) return;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        B.park[(0 * E + j) * (W * 64) + B.tid] = a[j];
+        B.park[(1 * E + j) * (W * 64) + B.tid] = b[j];
+    }
+}
+template <int W, int E>
+SAS_DEV void unpark2(const Blk<W> &B, double (&a)[E], double (&b)[E]) {
+    if (!B.park) return;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        a[j] = B.park[(0 * E + j) * (W * 64) + B.tid];
+        b[j] = B.park[(1 * E + j) * (W * 64) + B.tid];
+    }
+}
 
 // value of the previous thread (thread 0: `first`), two values per call
 template <int W>
@@ -306,7 +345,7 @@ SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double
 #pragma unroll
     for (int j = 1; j < E; ++j) loc[j] = loc[j - 1] + v[j];
     const double winc = wave_scan_sum(loc[E - 1]);
-    const double wexc = lane_prev(winc, 0.0);
+    const double wexc = lane_prev0(winc);
     double u[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) u[j] = wexc + loc[j];
@@ -452,16 +491,22 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
 #pragma unroll
             for (int j = 0; j < E; ++j) Om[j] = 0.0 * mk;
         } else if (kmode != 0) {
+            // one straight-line loop per variant (the variant is uniform over the workgroup): with the selection inside the class loop
+            // the compiler kept a branch per class and the eight independent square roots ran one after the other
             const UDiv by_S = udiv_prepare(S);
+            double r[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = udiv(SA_hi[j], by_S);
+            if (kmode == 1) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = sqrt_unit(r[j]);
+            } else if (kmode == 2) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = r[j] * sqrt_unit(r[j]);
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const double x = SA_hi[j];
-                const double r = udiv(x, by_S);
-                double v;
-                if (kmode == 1) v = sqrt_unit(r);
-                else if (kmode == 2) v = r * sqrt_unit(r);
-                else v = r;
-                const double o = (x > 0 ? fmin(v, 1.) : 0.) * 1.0 * mk;   // x <= S ? v : 1, and v > 1 exactly where x > S
+                const double o = (SA_hi[j] > 0 ? fmin(r[j], 1.) : 0.) * 1.0 * mk;   // x <= S ? v : 1, and v > 1 exactly where x > S
                 Om[j] = o * mk;
             }
         } else {
@@ -560,11 +605,18 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
             mx = fmax(mx, cdf_hi[j]);
         }
     }
+    // the five counts, the two sums and the maximum cross the waves in ONE exchange (eight slots per wave, one barrier)
+    v[0] = wave_sum(v[0]);
+    v[1] = wave_sum(v[1]);
+    mx = wave_max(mx);
     if (W > 1) {
         const int buf = B.phase++ & 1;
         if (B.lane == 0) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) B.red[buf][B.wave][q] = (double)cnt5[q];
+            B.red[buf][B.wave][5] = v[0];
+            B.red[buf][B.wave][6] = v[1];
+            B.red[buf][B.wave][7] = mx;
         }
         SAS_SYNC();
 #pragma unroll
@@ -573,9 +625,15 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
             for (int w = 1; w < W; ++w) c += B.red[buf][w][q];
             cnt5[q] = (int)c;
         }
+        v[0] = B.red[buf][0][5];
+        v[1] = B.red[buf][0][6];
+        mx = B.red[buf][0][7];
+        for (int w = 1; w < W; ++w) {
+            v[0] = v[0] + B.red[buf][w][5];
+            v[1] = v[1] + B.red[buf][w][6];
+            mx = fmax(mx, B.red[buf][w][7]);
+        }
     }
-    blk_sum<W, 2>(B, v);
-    mx = blk_max<W>(B, mx);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         if (skip10_90 && (q == 0 || q == 4)) continue;

@@ -43,16 +43,25 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
         sas_omega<W, E, FAM>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
         double Om_lo, unused;
         blk_prev2<W>(B, Om[E - 1], 0.0, Om_edge0, 0.0, Om_lo, unused);
-        double tti[E];
+        // Written stage by stage over the thread's classes, not class by class: the E chains are independent, and in the class-by-class
+        // form the compiler emitted them one after the other through a single temporary (eleven dependent fp64 operations each).
+        double tq[E], tti[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const double d = Om[j] - (j == 0 ? Om_lo : Om[j - 1]);
-            double t = fmax(d, 0.0);                                            // :430-433  where(d >= 0, d, 0)
-            const double q = fmin(flux * t * h, san[j]);                        // :435-438  where(flux t h > san, san, flux t h)
-            t = udiv(q, by_fh);                                                 // :440-443: q / (flux * h), fh > 0 here
-            san[j] = san[j] + -t * flux * h;                                    // :445-448
-            tti[j] = t;
-        }
+        for (int j = 0; j < E; ++j) tq[j] = fmax(Om[j] - (j == 0 ? Om_lo : Om[j - 1]), 0.0);   // :430-433  where(d >= 0, d, 0)
+#pragma unroll
+        for (int j = 0; j < E; ++j) tq[j] = flux * tq[j];
+#pragma unroll
+        for (int j = 0; j < E; ++j) tq[j] = fmin(tq[j] * h, san[j]);                            // :435-438  where(flux t h > san, san, flux t h)
+#pragma unroll
+        for (int j = 0; j < E; ++j) tti[j] = tq[j] * by_fh.r;                                   // :440-443: q / (flux * h), fh > 0 here
+#pragma unroll
+        for (int j = 0; j < E; ++j) tq[j] = __builtin_fma(-by_fh.d, tti[j], tq[j]);             //   (udiv, its three steps stage by stage)
+#pragma unroll
+        for (int j = 0; j < E; ++j) tti[j] = __builtin_fma(tq[j], by_fh.r, tti[j]);
+#pragma unroll
+        for (int j = 0; j < E; ++j) tq[j] = -tti[j] * flux;
+#pragma unroll
+        for (int j = 0; j < E; ++j) san[j] = san[j] + tq[j] * h;                                // :445-448
         // :461-468.  The reference accumulates TTn += cumsum(tti) and takes diff(TTn / N) afterwards (:482-490);
         // diff(cumsum(.)) is the identity, so the sub-step distributions are accumulated directly (the
         // reference's own `ttn`).  Differs from the round trip through the cumulative sums by ~1e-16 absolute
@@ -94,13 +103,16 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
 // calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
 // calc_percolation_rz/ss_transport_iso_kernel (core/subsurface_runoff.py:1531-1626, 1753-1820),
 // calc_capillary_rise_rz_transport_iso_kernel (core/capillary_rise.py:404-500).
+// sa / msa: the compartment the flux leaves; sa_sink / msa_sink: the OTHER compartment, which receives the water if SINK and is otherwise
+// untouched -- either way it waits in the parking area (park2) while the sub-steps and the statistics run.
 template <int W, int E, bool SINK, bool KEEP>
 SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&sa)[E], double (&msa)[E], double (&sa_sink)[E],
                      double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
     const int A = P.ages;
-    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
-    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
+    const double flux = B.scal[SC_FLUX + f];
+    const double *p = B.scal + SC_PAR + 7 * f;
     double tt[E];
+    park2<W, E>(B, sa_sink, msa_sink);
     calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
     double mtt[E], s[2] = {0.0, 0.0};
 #pragma unroll
@@ -136,6 +148,7 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
         ((double *)P.a[SA_C_evap_soil + f])[cell] = C;
         ((double *)P.a[SA_C_iso_evap_soil + f])[cell] = conc_to_delta(P, C) * mk;
     }
+    unpark2<W, E>(B, sa_sink, msa_sink);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         if (SINK) {
@@ -157,8 +170,8 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
 // and calc_infiltration_ss_transport_iso_kernel (:2441-2512).  which: 0 matrix -> rz, 1 pf -> rz, 2 pf -> ss.
 template <int W, int E>
 SAS_DEV void inflow(Blk<W> &B, const SasArgs &P, int64_t cell, int which, double (&sa)[E], double (&msa)[E], double mk, int base) {
-    const double inf = ((const double *)P.a[SA_inf_mat_rz + which])[P.day_off + cell];
-    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
+    const double inf = B.scal[SC_INF + which];
+    const double C_in = B.scal[SC_CIN];
     if (B.tid == 0) {
         const double C = (inf > 0 ? C_in : 0) * mk;
         ((double *)P.a[SA_C_inf_mat_rz + which])[cell] = C;
@@ -217,9 +230,10 @@ SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, int b
 template <int W, int E, bool SINK, bool KEEP, bool WATER>
 SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double alpha, double (&sa)[E], double (&msa)[E],
                            double (&sa_sink)[E], double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
-    const double flux = ((const double *)P.a[SA_evap_soil + f])[P.day_off + cell];
-    const double *p = (const double *)P.a[SA_sas_params_evap_soil + f] + cell * 8;
+    const double flux = B.scal[SC_FLUX + f];
+    const double *p = B.scal + SC_PAR + 7 * f;
     double tt[E];
+    park2<W, E>(B, sa_sink, msa_sink);   // the other compartment (outflux above)
     calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
     double mtt[E], s[1] = {0.0};
 #pragma unroll
@@ -241,6 +255,7 @@ SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, dou
             ((double *)P.a[SA_M_evap_soil + f])[cell] = s[0] * mk;
         }
     }
+    unpark2<W, E>(B, sa_sink, msa_sink);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         double v = sa[j] + -flux * tt[j];  // update_sa :599-619
@@ -259,11 +274,11 @@ SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, dou
 template <int W, int E>
 SAS_DEV void inflow_anion(Blk<W> &B, const SasArgs &P, int64_t cell, bool subsoil, double (&sa)[E], double (&msa)[E], double mk,
                           int base) {
-    const double C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
+    const double C_in = B.scal[SC_CIN];
     double d_sa, d_msa;
     if (!subsoil) {
-        const double im = ((const double *)P.a[SA_inf_mat_rz])[P.day_off + cell];
-        const double ip = ((const double *)P.a[SA_inf_pf_rz])[P.day_off + cell];
+        const double im = B.scal[SC_INF + 0];
+        const double ip = B.scal[SC_INF + 1];
         const double C0 = (im > 0 ? C_in : 0) * mk, C1 = (ip > 0 ? C_in : 0) * mk;
         const double M0 = C0 * im * mk, M1 = C1 * ip * mk;
         if (B.tid == 0) {
@@ -275,7 +290,7 @@ SAS_DEV void inflow_anion(Blk<W> &B, const SasArgs &P, int64_t cell, bool subsoi
         d_sa = im + ip * mk;
         d_msa = M0 + M1 * mk;
     } else {
-        const double ip = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell];
+        const double ip = B.scal[SC_INF + 2];
         const double C2 = (ip > 0 ? C_in : 0) * mk;
         const double M2 = C2 * ip * mk;
         if (B.tid == 0) {
@@ -320,7 +335,10 @@ SAS_DEV void load_dist(const SasArgs &P, int64_t cell, int base, int f, Dist<E> 
 #endif
 // Eight age classes per thread (the <2, 8> shape for ages <= 1024, RH_SAS_E8): the scans and lane exchanges of a sub-step are paid
 // once per thread, so twice the classes per thread halve their share; the state then needs the register budget of 2 waves per SIMD.
-#define SAS_OCCUPANCY_E8 __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef RH_SAS_E8_WAVES
+#define RH_SAS_E8_WAVES 2
+#endif
+#define SAS_OCCUPANCY_E8 __attribute__((amdgpu_waves_per_eu(RH_SAS_E8_WAVES, RH_SAS_E8_WAVES)))
 template <int W, int E, bool ANION>
 __device__ __forceinline__ void sas_body(const SasArgs &P);
 template <int W, int E, bool ANION>
@@ -344,9 +362,30 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     __shared__ double2 s_logt[64];
+    __shared__ double s_park[E == 8 ? 2 * 8 * W * 64 : 1];   // two age vectors per thread (park2): the eight-class shapes only
+    __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
+    {   // the column's scalars of the day (SasScal): independent loads, one wait
+        const int64_t c = blockIdx.x, dc = P.day_off + c;
+        double v[SC_COUNT];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) v[SC_FLUX + f] = ((const double *)P.a[SA_evap_soil + f])[dc];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[SC_INF + k] = ((const double *)P.a[SA_inf_mat_rz + k])[dc];
+        v[SC_CIN] = ((const double *)P.a[SA_C_in])[dc];
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) v[SC_PAR + 7 * f + i] = ((const double *)P.a[SA_sas_params_evap_soil + f])[c * 8 + i];
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < SC_COUNT; ++k) s_scal[k] = v[k];
+        }
+    }
     __syncthreads();
     Blk<W> B;
+    B.scal = s_scal;
+    B.park = (E == 8) ? s_park : nullptr;
     B.logt = s_logt;
     B.tid = threadIdx.x;
     B.lane = threadIdx.x & 63;
@@ -382,9 +421,9 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
         if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, sa_rz, msa_rz, mk, base);
         if (P.stages & RH_SAS_EVAP) {   // water only -- but the virtual tracer leaves with it at alpha = 1
             if (P.tracer == RH_SAS_TRACER_VIRTUAL)
-                outflux_anion<W, E, false, false, false>(B, P, cell, 0, 1.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+                outflux_anion<W, E, false, false, false>(B, P, cell, 0, 1.0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
             else
-                outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+                outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
         }
         if (P.stages & RH_SAS_TRANSP) {
             // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
@@ -395,14 +434,14 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
             blk_sum<W, 1>(B, S);
             const bool stop = (lu > 500) && (lu < 599) && (S[0] >= 0.8 * ((const double *)P.a[SA_S_sat_rz])[cell]);
             const double alpha = (stop ? 0 : ((const double *)P.a[SA_alpha_transp])[cell]) * mk;
-            outflux_anion<W, E, false, true, false>(B, P, cell, 1, alpha, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+            outflux_anion<W, E, false, true, false>(B, P, cell, 1, alpha, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
             have_transp = true;
         }
         if (P.stages & RH_SAS_Q_RZ)
             outflux_anion<W, E, true, false, false>(B, P, cell, 2, alpha_q, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
         if (P.stages & RH_SAS_INF_SS) inflow_anion<W, E>(B, P, cell, true, sa_ss, msa_ss, mk, base);
         if (P.stages & RH_SAS_Q_SS) {
-            outflux_anion<W, E, false, true, false>(B, P, cell, 3, alpha_q, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
+            outflux_anion<W, E, false, true, false>(B, P, cell, 3, alpha_q, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_q_ss);
             have_q_ss = true;
         }
         if (P.stages & RH_SAS_CPR)
@@ -412,15 +451,15 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
         inflow<W, E>(B, P, cell, 0, sa_rz, msa_rz, mk, base);
         inflow<W, E>(B, P, cell, 1, sa_rz, msa_rz, mk, base);
     }
-    if (P.stages & RH_SAS_EVAP) outflux<W, E, false, false>(B, P, cell, 0, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+    if (P.stages & RH_SAS_EVAP) outflux<W, E, false, false>(B, P, cell, 0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
     if (P.stages & RH_SAS_TRANSP) {
-        outflux<W, E, false, true>(B, P, cell, 1, sa_rz, msa_rz, sa_rz, msa_rz, mk, base, d_transp);
+        outflux<W, E, false, true>(B, P, cell, 1, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
         have_transp = true;
     }
     if (P.stages & RH_SAS_Q_RZ) outflux<W, E, true, false>(B, P, cell, 2, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
     if (P.stages & RH_SAS_INF_SS) inflow<W, E>(B, P, cell, 2, sa_ss, msa_ss, mk, base);
     if (P.stages & RH_SAS_Q_SS) {
-        outflux<W, E, false, true>(B, P, cell, 3, sa_ss, msa_ss, sa_ss, msa_ss, mk, base, d_q_ss);
+        outflux<W, E, false, true>(B, P, cell, 3, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_q_ss);
         have_q_ss = true;
     }
     if (P.stages & RH_SAS_CPR) outflux<W, E, true, false>(B, P, cell, 4, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
@@ -494,9 +533,11 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
                 age_stats<W, E>(B, P, cell, base, d.TT_hi, d.TT_lo, d.tt, SA_tt10_q_ss, false);
             }
             // the reference never assigns rt10 / rt90 of root zone and subsoil (:181-196, :232-247)
+            park2<W, E>(B, msa_rz, msa_ss);   // (the statistics read the StorAges only)
             residence_stats<W, E>(B, P, cell, base, sa_rz, mk, SA_rt10_rz, true);
             residence_stats<W, E>(B, P, cell, base, sa_ss, mk, SA_rt10_ss, true);
             residence_stats<W, E>(B, P, cell, base, sa_s, mk, SA_rt10_s, false);
+            unpark2<W, E>(B, msa_rz, msa_ss);
         }
     }
 

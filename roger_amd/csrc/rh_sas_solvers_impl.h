@@ -593,6 +593,8 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     B.phase = 0;
     B.red = s_red;
     B.xch = s_xch;
+    B.park = nullptr;
+    B.scal = nullptr;
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
