@@ -97,9 +97,43 @@ static double conc_to_delta(const oc_sas *P, double conc) {
     return ((d < P->d18O_min) || (d > P->d18O_max)) ? NAN : d;
 }
 
+/* DIAGNOSTIC SWITCHES (environment OC_SAS_DEVICE_ORDER, default 0 = the reference's arithmetic; tools/sas_tie_causes.py): the device
+ * kernel differs from the reference in the ORDER of two floating-point summations, and this reproduces either on the CPU to find out
+ * which of them produces the device's residue ties:
+ *   bit 0: the cumulative sums over the age axis in the association of the kernel's wave scan (one age class per lane, ages <= 63:
+ *          the shape the small golden cases run in) instead of numpy's running sum;
+ *   bit 1: the sub-step distributions accumulated directly (ttn += tti) instead of diff(cumsum(tti)) accumulated and differenced. */
+static int oc_device_order(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("OC_SAS_DEVICE_ORDER");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+/* inclusive prefix sum over 64 lanes as rh_sas_dev.h wave_scan_sum forms it: row_shr 1, 2, 4, 8 inside rows of 16 lanes, then lane 15
+ * of a row into rows 1 and 3, lane 31 into rows 2 and 3 */
+static void oc_wave_scan(double *v) {
+    double t[64];
+    for (int sh = 1; sh <= 8; sh <<= 1) {
+        for (int i = 0; i < 64; ++i) t[i] = ((i & 15) >= sh ? v[i - sh] : 0.0) + v[i];
+        memcpy(v, t, sizeof(t));
+    }
+    for (int i = 0; i < 64; ++i) t[i] = (((i >> 4) & 1) ? v[(i & ~15) - 1] : 0.0) + v[i];
+    memcpy(v, t, sizeof(t));
+    for (int i = 0; i < 64; ++i) t[i] = ((i >> 5) ? v[31] : 0.0) + v[i];
+    memcpy(v, t, sizeof(t));
+}
 /* SA[0] = 0, SA[1:] = cumsum(sa): transport.py:343-359 */
 static void calc_SA(double *SA, const double *sa, int64_t ages) {
     SA[0] = 0;
+    if ((oc_device_order() & 1) && ages <= 63) {   /* k_sas<1, 1>: hi = (inclusive scan of the lane before) + own value */
+        double w[64];
+        for (int i = 0; i < 64; ++i) w[i] = (i < ages ? sa[i] : 0.0);
+        oc_wave_scan(w);
+        for (int64_t k = 0; k < ages; ++k) SA[k + 1] = (k == 0 ? 0.0 : w[k - 1]) + sa[k];
+        return;
+    }
     double acc = 0;
     for (int64_t k = 0; k < ages; ++k) {
         acc = (k == 0) ? sa[0] : acc + sa[k];
@@ -219,6 +253,11 @@ static void calc_tt(const oc_sas *P, double *tt, const double *SA, const double 
     memcpy(SAn, SA, sizeof(double) * NA);
     memcpy(san, sa, sizeof(double) * A);
     for (int64_t k = 0; k < NA; ++k) TTn[k] = 0;
+    double ttn_direct[4096];
+    if (oc_device_order() & 2) {
+        if (A > 4096) abort();
+        for (int64_t k = 0; k < A; ++k) ttn_direct[k] = 0;
+    }
     const double h = 1.0 / (double)N;
     for (int64_t it = 0; it < N; ++it) {
         sas_omega(TTi, SAn, NA, p, mk);
@@ -234,9 +273,19 @@ static void calc_tt(const oc_sas *P, double *tt, const double *SA, const double 
             SAn[k + 1] = acc;
             cum = (k == 0) ? t : cum + t;
             TTn[k + 1] += cum;
+            if (oc_device_order() & 2) ttn_direct[k] += t;
         }
+        if (oc_device_order() & 1) calc_SA(SAn, san, A);
     }
     for (int64_t k = 0; k < NA; ++k) TT[k] = TTn[k] / (double)N;
+    if (oc_device_order() & 2) {   /* the kernel: tt = ttn / N directly */
+        for (int64_t k = 0; k < A; ++k) {
+            double t = ttn_direct[k] / (double)N;
+            double q = (flux * t > sa[k] ? sa[k] : flux * t);
+            tt[k] = (flux > 0 ? q / flux : 0);
+        }
+        return;
+    }
     for (int64_t k = 0; k < A; ++k) {
         double t = TT[k + 1] - TT[k];
         double q = (flux * t > sa[k] ? sa[k] : flux * t);
