@@ -17,6 +17,7 @@
 // sensitive to still holds exactly: cumulative values are non-decreasing for non-negative input and
 // an empty age class contributes an exact 0 to every difference of cumulative values.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include <cmath>
 #include <cstdlib>
@@ -343,7 +344,25 @@ int rh_sas_stages(rh_sas_ctx *ctx, int64_t day, int stages) {
     // smallest workgroup whose blocked layout covers the ages + 1 edges (rh_sas_kernels.h; the isotope and the anion kernels are
     // translation units of their own, rh_sas_det_iso.hip / rh_sas_det_anion.hip)
     static const bool e4 = std::getenv("RH_SAS_E4") != nullptr;
+#ifdef RH_SAS_PHASES
+    static unsigned long long *d_phases = nullptr;
+    if (!d_phases) (void)hipMalloc((void **)&d_phases, 32 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_phases, 0, 32 * sizeof(unsigned long long), ctx->stream);
+    args.phases = d_phases;
+#endif
     const int lrc = (ctx->cfg.tracer != RH_SAS_TRACER_OXYGEN18 ? rh_sas_launch_det_anion : rh_sas_launch_det_iso)(ctx->stream, args, (unsigned)ctx->cfg.n_cells, c.ages + 1, e4);
+#ifdef RH_SAS_PHASES
+    {
+        unsigned long long h[32];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h, d_phases, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int k = 0; k < 16; ++k) tot += h[k];
+        std::fprintf(stderr, "sas phases, cycles per column (day %lld):", (long long)day);
+        for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d:%.0f", k, (double)h[k] / (double)ctx->cfg.n_cells);
+        std::fprintf(stderr, "  total %.0f\n", (double)tot / (double)ctx->cfg.n_cells);
+    }
+#endif
     if (lrc) return sfail(ctx, lrc, "rh_sas_stages: the age axis does not fit the kernel shapes of this build");
     SHIPCHK(ctx, hipGetLastError());
     if (ctx->timing) SHIPCHK(ctx, hipEventRecord(ev1, ctx->stream));

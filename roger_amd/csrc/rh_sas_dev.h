@@ -170,6 +170,9 @@ struct SasArgs {
     double vsmow, dmin, dmax;
     int *unsupported;  // device flag: a column asked for a SAS family this kernel does not implement
     void *a[SA_COUNT];
+#ifdef RH_SAS_PHASES   // measurement builds: cycles per phase of the day, summed over the columns (thread 0 of every column)
+    unsigned long long *phases;
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -184,7 +187,22 @@ struct Blk {
     double (*xch)[W][2];   // [2][W][2]
     double *park;          // LDS parking area of the eight-class shapes ([2][8][W * 64] doubles), else null
     const double *scal;    // LDS copy of the column's scalars of the day (SasScal), the deterministic kernels only
+#ifdef RH_SAS_PHASES
+    unsigned long long t_last;
+#endif
 };
+#ifdef RH_SAS_PHASES
+#define SAS_PH(B, P, k)                                                              \
+    do {                                                                             \
+        if ((B).tid == 0) {                                                          \
+            const unsigned long long t_ = clock64();                                 \
+            atomicAdd(&(P).phases[k], t_ - (B).t_last);                              \
+            (B).t_last = t_;                                                         \
+        }                                                                            \
+    } while (0)
+#else
+#define SAS_PH(B, P, k) ((void)0)
+#endif
 // The column's scalars of the day -- the five fluxes, the three infiltration terms, the input signal, seven SAS parameters per flux --
 // fetched in ONE batch of independent loads at the start of the kernel and kept in LDS: read where they are needed, each is a dependent
 // round trip to HBM in front of a branch (flux > 0?  which family?), two or three per flux, while both waves of the column wait.
@@ -245,11 +263,11 @@ SAS_DEV double wave_sum(double v) { return lane63(wave_scan_sum(v)); }
 
 // Parking: two age vectors of a thread leave the register file for LDS while the kernel works on the other compartment (the eight-class
 // shapes: the state of a column is 64 registers per thread, the sub-step loop needs only the StorAge it works on).  Every thread reads back
-// what it wrote itself -- no barrier; slot [a][j][tid], so the lanes of a wave touch consecutive words.  Without a parking area (B.park == null:
-// the other shapes) both calls do nothing and the vectors stay in registers.
+// what it wrote itself -- no barrier; slot [a][j][tid], so the lanes of a wave touch consecutive words.  The other shapes (E != 8) have no
+// parking area: both calls do nothing and the vectors stay in registers.
 template <int W, int E>
 SAS_DEV void park2(const Blk<W> &B, const double (&a)[E], const double (&b)[E]) {
-    if (!B.park) return;
+    if (E != 8) return;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         B.park[(0 * E + j) * (W * 64) + B.tid] = a[j];
@@ -258,7 +276,7 @@ SAS_DEV void park2(const Blk<W> &B, const double (&a)[E], const double (&b)[E]) 
 }
 template <int W, int E>
 SAS_DEV void unpark2(const Blk<W> &B, double (&a)[E], double (&b)[E]) {
-    if (!B.park) return;
+    if (E != 8) return;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         a[j] = B.park[(0 * E + j) * (W * 64) + B.tid];
@@ -573,9 +591,29 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
     }
 }
 
+// The SAS families with library calls inside (kumaraswami: two pow per class, exponential, gamma) as a function of their own.  Inlined
+// into the loop over sub-steps and fluxes, the constants of ALL of them would be hoisted out of that loop together and held in
+// registers for the whole kernel (measured: 150 spilled VGPRs with a single age class per thread); the benchmark's power law, the
+// uniform and the dirac family stay inline.  The arrays cross the call through scratch memory, on this path only.
+template <int E>
+__device__ __attribute__((noinline)) void omega_library_families(int fam, const double *pr, const double *SA_hi, double Smax, double mk, int base,
+                                                                  int A, double *Om) {
+    Blk<1> B{};
+    PowConsts C{};
+    double p[7], x[E], o[E], edge0 = 0.0;
+    for (int i = 0; i < 7; ++i) p[i] = pr[i];
+#pragma unroll
+    for (int j = 0; j < E; ++j) x[j] = SA_hi[j];
+    if (fam == FAM_KUMARASWAMI) sas_omega<1, E, FAM_KUMARASWAMI>(B, C, p, x, Smax, mk, base, A, o, edge0);
+    else if (fam == FAM_EXPONENTIAL) sas_omega<1, E, FAM_EXPONENTIAL>(B, C, p, x, Smax, mk, base, A, o, edge0);
+    else sas_omega<1, E, FAM_GAMMA>(B, C, p, x, Smax, mk, base, A, o, edge0);
+#pragma unroll
+    for (int j = 0; j < E; ++j) Om[j] = o[j];
+}
+
 template <int W, int E>
 SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&cdf_hi)[E], double cdf_lo,
-                       const double (&dens)[E], int first_arr, bool skip10_90);
+                       const double (&dens)[E], double *const (&dst6)[6], bool skip10_90);
 // The age statistics of a flux's travel time distribution are formed as soon as the distribution exists when the whole day runs
 // in one launch (they depend on nothing later); keeping tt / TT alive until the storage stage cost 36 registers across four fluxes,
 // which the compiler spilled.  With the stages in launches of their own they come back from the diagnostics arrays (load_dist).
@@ -583,10 +621,10 @@ SAS_DEV bool stats_now(const SasArgs &P) { return P.stats && (P.stages & RH_SAS_
 
 // calc_age_percentile :9-56 for the five percentiles at once + the mean age.
 //   cdf_hi / cdf_lo: cumulative distribution at the upper edges of the thread's classes / lower edge of its first
-//   dens: the distribution itself.  dst: arrays of the 6 statistics; skip10_90: leave rt10 / rt90 unassigned.
+//   dens: the distribution itself.  dst6: arrays of the 6 statistics; skip10_90: leave rt10 / rt90 unassigned.
 template <int W, int E>
 SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&cdf_hi)[E], double cdf_lo,
-                       const double (&dens)[E], int first_arr, bool skip10_90) {
+                       const double (&dens)[E], double *const (&dst6)[6], bool skip10_90) {
     const int A = P.ages;
     const double Q[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
     // number of classes with cdf <= q, per percentile: counted with ballots (a compare per class and percentile, the population
@@ -637,7 +675,7 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         if (skip10_90 && (q == 0 || q == 4)) continue;
-        double *dst = (double *)P.a[first_arr + q] + cell;
+        double *dst = dst6[q] + cell;
         const int cnt = cnt5[q];  // number of classes with cdf <= q; the crossing is in class `cnt`
         if (!(mx > 0)) {
             if (B.tid == 0) *dst = NAN;
@@ -656,7 +694,16 @@ SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, cons
                 }
         }
     }
-    if (B.tid == 0) ((double *)P.a[first_arr + 5])[cell] = (v[0] > 0 ? v[1] : NAN);
+    if (B.tid == 0) dst6[5][cell] = (v[0] > 0 ? v[1] : NAN);
+}
+// ... with the six arrays given by the registry index of the first
+template <int W, int E>
+SAS_DEV void age_stats(Blk<W> &B, const SasArgs &P, int64_t cell, int base, const double (&cdf_hi)[E], double cdf_lo,
+                       const double (&dens)[E], int first_arr, bool skip10_90) {
+    double *dst6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst6[q] = (double *)P.a[first_arr + q];
+    age_stats<W, E>(B, P, cell, base, cdf_hi, cdf_lo, dens, dst6, skip10_90);
 }
 
 template <int W, int E>

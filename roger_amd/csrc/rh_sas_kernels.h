@@ -40,7 +40,10 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
             Smax *= mk;
         }
         double Om[E];
-        sas_omega<W, E, FAM>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
+        if constexpr (FAM == FAM_KUMARASWAMI || FAM == FAM_EXPONENTIAL || FAM == FAM_GAMMA)
+            omega_library_families<E>(FAM, pr, SA_hi, Smax, mk, base, A, Om);   // out of line: rh_sas_dev.h
+        else
+            sas_omega<W, E, FAM>(B, C, pr, SA_hi, Smax, mk, base, A, Om, Om_edge0);
         double Om_lo, unused;
         blk_prev2<W>(B, Om[E - 1], 0.0, Om_edge0, 0.0, Om_lo, unused);
         // Written stage by stage over the thread's classes, not class by class: the E chains are independent, and in the class-by-class
@@ -99,21 +102,35 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
 }
 
 
+// The array of flux f (0 .. 4) out of a group of five consecutive registry entries: a chain of selects over constant indices on the scalar
+// unit (an index computed at run time into the kernel's argument block would move the whole block into scratch memory).
+SAS_DEV double *flux_arr(const SasArgs &P, int first, int f) {
+    void *q = P.a[first];
+    q = (f == 1) ? P.a[first + 1] : q;
+    q = (f == 2) ? P.a[first + 2] : q;
+    q = (f == 3) ? P.a[first + 3] : q;
+    q = (f == 4) ? P.a[first + 4] : q;
+    return (double *)q;
+}
+
 // One outgoing flux: SA, tt, TT, mtt, C, C_iso, the sink's isotope mixing, update_sa.
 // calc_evaporation/transpiration_transport_iso_kernel (core/evapotranspiration.py:653-719, 831-901),
 // calc_percolation_rz/ss_transport_iso_kernel (core/subsurface_runoff.py:1531-1626, 1753-1820),
 // calc_capillary_rise_rz_transport_iso_kernel (core/capillary_rise.py:404-500).
-// sa / msa: the compartment the flux leaves; sa_sink / msa_sink: the OTHER compartment, which receives the water if SINK and is otherwise
-// untouched -- either way it waits in the parking area (park2) while the sub-steps and the statistics run.
-template <int W, int E, bool SINK, bool KEEP>
-SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&sa)[E], double (&msa)[E], double (&sa_sink)[E],
-                     double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
+// sa / msa: the compartment the flux leaves (the ACTIVE one, in registers); sa_o / msa_o: the other compartment, which receives the
+// water if `sink` and is otherwise untouched -- with the eight-class shapes it waits in the parking area (it is parked when this is
+// called and when it returns).  ONE instance serves the five fluxes (the caller's loop over f; sink, keep and the arrays of the flux are
+// run-time values): with an instance per flux the kernel was 540 KB of code and the compiler kept the addresses of five fluxes' outputs
+// alive at once.  keep: the age statistics of the travel time distribution (transpiration, percolation of the subsoil).
+template <int W, int E>
+SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, bool sink, bool keep, double (&sa)[E], double (&msa)[E],
+                     double (&sa_o)[E], double (&msa_o)[E], double mk, int base) {
     const int A = P.ages;
     const double flux = B.scal[SC_FLUX + f];
     const double *p = B.scal + SC_PAR + 7 * f;
     double tt[E];
-    park2<W, E>(B, sa_sink, msa_sink);
     calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
+    SAS_PH(B, P, 2 + 2 * f);
     double mtt[E], s[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -122,14 +139,19 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
         s[0] += mtt[j] * tt[j];
         s[1] += tt[j];
     }
-    if (P.diag || (KEEP && stats_now(P))) {  // TT[1:] = cumsum(tt)
+    if (P.diag || (keep && stats_now(P))) {  // TT[1:] = cumsum(tt)
         double TT_hi[E], TT_lo;
         blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-        if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
+        if (keep && stats_now(P)) {
+            double *dst[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dst[q] = (double *)(f == 1 ? P.a[SA_tt10_transp + q] : P.a[SA_tt10_q_ss + q]);
+            age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, dst, false);
+        }
         if (P.diag) {
-            double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
-            double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
-            double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
+            double *o_tt = flux_arr(P, SA_tt_evap_soil, f) + cell * A;
+            double *o_mtt = flux_arr(P, SA_mtt_evap_soil, f) + cell * A;
+            double *o_TT = flux_arr(P, SA_TT_evap_soil, f) + cell * (A + 1);
             if (B.tid == 0) o_TT[0] = 0.0;
 #pragma unroll
             for (int j = 0; j < E; ++j)
@@ -145,25 +167,28 @@ SAS_DEV void outflux(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double (&
         double conc = (s[1] > 0 ? s[0] / s[1] : NAN);
         conc = (conc != 0 ? conc : NAN);
         const double C = conc * mk;
-        ((double *)P.a[SA_C_evap_soil + f])[cell] = C;
-        ((double *)P.a[SA_C_iso_evap_soil + f])[cell] = conc_to_delta(P, C) * mk;
+        flux_arr(P, SA_C_evap_soil, f)[cell] = C;
+        flux_arr(P, SA_C_iso_evap_soil, f)[cell] = conc_to_delta(P, C) * mk;
     }
-    unpark2<W, E>(B, sa_sink, msa_sink);
+    if (sink) {
+        unpark2<W, E>(B, sa_o, msa_o);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double add = tt[j] * flux;
+            const UDiv by_tot = udiv_prepare(add + sa_o[j]);   // two quotients by one divisor (udiv: the bits of `/`)
+            msa_o[j] = (add + sa_o[j] > 0 ? msa_o[j] * udiv(sa_o[j], by_tot) + mtt[j] * udiv(add, by_tot) : msa_o[j]) * mk;
+            sa_o[j] += tt[j] * flux * mk;
+        }
+        park2<W, E>(B, sa_o, msa_o);
+    }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        if (SINK) {
-            const double add = tt[j] * flux;
-            const UDiv by_tot = udiv_prepare(add + sa_sink[j]);   // two quotients by one divisor (udiv: the bits of `/`)
-            msa_sink[j] = (add + sa_sink[j] > 0
-                               ? msa_sink[j] * udiv(sa_sink[j], by_tot) + mtt[j] * udiv(add, by_tot)
-                               : msa_sink[j]) * mk;
-        }
         double v = sa[j] + -flux * tt[j];  // update_sa :599-619
         v = ((v > -1e-5) && (v < 0)) ? 0 : v;
         sa[j] = v * mk;
-        if (SINK) sa_sink[j] += tt[j] * flux * mk;
         msa[j] = (sa[j] <= 0 ? 0 : msa[j]) * mk;
     }
+    SAS_PH(B, P, 3 + 2 * f);
 }
 
 // Infiltration into age class 0: calc_infiltration_rz_transport_iso_kernel (core/infiltration.py:2218-2346)
@@ -200,46 +225,51 @@ SAS_DEV void inflow(Blk<W> &B, const SasArgs &P, int64_t cell, int which, double
 // ---------------------------------------------------------------------------------------------
 
 // TT = cumsum(tt) for the age statistics (KEEP) and the diagnostics arrays; mtt may be null (soil evaporation)
-template <int W, int E, bool KEEP>
-SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, int base, const double (&tt)[E], const double *mtt,
-                         Dist<E> &keep) {
-    if (!(P.diag || (KEEP && stats_now(P)))) return;
+template <int W, int E>
+SAS_DEV void record_dist(Blk<W> &B, const SasArgs &P, int64_t cell, int f, bool keep, int base, const double (&tt)[E], const double (&mtt)[E],
+                         bool with_mtt) {
+    if (!(P.diag || (keep && stats_now(P)))) return;
     const int A = P.ages;
     double TT_hi[E], TT_lo;
     blk_cumsum<W, E, false>(B, tt, TT_hi, TT_lo, nullptr, base, 0);
-    if (KEEP && stats_now(P)) age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, f == 1 ? SA_tt10_transp : SA_tt10_q_ss, false);
+    if (keep && stats_now(P)) {
+        double *dst[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dst[q] = (double *)(f == 1 ? P.a[SA_tt10_transp + q] : P.a[SA_tt10_q_ss + q]);
+        age_stats<W, E>(B, P, cell, base, TT_hi, TT_lo, tt, dst, false);
+    }
     if (P.diag) {
-        double *o_tt = (double *)P.a[SA_tt_evap_soil + f] + cell * A;
-        double *o_mtt = (double *)P.a[SA_mtt_evap_soil + f] + cell * A;
-        double *o_TT = (double *)P.a[SA_TT_evap_soil + f] + cell * (A + 1);
+        double *o_tt = flux_arr(P, SA_tt_evap_soil, f) + cell * A;
+        double *o_mtt = flux_arr(P, SA_mtt_evap_soil, f) + cell * A;
+        double *o_TT = flux_arr(P, SA_TT_evap_soil, f) + cell * (A + 1);
         if (B.tid == 0) o_TT[0] = 0.0;
 #pragma unroll
         for (int j = 0; j < E; ++j)
             if (base + j < A) {
                 o_tt[base + j] = tt[j];
-                if (mtt) o_mtt[base + j] = mtt[j];
+                if (with_mtt) o_mtt[base + j] = mtt[j];
                 o_TT[base + j + 1] = TT_hi[j];
             }
     }
 }
 
-// One outgoing flux of the anion kernels.  WATER: calc_evaporation_transport_kernel (core/evapotranspiration.py:620-650),
+// One outgoing flux of the anion kernels.  water: calc_evaporation_transport_kernel (core/evapotranspiration.py:620-650),
 // the solute stays behind.  Otherwise calc_transpiration_transport_anion_kernel (:905-985),
 // calc_percolation_rz/ss_transport_anion_kernel (core/subsurface_runoff.py:1630-1716, 1823-1893),
-// calc_capillary_rise_rz_transport_anion_kernel (core/capillary_rise.py:503-590).
-template <int W, int E, bool SINK, bool KEEP, bool WATER>
-SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, double alpha, double (&sa)[E], double (&msa)[E],
-                           double (&sa_sink)[E], double (&msa_sink)[E], double mk, int base, Dist<E> &keep) {
+// calc_capillary_rise_rz_transport_anion_kernel (core/capillary_rise.py:503-590).  One instance for the five fluxes, as outflux above.
+template <int W, int E>
+SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, bool sink, bool keep, bool water, double alpha,
+                           double (&sa)[E], double (&msa)[E], double (&sa_o)[E], double (&msa_o)[E], double mk, int base) {
     const double flux = B.scal[SC_FLUX + f];
     const double *p = B.scal + SC_PAR + 7 * f;
     double tt[E];
-    park2<W, E>(B, sa_sink, msa_sink);   // the other compartment (outflux above)
     calc_tt<W, E>(B, P, p, flux, sa, mk, base, tt);
     double mtt[E], s[1] = {0.0};
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         tt[j] *= mk;
-        if (!WATER) {
+        mtt[j] = 0.0;
+        if (!water) {
             double m = (sa[j] > 0 ? msa[j] / sa[j] : 0) * alpha * tt[j] * flux;
             m = (m <= 0 ? 0 : m);
             m = (m > msa[j] ? msa[j] : m);
@@ -247,25 +277,29 @@ SAS_DEV void outflux_anion(Blk<W> &B, const SasArgs &P, int64_t cell, int f, dou
             s[0] += mtt[j];
         }
     }
-    record_dist<W, E, KEEP>(B, P, cell, f, base, tt, WATER ? nullptr : mtt, keep);
-    if (!WATER) {
+    record_dist<W, E>(B, P, cell, f, keep, base, tt, mtt, !water);
+    if (!water) {
         blk_sum<W, 1>(B, s);
         if (B.tid == 0) {
-            ((double *)P.a[SA_C_evap_soil + f])[cell] = (flux > 0 ? s[0] / flux : 0) * mk;
-            ((double *)P.a[SA_M_evap_soil + f])[cell] = s[0] * mk;
+            flux_arr(P, SA_C_evap_soil, f)[cell] = (flux > 0 ? s[0] / flux : 0) * mk;
+            flux_arr(P, SA_M_evap_soil, f)[cell] = s[0] * mk;
         }
     }
-    unpark2<W, E>(B, sa_sink, msa_sink);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         double v = sa[j] + -flux * tt[j];  // update_sa :599-619
         v = ((v > -1e-5) && (v < 0)) ? 0 : v;
         sa[j] = v * mk;
-        if (!WATER) msa[j] += -mtt[j] * mk;
-        if (SINK) {
-            msa_sink[j] += mtt[j] * mk;
-            sa_sink[j] += tt[j] * flux * mk;
+        if (!water) msa[j] += -mtt[j] * mk;
+    }
+    if (sink) {
+        unpark2<W, E>(B, sa_o, msa_o);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            msa_o[j] += mtt[j] * mk;
+            sa_o[j] += tt[j] * flux * mk;
         }
+        park2<W, E>(B, sa_o, msa_o);
     }
 }
 
@@ -384,6 +418,9 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     }
     __syncthreads();
     Blk<W> B;
+#ifdef RH_SAS_PHASES
+    B.t_last = clock64();
+#endif
     B.scal = s_scal;
     B.park = (E == 8) ? s_park : nullptr;
     B.logt = s_logt;
@@ -398,72 +435,91 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     const int base = B.tid * E;
     const double mk = (double)((const int *)P.a[SA_maskCatch])[cell];
 
-    double sa_rz[E], msa_rz[E], sa_ss[E], msa_ss[E];
+    // ca / cma: the ACTIVE compartment (the one the current flux leaves), co / cmo: the other one -- which, with the eight-class shapes,
+    // waits in the parking area while the fluxes run (its registers are free).  Root zone first (evaporation, transpiration, percolation
+    // into the subsoil), then the compartments change places (subsoil percolation, capillary rise into the root zone).
+    double ca[E], cma[E], co[E], cmo[E];
     {
         const double *g0 = (const double *)P.a[SA_sa_rz] + cell * A, *g1 = (const double *)P.a[SA_msa_rz] + cell * A;
         const double *g2 = (const double *)P.a[SA_sa_ss] + cell * A, *g3 = (const double *)P.a[SA_msa_ss] + cell * A;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const bool in = base + j < A;
-            sa_rz[j] = in ? g0[base + j] : 0.0;
-            msa_rz[j] = in ? g1[base + j] : 0.0;
-            sa_ss[j] = in ? g2[base + j] : 0.0;
-            msa_ss[j] = in ? g3[base + j] : 0.0;
+            ca[j] = in ? g0[base + j] : 0.0;
+            cma[j] = in ? g1[base + j] : 0.0;
+            co[j] = in ? g2[base + j] : 0.0;
+            cmo[j] = in ? g3[base + j] : 0.0;
         }
     }
-    Dist<E> d_transp, d_q_ss;
-    bool have_transp = false, have_q_ss = false;
+    park2<W, E>(B, co, cmo);
+    SAS_PH(B, P, 0);
+    const bool have_transp = P.stages & RH_SAS_TRANSP, have_q_ss = P.stages & RH_SAS_Q_SS;
     const bool stats = P.stats && (P.stages & RH_SAS_STORAGE);
 
-    // order of svat_transport_model_deterministic :949-991
+    // order of svat_transport_model_deterministic :949-991; ONE instance of the flux code, run five times
+    double alpha_q = 0.0;
     if constexpr (ANION) {
-        const double alpha_q = ((const double *)P.a[SA_alpha_q])[cell];
-        if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, sa_rz, msa_rz, mk, base);
-        if (P.stages & RH_SAS_EVAP) {   // water only -- but the virtual tracer leaves with it at alpha = 1
-            if (P.tracer == RH_SAS_TRACER_VIRTUAL)
-                outflux_anion<W, E, false, false, false>(B, P, cell, 0, 1.0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-            else
-                outflux_anion<W, E, false, false, true>(B, P, cell, 0, 0.0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-        }
-        if (P.stages & RH_SAS_TRANSP) {
-            // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
-            const int lu = ((const int *)P.a[SA_lu_id])[cell];
-            double S[1] = {0.0};
-#pragma unroll
-            for (int j = 0; j < E; ++j) S[0] += sa_rz[j];
-            blk_sum<W, 1>(B, S);
-            const bool stop = (lu > 500) && (lu < 599) && (S[0] >= 0.8 * ((const double *)P.a[SA_S_sat_rz])[cell]);
-            const double alpha = (stop ? 0 : ((const double *)P.a[SA_alpha_transp])[cell]) * mk;
-            outflux_anion<W, E, false, true, false>(B, P, cell, 1, alpha, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-            have_transp = true;
-        }
-        if (P.stages & RH_SAS_Q_RZ)
-            outflux_anion<W, E, true, false, false>(B, P, cell, 2, alpha_q, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-        if (P.stages & RH_SAS_INF_SS) inflow_anion<W, E>(B, P, cell, true, sa_ss, msa_ss, mk, base);
-        if (P.stages & RH_SAS_Q_SS) {
-            outflux_anion<W, E, false, true, false>(B, P, cell, 3, alpha_q, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_q_ss);
-            have_q_ss = true;
-        }
-        if (P.stages & RH_SAS_CPR)
-            outflux_anion<W, E, true, false, false>(B, P, cell, 4, alpha_q, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
+        alpha_q = ((const double *)P.a[SA_alpha_q])[cell];
+        if (P.stages & RH_SAS_INF_RZ) inflow_anion<W, E>(B, P, cell, false, ca, cma, mk, base);
     } else {
-    if (P.stages & RH_SAS_INF_RZ) {
-        inflow<W, E>(B, P, cell, 0, sa_rz, msa_rz, mk, base);
-        inflow<W, E>(B, P, cell, 1, sa_rz, msa_rz, mk, base);
+        if (P.stages & RH_SAS_INF_RZ) {
+            inflow<W, E>(B, P, cell, 0, ca, cma, mk, base);
+            inflow<W, E>(B, P, cell, 1, ca, cma, mk, base);
+        }
     }
-    if (P.stages & RH_SAS_EVAP) outflux<W, E, false, false>(B, P, cell, 0, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-    if (P.stages & RH_SAS_TRANSP) {
-        outflux<W, E, false, true>(B, P, cell, 1, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-        have_transp = true;
+    SAS_PH(B, P, 1);
+#pragma nounroll
+    for (int f = 0; f < 5; ++f) {
+        if (f == 3) {   // the subsoil becomes the active compartment
+            if constexpr (E == 8) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    double *s0 = &B.park[(0 * E + j) * (W * 64) + B.tid], *s1 = &B.park[(1 * E + j) * (W * 64) + B.tid];
+                    const double t0 = *s0, t1 = *s1;
+                    *s0 = ca[j];
+                    *s1 = cma[j];
+                    ca[j] = t0;
+                    cma[j] = t1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double t0 = ca[j], t1 = cma[j];
+                    ca[j] = co[j];
+                    cma[j] = cmo[j];
+                    co[j] = t0;
+                    cmo[j] = t1;
+                }
+            }
+            if (P.stages & RH_SAS_INF_SS) {
+                if constexpr (ANION) inflow_anion<W, E>(B, P, cell, true, ca, cma, mk, base);
+                else inflow<W, E>(B, P, cell, 2, ca, cma, mk, base);
+            }
+        }
+        // RH_SAS_EVAP, _TRANSP, _Q_RZ = 1 << (1 + f); RH_SAS_Q_SS, _CPR = 1 << (2 + f)
+        if (!(P.stages & (f < 3 ? (2 << f) : (4 << f)))) continue;
+        const bool sink = (f == 2) || (f == 4), keep = (f == 1) || (f == 3);
+        if constexpr (ANION) {
+            // soil evaporation takes water only -- but the virtual tracer leaves with it at alpha = 1
+            const bool water = (f == 0) && (P.tracer != RH_SAS_TRACER_VIRTUAL);
+            double alpha = (f == 0) ? 1.0 : alpha_q;
+            if (f == 1) {
+                // crop solute uptake stops if the root zone holds more than 80 % of saturation: evapotranspiration.py:932-939
+                const int lu = ((const int *)P.a[SA_lu_id])[cell];
+                double S[1] = {0.0};
+#pragma unroll
+                for (int j = 0; j < E; ++j) S[0] += ca[j];
+                blk_sum<W, 1>(B, S);
+                const bool stop = (lu > 500) && (lu < 599) && (S[0] >= 0.8 * ((const double *)P.a[SA_S_sat_rz])[cell]);
+                alpha = (stop ? 0 : ((const double *)P.a[SA_alpha_transp])[cell]) * mk;
+            }
+            outflux_anion<W, E>(B, P, cell, f, sink, keep, water, alpha, ca, cma, co, cmo, mk, base);
+        } else {
+            outflux<W, E>(B, P, cell, f, sink, keep, ca, cma, co, cmo, mk, base);
+        }
     }
-    if (P.stages & RH_SAS_Q_RZ) outflux<W, E, true, false>(B, P, cell, 2, sa_rz, msa_rz, sa_ss, msa_ss, mk, base, d_transp);
-    if (P.stages & RH_SAS_INF_SS) inflow<W, E>(B, P, cell, 2, sa_ss, msa_ss, mk, base);
-    if (P.stages & RH_SAS_Q_SS) {
-        outflux<W, E, false, true>(B, P, cell, 3, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_q_ss);
-        have_q_ss = true;
-    }
-    if (P.stages & RH_SAS_CPR) outflux<W, E, true, false>(B, P, cell, 4, sa_ss, msa_ss, sa_rz, msa_rz, mk, base, d_transp);
-    }
+    unpark2<W, E>(B, co, cmo);
+    double (&sa_rz)[E] = co, (&msa_rz)[E] = cmo, (&sa_ss)[E] = ca, (&msa_ss)[E] = cma;   // (after the change of places at f == 3)
 
     if (P.stages & RH_SAS_STORAGE) {
         // calc_root_zone_transport_iso_kernel (core/root_zone.py:189-217), calc_subsoil_transport_iso_kernel
@@ -520,6 +576,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
                     o1[base + j] = msa_s[j];
                 }
         }
+        SAS_PH(B, P, 12);
         if (stats) {  // calculate_age_statistics_* :59-312
             // stages run one launch at a time: the distributions come back from the diagnostics arrays
             if (!have_transp) {
@@ -539,6 +596,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
             residence_stats<W, E>(B, P, cell, base, sa_s, mk, SA_rt10_s, false);
             unpark2<W, E>(B, msa_rz, msa_ss);
         }
+        SAS_PH(B, P, 13);
     }
 
     if (P.stages & RH_SAS_RESCALE) {
@@ -635,6 +693,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
                 g3[base + j] = msa_ss[j];
             }
     }
+    SAS_PH(B, P, 14);
 }
 
 

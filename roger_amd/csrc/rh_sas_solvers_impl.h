@@ -41,26 +41,6 @@ SAS_DEV double euler_mix(double msa, double sa, double dsa1, double dmsa1) {
     return ((dsa1 > 0) && (m <= 0)) ? dmsa1 : m;
 }
 
-// The SAS families with library calls inside (kumaraswami: two pow per class, exponential, gamma) as a function of their own.  Inlined
-// into the loop over sub-steps and fluxes, the constants of ALL of them would be hoisted out of that loop together and held in
-// registers for the whole kernel (measured: 150 spilled VGPRs with a single age class per thread); the benchmark's power law, the
-// uniform and the dirac family stay inline.  The arrays cross the call through scratch memory, on this path only.
-template <int E>
-__device__ __attribute__((noinline)) void omega_library_families(int fam, const double *pr, const double *SA_hi, double Smax, double mk, int base,
-                                                                  int A, double *Om) {
-    Blk<1> B{};
-    PowConsts C{};
-    double p[7], x[E], o[E], edge0 = 0.0;
-    for (int i = 0; i < 7; ++i) p[i] = pr[i];
-#pragma unroll
-    for (int j = 0; j < E; ++j) x[j] = SA_hi[j];
-    if (fam == FAM_KUMARASWAMI) sas_omega<1, E, FAM_KUMARASWAMI>(B, C, p, x, Smax, mk, base, A, o, edge0);
-    else if (fam == FAM_EXPONENTIAL) sas_omega<1, E, FAM_EXPONENTIAL>(B, C, p, x, Smax, mk, base, A, o, edge0);
-    else sas_omega<1, E, FAM_GAMMA>(B, C, p, x, Smax, mk, base, A, o, edge0);
-#pragma unroll
-    for (int j = 0; j < E; ++j) Om[j] = o[j];
-}
-
 // tt of one flux on the cumulative StorAge of its source: calc_TT_num + calc_TT_num_nonneg + the clipped differences (:2187-2199).
 //   SA_hi: cumulative StorAge (masked) at the upper edges of the thread's classes; sa: its differences, diff(SA) (one_flux)
 template <int W, int E>
