@@ -65,6 +65,15 @@ SAS_DEV double sqrt_unit(double r) {
     return __builtin_fma(__builtin_fma(-g, g, r), h, g);
 }
 
+// min(a, b) as the one instruction it is.  fmin() makes the compiler quiet a possible signalling NaN in an operand that comes straight from
+// memory (a v_max_f64 x, x in front of every v_min_f64 of the sub-step loop); the age vectors hold no signalling NaNs -- every value was
+// produced by arithmetic, the NaN markers of empty classes are quiet.
+SAS_DEV double min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
 // operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
 #include "rh_sas_tables.inc"
@@ -379,10 +388,10 @@ SAS_DEV void blk_cumsum(Blk<W> &B, const double (&v)[E], double (&hi)[E], double
         ktop = wave_max(kmine);
         utop = wave_max(kmine == ktop && ktop >= 0 ? umine : -INFINITY);  // exactly one lane holds class ktop
     } else if (ptop) {
-        const int top_thread = top_k / E, top_j = top_k % E;  // uniform
-        double mine = u[0];
-#pragma unroll
-        for (int j = 1; j < E; ++j) mine = (j == top_j) ? u[j] : mine;
+        // (the classes above top_k = ages - 1 hold exact zeros -- padding, which no flux can fill --, so inside the thread that owns top_k
+        //  the running sum repeats itself bit for bit from there on: its LAST value is the value at top_k, no selection by top_k % E)
+        const int top_thread = top_k / E;  // uniform
+        const double mine = u[E - 1];
         const unsigned long long b = __double_as_longlong(mine);
         const int src = top_thread & 63;
         const unsigned lo32 = __builtin_amdgcn_readlane((int)(unsigned)b, src), hi32 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
@@ -522,11 +531,11 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = r[j] * sqrt_unit(r[j]);
             }
+            // where(x > 0, where(x <= S, v, 1), 0) without a compare: x <= 0 leaves a NaN (0 * inf from the reciprocal square root) or, with
+            // exponent 1, a quotient <= 0, and max(., 0) returns the 0 (maxNum: the operand that is a number); v > 1 exactly where x > S.
+            // (. * mk) * mk == . * mk bit for bit: the mask is 0 or 1 (the reference's maskCatch is a bool; sas_body normalises it)
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const double o = (SA_hi[j] > 0 ? fmin(r[j], 1.) : 0.) * 1.0 * mk;   // x <= S ? v : 1, and v > 1 exactly where x > S
-                Om[j] = o * mk;
-            }
+            for (int j = 0; j < E; ++j) Om[j] = fmin(fmax(r[j], 0.), 1.) * mk;
         } else {
         const double log2S = sas_log2(C, S);
 #pragma unroll
@@ -535,8 +544,7 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
             // evaluated for every class and selected afterwards: straight-line code lets the E independent
             // evaluations interleave (a NaN from x <= 0 is discarded by the select)
             const double v = sas_pow_ratio(C, x, S, log2S, k);
-            const double o = (x > 0 ? (x <= S ? v : 1.) : 0.) * 1.0 * mk;
-            Om[j] = o * mk;
+            Om[j] = (x > 0 ? (x <= S ? v : 1.) : 0.) * mk;   // ((. * 1.0 * mk) * mk: the mask is 0 or 1)
         }
         }
     } else if (dirac) {  // piston flow, sas.py:43-64: the edge index (vs.nages) against the age threshold p1

@@ -54,7 +54,7 @@ SAS_DEV void calc_tt_family(Blk<W> &B, const SasArgs &P, const double *p, double
 #pragma unroll
         for (int j = 0; j < E; ++j) tq[j] = flux * tq[j];
 #pragma unroll
-        for (int j = 0; j < E; ++j) tq[j] = fmin(tq[j] * h, san[j]);                            // :435-438  where(flux t h > san, san, flux t h)
+        for (int j = 0; j < E; ++j) tq[j] = min_raw(tq[j] * h, san[j]);                            // :435-438  where(flux t h > san, san, flux t h)
 #pragma unroll
         for (int j = 0; j < E; ++j) tti[j] = tq[j] * by_fh.r;                                   // :440-443: q / (flux * h), fh > 0 here
 #pragma unroll
@@ -433,7 +433,8 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
-    const double mk = (double)((const int *)P.a[SA_maskCatch])[cell];
+    // the catchment mask: a bool in the reference (variables.py:462-470) -- 0 or 1, which makes (x * mk) * mk == x * mk exactly
+    const double mk = ((const int *)P.a[SA_maskCatch])[cell] != 0 ? 1.0 : 0.0;
 
     // ca / cma: the ACTIVE compartment (the one the current flux leaves), co / cmo: the other one -- which, with the eight-class shapes,
     // waits in the parking area while the fluxes run (its registers are free).  Root zone first (evaporation, transpiration, percolation

@@ -578,7 +578,7 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
-    const double mk = (double)((const int *)P.a[SA_maskCatch])[cell];
+    const double mk = ((const int *)P.a[SA_maskCatch])[cell] != 0 ? 1.0 : 0.0;   // a bool in the reference: 0 or 1 (sas_omega relies on it)
 
     double sa_rz[E], msa_rz[E], sa_ss[E], msa_ss[E];
     {
