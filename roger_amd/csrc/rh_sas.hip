@@ -58,7 +58,11 @@ __global__ void k_selftest_pow(const double *x, const double *k, double *out, in
     if (k[i] == 0.5) out[i] = sqrt_unit(x[i]);
     else if (k[i] == 1.5) out[i] = x[i] * sqrt_unit(x[i]);
     else if (k[i] == 1.0) out[i] = x[i];
-    else out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
+    else if (k[i] == 0.2) {   // the fifth-root path with its range check
+        int e2;
+        const double y = pow_fifth(x[i], &e2);
+        out[i] = (e2 < -126) ? sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]) : y;
+    } else out[i] = sas_pow_ratio(C, x[i], 1.0, 0.0, k[i]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -74,6 +74,32 @@ SAS_DEV double min_raw(double a, double b) {
     return r;
 }
 
+// r ** 0.2 for r in [2^-127, 1] (below, the single-precision log2 r is too coarse a start: 2^-17 absolute at 2^-128) -- the quotient SA / S under the benchmark's exponent of soil evaporation and capillary rise
+// (benchmarks/SVATOXYGEN18_benchmark.py:129-132) -- as a fifth root: 31 instructions instead of the 46 of exp2(k * log2 .), and within
+// 0.52 ulp of the true power where that path is 5 - 10 ulp wide.
+//   y0 = 2^(0.2 log2 r) in single precision (v_log_f32 / v_exp_f32: 20 bits);
+//   ONE Halley step on y^5 = r,  y1 = y0 + y0 (r - y0^5) / (3 y0^5 + 2 r)  (cubic: 20 -> 60 bits), with y0^5 as a double-double product
+//   so that the residual r - y0^5 (5e-6 r) keeps twelve digits;
+//   the exponent is the DOUBLE 0.2 = 1/5 + 1.11e-17, not 1/5: r^0.2 = r^(1/5) (1 + 1.11e-17 ln r), which is up to an ulp for small r and is
+//   added to the correction before the one final rounding.
+// r == 1 gives exactly 1.  *e2 = the binary exponent of r (the caller's range check); r <= 0 or NaN give NaN or garbage, clipped by the caller.
+SAS_DEV double pow_fifth(double r, int *e2) {
+    const int e = __builtin_amdgcn_frexp_exp(r);
+    const float mf = (float)__builtin_amdgcn_frexp_mant(r);          // [0.5, 1)
+    const float L = __builtin_amdgcn_logf(mf) + (float)e;            // log2 r
+    const double y0 = (double)__builtin_amdgcn_exp2f(0.2f * L);
+    const double p2h = y0 * y0, p2l = __builtin_fma(y0, y0, -p2h);
+    const double p4h = p2h * p2h, p4l = __builtin_fma(p2h + p2h, p2l, __builtin_fma(p2h, p2h, -p4h));
+    const double p5h = p4h * y0, p5l = __builtin_fma(p4l, y0, __builtin_fma(p4h, y0, -p5h));
+    const double d = (r - p5h) - p5l;                                // r - y0^5 (the first difference is exact)
+    const double den = __builtin_fma(3.0, p5h, r + r);
+    double rc = __builtin_amdgcn_rcp(den);                            // (v_rcp_f64 holds single precision: one Newton step, the correction
+    rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);        //  needs twelve digits)
+    const double c2 = (double)L * 7.6954795931166195e-18;            // (0.2 - 1/5) * ln 2 * log2 r
+    *e2 = e;
+    return y0 + __builtin_fma(y0, c2, (y0 * d) * rc);
+}
+
 // Polynomial coefficients live in constant memory so that they reach the FMAs as scalar-register
 // operands (one v_fma_f64 per Horner step); as immediates each step costs a 64-bit v_mov besides.
 #include "rh_sas_tables.inc"
@@ -513,7 +539,7 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
         // (benchmarks/SVATOXYGEN18_benchmark.py:129-138) -- go through a correctly rounded square root of the true quotient
         // SA / S (exactly 1 at the top edge, as in the reference's (SA / S) ** k) instead of exp2(k * log2 .).  The exponent
         // and S are uniform over the column, so the variants are branches of the whole workgroup, not selects per class.
-        const int kmode = (k == 0.5) ? 1 : ((k == 1.5) ? 2 : ((k == 1.0) ? 3 : 0));
+        const int kmode = (k == 0.5) ? 1 : ((k == 1.5) ? 2 : ((k == 1.0) ? 3 : ((k == 0.2) ? 4 : 0)));
         if (S <= 0) {   // Omega = where(S <= 0, 0, .): nothing to evaluate
 #pragma unroll
             for (int j = 0; j < E; ++j) Om[j] = 0.0 * mk;
@@ -530,6 +556,22 @@ SAS_DEV void sas_omega(Blk<W> &B, const PowConsts &C, const double (&p)[7], cons
             } else if (kmode == 2) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = r[j] * sqrt_unit(r[j]);
+            } else if (kmode == 4) {
+                double y[E];
+                bool tiny = false;   // a quotient in (0, 2^-127): below the range of the fifth-root path (the residue of a residue; residues are ~1e-20)
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    int e2;
+                    y[j] = pow_fifth(r[j], &e2);
+                    tiny |= e2 < -126;
+                }
+                if (__builtin_expect(__ballot(tiny) != 0, 0)) {
+                    const double log2S = sas_log2(C, S);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) y[j] = SA_hi[j] > 0 ? sas_pow_ratio(C, SA_hi[j], S, log2S, k) : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = y[j];
             }
             // where(x > 0, where(x <= S, v, 1), 0) without a compare: x <= 0 leaves a NaN (0 * inf from the reciprocal square root) or, with
             // exponent 1, a quotient <= 0, and max(., 0) returns the 0 (maxNum: the operand that is a number); v > 1 exactly where x > S.
