@@ -1,6 +1,6 @@
 // placement_probe.hip -- which access shape of the arena is insensitive to where hipMalloc put it?
 //   hipcc --offload-arch=gfx950 -O3 tools/experiments/placement_probe.hip -o gpurun_out/placement_probe
-//   placement_probe [arenas=8] [alloc=malloc|contig|carve] [slots=267]
+//   placement_probe [arenas=8] [alloc=malloc|contig|carve|mimic|fine|uncached|managed] [slots=267]
 // K arenas of the product's size (10^6 columns x `slots` 512-byte slots) are allocated one after the other in one process (the
 // staircase of tools/arena_levels.py: the first few allocations are fast, the rest sit on a plateau).  On EVERY arena the same
 // bytes (96 planes read + 96 planes written per column, k_calib_copy's shape) are moved with different address shapes:
@@ -88,6 +88,9 @@ int main(int argc, char **argv) {
     for (int k = 0; k < K; ++k) {
         if (big) arena[k] = big + (size_t)k * ((bytes + (2 << 20) - 1) / (2 << 20) * (2 << 20));
         else if (!strcmp(alloc, "contig")) CHK(hipExtMallocWithFlags((void **)&arena[k], bytes, hipDeviceMallocContiguous));
+        else if (!strcmp(alloc, "fine")) CHK(hipExtMallocWithFlags((void **)&arena[k], bytes, hipDeviceMallocFinegrained));
+        else if (!strcmp(alloc, "uncached")) CHK(hipExtMallocWithFlags((void **)&arena[k], bytes, hipDeviceMallocUncached));
+        else if (!strcmp(alloc, "managed")) CHK(hipMallocManaged((void **)&arena[k], bytes));
         else if (!strcmp(alloc, "mimic")) {   // rh_create's sequence: a stream, the arena (the product's exact size), a staging plane, the control block
             hipStream_t st; void *stage, *dev;
             CHK(hipStreamCreate(&st));
