@@ -221,7 +221,7 @@ struct Blk {
     double (*red)[W][8];   // [2][W][8]
     double (*xch)[W][2];   // [2][W][2]
     double *park;          // LDS parking area of the eight-class shapes ([2][8][W * 64] doubles), else null
-    const double *scal;    // LDS copy of the column's scalars of the day (SasScal), the deterministic kernels only
+    const double *scal;    // LDS copy of the column's scalars of the day (SasScal)
 #ifdef RH_SAS_PHASES
     unsigned long long t_last;
 #endif
@@ -242,6 +242,24 @@ struct Blk {
 // fetched in ONE batch of independent loads at the start of the kernel and kept in LDS: read where they are needed, each is a dependent
 // round trip to HBM in front of a branch (flux > 0?  which family?), two or three per flux, while both waves of the column wait.
 enum SasScal { SC_FLUX = 0, SC_INF = 5, SC_CIN = 8, SC_PAR = 9, SC_COUNT = SC_PAR + 5 * 7 };
+// fills the LDS copy of the column's scalars (SasScal): independent loads, one wait; the caller's barrier publishes it
+SAS_DEV void sas_load_scalars(const SasArgs &P, double *s_scal) {
+    const int64_t c = blockIdx.x, dc = P.day_off + c;
+    double v[SC_COUNT];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) v[SC_FLUX + f] = ((const double *)P.a[SA_evap_soil + f])[dc];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[SC_INF + k] = ((const double *)P.a[SA_inf_mat_rz + k])[dc];
+    v[SC_CIN] = ((const double *)P.a[SA_C_in])[dc];
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[SC_PAR + 7 * f + i] = ((const double *)P.a[SA_sas_params_evap_soil + f])[c * 8 + i];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < SC_COUNT; ++k) s_scal[k] = v[k];
+    }
+}
 
 // Cross-lane moves as DPP (data-parallel primitive) modifiers on VALU moves instead of LDS-crossbar
 // shuffles: a DPP move costs one VALU issue, a ds_bpermute a round trip through the LDS pipeline, and

@@ -399,23 +399,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_park[E == 8 ? 2 * 8 * W * 64 : 1];   // two age vectors per thread (park2): the eight-class shapes only
     __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
-    {   // the column's scalars of the day (SasScal): independent loads, one wait
-        const int64_t c = blockIdx.x, dc = P.day_off + c;
-        double v[SC_COUNT];
-#pragma unroll
-        for (int f = 0; f < 5; ++f) v[SC_FLUX + f] = ((const double *)P.a[SA_evap_soil + f])[dc];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[SC_INF + k] = ((const double *)P.a[SA_inf_mat_rz + k])[dc];
-        v[SC_CIN] = ((const double *)P.a[SA_C_in])[dc];
-#pragma unroll
-        for (int f = 0; f < 5; ++f)
-#pragma unroll
-            for (int i = 0; i < 7; ++i) v[SC_PAR + 7 * f + i] = ((const double *)P.a[SA_sas_params_evap_soil + f])[c * 8 + i];
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < SC_COUNT; ++k) s_scal[k] = v[k];
-        }
-    }
+    sas_load_scalars(P, s_scal);
     __syncthreads();
     Blk<W> B;
 #ifdef RH_SAS_PHASES

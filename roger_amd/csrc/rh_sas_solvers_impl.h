@@ -349,8 +349,8 @@ SAS_DEV double one_flux(Blk<W> &B, const SasArgs &P, int64_t cell, int base, int
             S_top = blk_max<W>(B, mx);
         }
     }
-    const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
-    const double *p = (const double *)arr5(P, SA_sas_params_evap_soil, f) + cell * 8;
+    const double flux = B.scal[SC_FLUX + f];          // (the column's scalars of the day wait in LDS: sas_load_scalars)
+    const double *p = B.scal + SC_PAR + 7 * f;
     euler_tt<W, E>(B, P, p, halve ? flux * scale / 2 : flux * scale, SA, sa_src, S_top, mk, base, masked, tt);
     return flux;
 }
@@ -483,7 +483,7 @@ SAS_DEV void explicit_substep(Blk<W> &B, const SasArgs &P, int64_t cell, int bas
         }
 #pragma unroll 1
         for (int f = 0; f < 5; ++f) {
-            const double flux = ((const double *)arr5(P, SA_evap_soil, f))[P.day_off + cell];
+            const double flux = B.scal[SC_FLUX + f];
             double tt[E], mtt[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) tt[j] = get5<E>(f, j, FIVE_ARGS(acc)) / 6.;
@@ -563,7 +563,9 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     __shared__ double2 s_logt[64];
+    __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
+    sas_load_scalars(P, s_scal);
     __syncthreads();
     Blk<W> B;
     B.logt = s_logt;
@@ -574,7 +576,7 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     B.red = s_red;
     B.xch = s_xch;
     B.park = nullptr;
-    B.scal = nullptr;
+    B.scal = s_scal;
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
@@ -594,8 +596,7 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
         }
     }
     const double h = 1 / (double)P.substeps;   // settings.h (benchmarks/SVATOXYGEN18_benchmark.py:30-31)
-    const double im = ((const double *)P.a[SA_inf_mat_rz])[P.day_off + cell], ip = ((const double *)P.a[SA_inf_pf_rz])[P.day_off + cell];
-    const double is = ((const double *)P.a[SA_inf_pf_ss])[P.day_off + cell], C_in = ((const double *)P.a[SA_C_in])[P.day_off + cell];
+    const double im = B.scal[SC_INF + 0], ip = B.scal[SC_INF + 1], is = B.scal[SC_INF + 2], C_in = B.scal[SC_CIN];
 
     for (int it = 0; it + 1 < P.substeps; ++it)
         explicit_substep<W, E, false, RK4, ANION>(B, P, cell, base, h, mk, im, ip, is, C_in, sa_rz, msa_rz, sa_ss, msa_ss);
