@@ -38,8 +38,12 @@ struct Col {
 #endif
 // RH_TILE_CELLS: columns per tile, 64 (a wavefront's) or a multiple of it up to the workgroup's 256 -- then a plane's slot holds the
 // columns of 2 or 4 consecutive wavefronts of a workgroup (1 / 2 KiB contiguous per plane and workgroup instead of 512-byte pieces).
+// 256 since the end of round 3: with the kernel's arithmetic cut by rh_pow the longer pieces show a little -- alternating with the 64-column
+// library inside one call, SVAT 10^6 columns 0.2143 -> 0.2065 and 0.2192 -> 0.2118 ms (medians of 3 and 4 pairs), 10^7 columns 1.959 -> 1.942
+// and 1.991 -> 1.962 ms, oneD alike; the driver's 20-step command and the 80 x 53 grid within +- 1 %, the routed step 3 % slower (0.396 ->
+// 0.408 ms).  With the library's pow the three sizes were within the noise.  The whole GPU suite runs on either.
 #ifndef RH_TILE_CELLS
-#define RH_TILE_CELLS 64
+#define RH_TILE_CELLS 256
 #endif
 #define RH_TILE_SHIFT (RH_TILE_CELLS == 64 ? 6 : (RH_TILE_CELLS == 128 ? 7 : 8))
 #define RH_SLOT_BYTES (RH_TILE_CELLS * 8)

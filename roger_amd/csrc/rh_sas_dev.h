@@ -320,7 +320,7 @@ SAS_DEV double wave_sum(double v) { return lane63(wave_scan_sum(v)); }
 // parking area: both calls do nothing and the vectors stay in registers.
 template <int W, int E>
 SAS_DEV void park2(const Blk<W> &B, const double (&a)[E], const double (&b)[E]) {
-    if (E != 8) return;
+    if (E < 8) return;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         B.park[(0 * E + j) * (W * 64) + B.tid] = a[j];
@@ -329,7 +329,7 @@ SAS_DEV void park2(const Blk<W> &B, const double (&a)[E], const double (&b)[E]) 
 }
 template <int W, int E>
 SAS_DEV void unpark2(const Blk<W> &B, double (&a)[E], double (&b)[E]) {
-    if (E != 8) return;
+    if (E < 8) return;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         a[j] = B.park[(0 * E + j) * (W * 64) + B.tid];

@@ -386,7 +386,10 @@ __global__ __launch_bounds__(W * 64) SAS_OCCUPANCY_E8 void k_sas8(const SasArgs 
 // Sixteen age classes per thread, ONE wavefront per column (ages <= 1023): no workgroup barrier and no exchange through LDS at all, the
 // scans are the wave's DPP scan plus a running sum over the thread's own classes; the state of a column then takes the register file of
 // a whole SIMD (1 wave/SIMD, 512 registers: VGPRs + AGPRs).  -DRH_SAS_EXPERIMENT_E16 builds ONLY this shape (experiments).
-#define SAS_OCCUPANCY_E16 __attribute__((amdgpu_waves_per_eu(1, 1)))
+#ifndef RH_SAS_E16_WAVES
+#define RH_SAS_E16_WAVES 1
+#endif
+#define SAS_OCCUPANCY_E16 __attribute__((amdgpu_waves_per_eu(RH_SAS_E16_WAVES, RH_SAS_E16_WAVES)))
 template <bool ANION>
 __global__ __launch_bounds__(64) SAS_OCCUPANCY_E16 void k_sas16(const SasArgs P) {
     sas_body<1, 16, ANION>(P);
@@ -396,7 +399,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_red[2][W][8];
     __shared__ double s_xch[2][W][2];
     __shared__ double2 s_logt[64];
-    __shared__ double s_park[E == 8 ? 2 * 8 * W * 64 : 1];   // two age vectors per thread (park2): the eight-class shapes only
+    __shared__ double s_park[E >= 8 ? 2 * E * W * 64 : 1];   // two age vectors per thread (park2): the shapes with eight classes per thread or more
     __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
     sas_load_scalars(P, s_scal);
@@ -406,7 +409,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     B.t_last = clock64();
 #endif
     B.scal = s_scal;
-    B.park = (E == 8) ? s_park : nullptr;
+    B.park = (E >= 8) ? s_park : nullptr;
     B.logt = s_logt;
     B.tid = threadIdx.x;
     B.lane = threadIdx.x & 63;
@@ -456,7 +459,7 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
 #pragma nounroll
     for (int f = 0; f < 5; ++f) {
         if (f == 3) {   // the subsoil becomes the active compartment
-            if constexpr (E == 8) {
+            if constexpr (E >= 8) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     double *s0 = &B.park[(0 * E + j) * (W * 64) + B.tid], *s1 = &B.park[(1 * E + j) * (W * 64) + B.tid];
