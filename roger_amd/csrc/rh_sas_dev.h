@@ -242,10 +242,11 @@ struct Blk {
 // fetched in ONE batch of independent loads at the start of the kernel and kept in LDS: read where they are needed, each is a dependent
 // round trip to HBM in front of a branch (flux > 0?  which family?), two or three per flux, while both waves of the column wait.
 enum SasScal { SC_FLUX = 0, SC_INF = 5, SC_CIN = 8, SC_PAR = 9, SC_COUNT = SC_PAR + 5 * 7 };
-// fills the LDS copy of the column's scalars (SasScal): independent loads, one wait; the caller's barrier publishes it
-SAS_DEV void sas_load_scalars(const SasArgs &P, double *s_scal) {
+// the column's scalars (SasScal) in two parts, so that the loads of the column's state can be requested in between and both round trips
+// to HBM overlap: sas_fetch_scalars requests them (independent loads), sas_publish_scalars stores them to LDS; the caller's barrier
+// makes them visible
+SAS_DEV void sas_fetch_scalars(const SasArgs &P, double (&v)[SC_COUNT]) {
     const int64_t c = blockIdx.x, dc = P.day_off + c;
-    double v[SC_COUNT];
 #pragma unroll
     for (int f = 0; f < 5; ++f) v[SC_FLUX + f] = ((const double *)P.a[SA_evap_soil + f])[dc];
 #pragma unroll
@@ -255,6 +256,8 @@ SAS_DEV void sas_load_scalars(const SasArgs &P, double *s_scal) {
     for (int f = 0; f < 5; ++f)
 #pragma unroll
         for (int i = 0; i < 7; ++i) v[SC_PAR + 7 * f + i] = ((const double *)P.a[SA_sas_params_evap_soil + f])[c * 8 + i];
+}
+SAS_DEV void sas_publish_scalars(const double (&v)[SC_COUNT], double *s_scal) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < SC_COUNT; ++k) s_scal[k] = v[k];

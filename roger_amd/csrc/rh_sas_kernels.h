@@ -402,8 +402,6 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     __shared__ double s_park[E >= 8 ? 2 * E * W * 64 : 1];   // two age vectors per thread (park2): the shapes with eight classes per thread or more
     __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
-    sas_load_scalars(P, s_scal);
-    __syncthreads();
     Blk<W> B;
 #ifdef RH_SAS_PHASES
     B.t_last = clock64();
@@ -420,6 +418,9 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
+    // the column's scalars and its state are requested together (one round trip to HBM, not two), the scalars go to LDS behind it
+    double scal_regs[SC_COUNT];
+    sas_fetch_scalars(P, scal_regs);
     // the catchment mask: a bool in the reference (variables.py:462-470) -- 0 or 1, which makes (x * mk) * mk == x * mk exactly
     const double mk = ((const int *)P.a[SA_maskCatch])[cell] != 0 ? 1.0 : 0.0;
 
@@ -439,6 +440,8 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
             cmo[j] = in ? g3[base + j] : 0.0;
         }
     }
+    sas_publish_scalars(scal_regs, s_scal);
+    __syncthreads();
     park2<W, E>(B, co, cmo);
     SAS_PH(B, P, 0);
     const bool have_transp = P.stages & RH_SAS_TRANSP, have_q_ss = P.stages & RH_SAS_Q_SS;

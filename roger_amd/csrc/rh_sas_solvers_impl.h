@@ -565,8 +565,6 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     __shared__ double2 s_logt[64];
     __shared__ double s_scal[SC_COUNT];
     if (threadIdx.x < 64) s_logt[threadIdx.x] = SAS_LOG_T[threadIdx.x];
-    sas_load_scalars(P, s_scal);
-    __syncthreads();
     Blk<W> B;
     B.logt = s_logt;
     B.tid = threadIdx.x;
@@ -580,6 +578,8 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
     const int64_t cell = blockIdx.x;
     const int A = P.ages;
     const int base = B.tid * E;
+    double scal_regs[SC_COUNT];        // the column's scalars and its state are requested together, the scalars go to LDS behind it
+    sas_fetch_scalars(P, scal_regs);
     const double mk = ((const int *)P.a[SA_maskCatch])[cell] != 0 ? 1.0 : 0.0;   // a bool in the reference: 0 or 1 (sas_omega relies on it)
 
     double sa_rz[E], msa_rz[E], sa_ss[E], msa_ss[E];
@@ -595,6 +595,8 @@ __device__ __forceinline__ void explicit_body(const SasArgs &P) {
             msa_ss[j] = in ? g3[base + j] : 0.0;
         }
     }
+    sas_publish_scalars(scal_regs, s_scal);
+    __syncthreads();
     const double h = 1 / (double)P.substeps;   // settings.h (benchmarks/SVATOXYGEN18_benchmark.py:30-31)
     const double im = B.scal[SC_INF + 0], ip = B.scal[SC_INF + 1], is = B.scal[SC_INF + 2], C_in = B.scal[SC_CIN];
 
