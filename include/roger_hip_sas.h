@@ -38,7 +38,8 @@
  * rh_sas_last_error for the text, one context = one HIP device + one stream, asynchronous
  * launches fenced by rh_sas_sync / rh_sas_download.
  *
- * Data layout.  All arrays are float64 (maskCatch: int32) over the rank's interior cells in C
+ * Data layout.  All arrays are float64 (maskCatch: int32, read as the reference's bool -- roger/variables.py:462-470 --: any non-zero
+ * value is 1) over the rank's interior cells in C
  * order (x, y); age-resolved arrays are (n_cells, ages) / (n_cells, ages + 1) with the age axis
  * contiguous, exactly the reference's `vs.sa_rz[2:-2, 2:-2, vs.tau, :]` etc., so that one
  * workgroup streams one column's age vector with unit stride.  Only the prognostic state
