@@ -1837,9 +1837,17 @@ static RcclApi *rccl_api() {
     static RcclApi api = [] {
         RcclApi a{};
         void *h = nullptr;
+        // RH_RCCL_LIB: this RCCL build and no other (a site's own build; tests/loopback_nccl.cpp, whose "ranks" are threads on one GPU)
+        if (const char *own = std::getenv("RH_RCCL_LIB")) {
+            h = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                a.why = std::string("RH_RCCL_LIB: ") + (dlerror() ? dlerror() : "cannot be loaded");
+                return a;
+            }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!h) {
             a.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
