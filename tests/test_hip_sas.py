@@ -204,6 +204,59 @@ def test_random_columns_against_oracle(n, ages, substeps, stats):
     ctx.close()
 
 
+def test_fifth_root_fallback_inside_the_kernel():
+    """The benchmark's exponents with quotients SA / S below the fifth-root path's range (2^-127): the youngest classes hold 1e-45 mm
+    (the residue of a residue), nothing infiltrates, so Omega's first arguments under soil evaporation (k = 0.2) are ~1e-47 and the
+    wave that owns them takes the general path for its classes (the ballot in sas_omega) -- in the benchmark's shape (k_sas8<2>) and in a
+    four-class shape.  Against the oracle: no NaN or garbage, every column within the loose bound of a residue tie, most at 1e-10."""
+    for n, ages in ((48, 1000), (48, 200)):
+        st = random_problem(n, ages, 6, seed=7 + ages, stats=True)
+        for f, k in zip(FLUXES, (0.2, 0.5, 1.5, 1.5, 0.2)):   # SVATOXYGEN18_benchmark.py:129-138
+            st.sas[f][:, 0] = 6
+            st.sas[f][:, 1] = k
+        tiny = np.arange(n) % 2 == 0
+        for key, v in (("rz", 1e-45), ("ss", 1e-50)):
+            st.state[f"sa_{key}"][tiny, 0] = v
+            st.state[f"sa_{key}"][tiny, 1] = v * 3
+            st.state[f"msa_{key}"][tiny, 0:2] = 0.00199
+        for k in ("inf_mat_rz", "inf_pf_rz", "inf_pf_ss"):
+            st.inp[k][:] = 0.0
+        st.inp["evap_soil"][:] = 0.4 + 0.01 * np.arange(n)
+        st.inp["cpr_rz"][:] = 0.2
+        st.maskCatch[:] = 1
+        ref = clone(st)
+        ctx = make_ctx(st)
+        push(ctx, st)
+        ctx.step(0)
+        pull(ctx, st)
+        ref.step_oracle()
+        bad = np.zeros(n, bool)
+        for k in list(st.out) + list(st.state):
+            a = st.out[k] if k in st.out else st.state[k]
+            b = ref.out[k] if k in ref.out else ref.state[k]
+            if k.startswith("msa"):
+                w = (ref.out["sa_s"] if k == "msa_s" else ref.state["sa" + k[3:]]) > 0
+                a, b = np.where(w, a, 0), np.where(w, b, 0)
+            if k.startswith("mtt"):
+                a, b = a * st.out["tt" + k[3:]], b * ref.out["tt" + k[3:]]
+            is_stat = k[:2] in ("tt", "rt") and a.ndim == 1
+            ok = np.isclose(a, b, rtol=1e-9 if is_stat else 1e-10, atol=1e-12, equal_nan=True)
+            lo = 0.05 if is_stat else 5e-3
+            loose = np.isclose(a, b, rtol=lo, atol=lo, equal_nan=True)
+            if k.startswith("C_") or is_stat:
+                loose |= np.isnan(a) ^ np.isnan(b)
+            if k in TIE_WIPED:
+                loose[:] = True
+            assert loose.all(), f"ages {ages} {k}: max dev {np.nanmax(np.abs(a - b))}"
+            assert np.isfinite(a[np.isfinite(b)]).all(), f"ages {ages} {k}: NaN / inf where the oracle has a number"
+            bad |= ~(ok.reshape(n, -1).all(axis=1))
+        print(f"TIES fifth-root fallback ages {ages}: {int(bad.sum())} of {n} columns ({int((bad & tiny).sum())} among the tiny ones)")
+        # (every column evaporates from young classes that nothing refills: emptied classes, hence residue ties, are frequent here --
+        #  measured 10 of 48, tiny and ordinary columns alike; what this test pins is the loose bound and the absence of NaN / garbage)
+        assert bad.sum() <= n // 3 and (bad & tiny).sum() <= (bad & ~tiny).sum() + 4, f"ages {ages}: columns {np.flatnonzero(bad)} miss 1e-10"
+        ctx.close()
+
+
 def test_mass_balance_full_age_axis():
     """10^4 columns x 1000 ages (0.32 GB of state): water leaves and enters exactly as the fluxes say."""
     n, ages = 10_000, 1000
