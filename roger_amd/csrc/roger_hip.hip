@@ -88,6 +88,10 @@ struct DevState {
     long long diag_interval;       // output interval in seconds (86400, 3600 or 600)
     int diag_rate, diag_collect, diag_slots;
     int diag_planes[32];
+    // sparse stores with accumulators: the pure-output planes an accumulator was given are stored by the sparse kernel after all
+    // (bit p of keep[p / 64]; keep_any = any bit set) -- the other ~70 stay unwritten
+    unsigned long long keep[(RH_NPLANES + 63) / 64];
+    int keep_any;
     // rh_enable_timing: dt_secs of every step since then (the time-step class of each timed launch)
     int *dt_log;
     int dt_log_cap, dt_log_n;
@@ -1132,9 +1136,16 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     } else {                                                       \
         RH_SEQ_##seq##_LOAD_##rt(LD)                               \
     }
+#ifdef RH_CENSUS   // (tools/isa_census.py counts what the sparse kernel stores when no accumulator asks for more)
+#define STK(name)
+#else
+#define STK(name) \
+    if ((D->keep[RH_P_##name >> 6] >> (RH_P_##name & 63)) & 1ull) rh_st(a, RH_P_##name, i, c.name);
+#endif
 #define RH_STORES(seq, rt)                                               \
     if constexpr (LAZY && SPARSE) {                                      \
         RH_SEQ_##seq##_SSTORE_##rt(ST)                                   \
+        if constexpr (KEEP) { RH_SEQ_##seq##_KSTORE_##rt(STK) }          \
     } else if constexpr (LAZY) {                                         \
         RH_SEQ_##seq##_LSTORE_##rt(ST)                                   \
     } else {                                                             \
@@ -1228,7 +1239,8 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 }
 
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
-template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE>
+// KEEP (with SPARSE): an accumulator was given planes the sparse kernel does not store -- those are stored after all (DevState::keep)
+template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE, bool KEEP = false>
 RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep) {
     {
     const Consts K = D->K;
@@ -1269,7 +1281,7 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
 // flags: RH_TAIL_*; grp_shift: 2^grp_shift workgroups per completion group; dst64: the summary word for the exchange between
 // ranks, written by the tail (or null)
-template <int MODE, bool LATERAL, bool LAZY, bool SPARSE = false>
+template <int MODE, bool LATERAL, bool LAZY, bool SPARSE = false, bool KEEP = false>
 __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int flags, int grp_shift, int *dst64) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
     // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
@@ -1310,8 +1322,8 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #else
         if (SPARSE && !Xp->last) {
 #endif
-            if (monthly) step_column<true, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
-            else step_column<false, LATERAL, LAZY, SPARSE>(a, D, Xp, i, q, bad, dep);
+            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep);
+            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep);
         } else {
             if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
             else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
@@ -2619,11 +2631,16 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     // follows inside this call (the accumulator kernel may, if it was given an X_m1 plane)
     const bool lazy = ctx->lazy_ok && ctx->rot_consistent && !ctx->diag_reads_m1;
     // sparse stores: another step of the same rh_run_steps call follows and nothing in between reads what this one only produces
-    const bool sparse = lazy && ctx->sparse_next && monthly < 0 && !ctx->diag_reads_sparse;
+    const bool sparse = lazy && ctx->sparse_next && monthly < 0;   // (planes an accumulator reads are kept: DevState::keep, the KEEP variant)
+    const bool keep = sparse && ctx->diag_reads_sparse;
     ctx->sparse_next = false;
 #define RH_LAUNCH_STEP(MODE)                                          \
     do {                                                              \
-        if (MODE == 2 && lat && sparse)                               \
+        if (MODE == 2 && lat && keep)                                 \
+            RH_LAUNCH_K((k_step<2, true, true, true, true>));         \
+        else if (MODE == 2 && keep)                                   \
+            RH_LAUNCH_K((k_step<2, false, true, true, true>));        \
+        else if (MODE == 2 && lat && sparse)                          \
             RH_LAUNCH_K((k_step<2, true, true, true>));               \
         else if (MODE == 2 && sparse)                                 \
             RH_LAUNCH_K((k_step<2, false, true, true>));              \
@@ -3220,9 +3237,20 @@ int rh_diag_configure(rh_ctx *ctx, const int *rate_planes, int n_rate, const int
         if (planes[j] < 0 || planes[j] >= ctx->planes_held || PLANE_IS_INT[planes[j]])
             return fail(ctx, RH_ERR_ARG, "rh_diag_configure: plane ids must name float64 planes");
     }
-    ctx->diag_reads_sparse = false;   // an accumulated pure-output plane must be in memory after every step
-    for (int j = 0; j < n_rate + n_collect; ++j)
-        if (pure_output_planes()[ctx->cfg.enable_lateral_flow ? 1 : 0][planes[j]]) ctx->diag_reads_sparse = true;
+    // an accumulated pure-output plane must be in memory after every step: the sparse kernel keeps storing THOSE planes (DevState::keep)
+    ctx->diag_reads_sparse = false;
+    {
+        unsigned long long keep[(RH_NPLANES + 63) / 64] = {};
+        for (int j = 0; j < n_rate + n_collect; ++j)
+            if (pure_output_planes()[ctx->cfg.enable_lateral_flow ? 1 : 0][planes[j]]) {
+                ctx->diag_reads_sparse = true;
+                keep[planes[j] >> 6] |= 1ull << (planes[j] & 63);
+            }
+        const int any = ctx->diag_reads_sparse ? 1 : 0;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dev->keep, keep, sizeof(keep), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->keep_any, &any, sizeof(any), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->diag_reads_m1 = false;   // an accumulated X_m1 plane keeps the fused kernel from skipping its stores
     for (int j = 0; j < n_rate + n_collect; ++j) {
         const size_t len = std::strlen(PLANE_NAMES[planes[j]]);

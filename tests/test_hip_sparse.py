@@ -89,18 +89,36 @@ def test_run_steps_in_pieces_leaves_every_plane_as_full_steps_do(native, case): 
             compare(pa, g[f"s{stop:05d}"], names, what=f"{case} step {stop} (rh_run_steps in pieces)")
 
 
-def test_an_accumulated_pure_output_plane_switches_the_option_off(native):  # noqa: F811
+def test_accumulated_pure_output_planes_are_kept_and_the_option_stays_on(native, monkeypatch):  # noqa: F811
+    """An accumulator that was given pure-output planes (q_ss, aet ...) used to switch the sparse stores off; since the end of round 3 the
+    sparse kernel stores THOSE planes after all (DevState::keep) and leaves the other ~70 unwritten.  The daily sums equal, bit for bit,
+    the sums of a context that stores everything (RH_NO_SPARSE_STORES), over every day of the run, and so does the state at the end."""
+    import hip_util as H
+
     g, names, forcing = load_case("svat_hetero_combo")
-    ctx = _ctx(native, g, names)
-    assert "q_ss" in ctx.pure_output_planes() and "S_fp_rz" not in ctx.pure_output_planes()
-    ctx.set_forcing_series(forcing)
-    ctx.diag_configure(rate=["S_fp_rz"], collect=[], n_slots=4)   # state only: sparse stores stay on
-    ctx.run_steps(30)
-    assert ctx.sparse_steps() >= 28
-    ctx.diag_configure(rate=["q_ss", "aet"], collect=["S_fp_rz"], n_slots=4)
-    ctx.run_steps(30)
-    assert ctx.sparse_steps() == 0
-    ctx.close()
+    assert {"q_ss", "aet"} <= set(_ctx(native, g, names).pure_output_planes())
+    rate, collect = ["q_ss", "aet", "inf_mat_rz", "prec"], ["S_fp_rz", "theta"]
+    out = []
+    for no_sparse in (False, True):
+        if no_sparse:
+            monkeypatch.setenv("RH_NO_SPARSE_STORES", "1")
+        ctx = _ctx(native, g, names)
+        ctx.set_forcing_series(forcing)
+        ctx.diag_configure(rate=["S_fp_rz"], collect=[], n_slots=4)   # state only
+        ctx.run_steps(30)
+        assert ctx.sparse_steps() == 0 if no_sparse else ctx.sparse_steps() >= 28   # (the first step after an upload is eager)
+        ctx.diag_configure(rate=rate, collect=collect, n_slots=16)
+        ctx.run_steps(200)
+        assert ctx.sparse_steps() == 0 if no_sparse else ctx.sparse_steps() >= 198
+        sums = {nm: [ctx.diag_download(nm, slot) for slot in range(4)] for nm in rate + collect}
+        out.append((sums, H.download_snapshot(ctx, names), [ctx.diag_steps(slot) for slot in range(4)]))
+        ctx.close()
+    assert out[0][2] == out[1][2] and sum(out[0][2]) > 0
+    for nm in rate + collect:
+        for slot in range(4):
+            np.testing.assert_array_equal(out[0][0][nm][slot], out[1][0][nm][slot], err_msg=f"{nm} slot {slot}")
+    assert any(np.any(out[0][0]["q_ss"][slot] != 0) for slot in range(4)) and any(np.any(out[0][0]["aet"][slot] != 0) for slot in range(4))
+    assert np.array_equal(out[0][1], out[1][1], equal_nan=True)
 
 
 # ---- the routed step (settings.enable_routing_1D): three passes, a pass also keeps what a later pass of the same step loads --------

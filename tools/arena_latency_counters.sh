@@ -16,7 +16,7 @@ for d in sorted(glob.glob(o + "/*/")):
     by = collections.defaultdict(dict)
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_step<2, false, true, true>" in r["Kernel_Name"]:
+            if "k_step<2, false, true, true, false>" in r["Kernel_Name"]:
                 k = int(r["Dispatch_Id"])
                 by[k][r["Counter_Name"]] = float(r["Counter_Value"])
                 by[k]["dur"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])

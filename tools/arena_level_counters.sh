@@ -11,7 +11,7 @@ d = sys.argv[1]
 rows = []
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_step<2, false, true>" in r["Kernel_Name"]:
+        if "k_step<2, false, true, false, false>" in r["Kernel_Name"]:
             rows.append(r)
 by = collections.defaultdict(dict)
 for r in rows:

@@ -24,7 +24,7 @@ d, v = sys.argv[1], sys.argv[2]
 vals, dur = collections.defaultdict(list), []
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_step<2, false, true>" in r["Kernel_Name"]:
+        if "k_step<2, false, true, false, false>" in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 print(f"{v:5s} kernel {sum(dur) / max(len(dur), 1) / 1e6:.4f} ms  " + "  ".join(f"{k} {sum(x) / len(x):.4g}" for k, x in sorted(vals.items())))

@@ -282,9 +282,10 @@ def main():
             rec["lst"] = rec["st"] - rotated
             rec["alias"] = sorted(alias_at.get(i, []), key=lambda p: order.get(p[0]))
             rec["sst"] = rec["lst"] - sparse["oned" if "lateral" in seq else "svat"]
+            rec["kst"] = rec["lst"] - rec["sst"]   # what the sparse kernel leaves out: stored after all where DevState::keep asks for the plane
         for rec in recs:
             rt = rec["rt"]
-            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st"), ("LLOAD", "lld"), ("LSTORE", "lst"), ("SSTORE", "sst")):
+            for kind, key in (("ROT", "rot"), ("LOAD", "ld"), ("STORE", "st"), ("LLOAD", "lld"), ("LSTORE", "lst"), ("SSTORE", "sst"), ("KSTORE", "kst")):
                 lines.append(f"#define RH_SEQ_{seq}_{kind}_{rt}(X) " + " ".join(f"X({n})" for n in sorted(rec[key], key=order.get)))
             lines.append(f"#define RH_SEQ_{seq}_ALIAS_{rt}(A) " + " ".join(f"A({xm1}, {x})" for xm1, x in rec["alias"]))
         # the fused kernel samples the summary bits of the next step's predicates (roger_hip.hip, k_step): prec and ta

@@ -47,8 +47,8 @@ def census():
             st = sum(WIDTH[w] for op, w in re.findall(r"^\s+(?:global|buffer|flat)_(load|store)_(\w+)", body, re.M) if op == "store")
             out["mode0_" + name] = {"load_bytes": ld, "store_bytes": st, "in_loops": 0}
             continue
-        m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])ELb([01])EEv", fn)
-        if not m:
+        m = re.match(r"_Z6k_stepILi(\d)ELb([01])ELb([01])ELb([01])ELb([01])EEv", fn)
+        if not m or m.group(5) == "1":   # (the KEEP variants store what an accumulator asks for on top: counted by the caller, not here)
             continue
         body = fn[: fn.find(".Lfunc_end")]   # (the whole function: the kernel has early exits)
         ld = st = 0

@@ -34,8 +34,8 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   svat_pairs() {   # model, size, n
     export RH_PMC_MODEL=$1 RH_PMC_SIZE=$2
     local lat=false; [ $1 = oned ] && lat=true
-    pmc_pair k_step_$1_sparse "k_step<2, $lat, true, true>" $3 $3 python3 tools/pmc_workload.py
-    RH_NO_SPARSE_STORES=1 pmc_pair k_step_$1_lazy "k_step<2, $lat, true, false>" $3 $3 python3 tools/pmc_workload.py
+    pmc_pair k_step_$1_sparse "k_step<2, $lat, true, true, false>" $3 $3 python3 tools/pmc_workload.py
+    RH_NO_SPARSE_STORES=1 pmc_pair k_step_$1_lazy "k_step<2, $lat, true, false, false>" $3 $3 python3 tools/pmc_workload.py
   }
   svat_pairs svat 1000x1000 1000000
   svat_pairs oned 1000x1000 1000000
