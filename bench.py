@@ -395,11 +395,12 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
 
 
 def bench_setup(args, torch, device):
-    """`--stepping setup | hooks`: the SVAT / oneD benchmark as a RogerSetup SCRIPT calling plain `run()` (roger/roger.py:523-580), one
-    GPU.  setup: the script leaves the per-step hooks to the model class -- run() then advances through rh_run_steps under
+    """`--stepping setup | hooks | routines`: the SVAT / oneD benchmark as a RogerSetup SCRIPT calling plain `run()` (roger/roger.py:523-580),
+    one GPU.  setup: the script leaves the per-step hooks to the model class -- run() then advances through rh_run_steps under
     rh_set_time_limit, a few rounds per run.  hooks: the script brings a per-step hook of its own (here a read_data that does
-    nothing), so run() keeps the reference's loop: set_forcing / set_parameters / after_timestep on the host and three native calls
-    per step (rh_adaptive_dt, rh_step_core, rh_after_timestep).  One step = one model time step; the run covers `--days` days
+    nothing), so run() keeps the reference's loop: the hooks on the host, then -- set_parameters and after_timestep being the model
+    class's -- the physics of the step as ONE native call (rh_svat_step).  routines: the three native calls per step
+    (rh_adaptive_dt, rh_step_core, rh_after_timestep) of a script that brings its own set_parameters or after_timestep.  One step = one model time step; the run covers `--days` days
     after `--warmup-days` untimed ones, the steps are counted from vs.itt."""
     from roger_amd import roger_routine
     from roger_amd.forcing import combo_forcing
@@ -416,7 +417,9 @@ def bench_setup(args, torch, device):
     class Benchmark(base):
         initial_theta = dict(theta_rz=BENCHMARK_PARAMS["theta_rz"], theta_ss=BENCHMARK_PARAMS["theta_ss"])
 
-    if args.stepping == "hooks":
+    if args.stepping == "routines":
+        os.environ["RH_STEP_BY_ROUTINE"] = "1"   # (what a script with a set_parameters / after_timestep hook of its own gets)
+    if args.stepping in ("hooks", "routines"):
         class Benchmark(Benchmark):   # noqa: F811
             @roger_routine
             def read_data(self, state):   # a per-step hook of the script's own: run() must keep calling it
@@ -461,7 +464,8 @@ def bench_setup(args, torch, device):
                         f"parameters, combo forcing (seed 42), {args.days} days after {args.warmup_days} untimed ones",
             "cells_per_gpu": n,
             "stepping": "RogerSetup.run(): " + ("stock per-step hooks, rh_run_steps under rh_set_time_limit (rounds)" if args.stepping == "setup"
-                                                else "a per-step hook of the script's own: the reference's loop, hooks on the host, rh_adaptive_dt + rh_step_core + rh_after_timestep per step"),
+                                                else ("a per-step hook of the script's own in front of the physics: the reference's loop, hooks on the host, the rest of the step one native call (rh_svat_step)" if args.stepping == "hooks"
+                                                      else "the reference's loop with the three-call step: hooks on the host, rh_adaptive_dt + rh_step_core + rh_after_timestep per step")),
             "wall_s": elapsed,
         },
     }
@@ -557,9 +561,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
-    ap.add_argument("--stepping", choices=("device", "setup", "hooks"), default="device",
-                    help="device: rh_run_steps driven by this script (the headline line); setup / hooks: the benchmark as a RogerSetup "
-                         "script calling plain run() with the model class's stock hooks / with a per-step hook of its own (one GPU)")
+    ap.add_argument("--stepping", choices=("device", "setup", "hooks", "routines"), default="device",
+                    help="device: rh_run_steps driven by this script (the headline line); setup / hooks / routines: the benchmark as a RogerSetup "
+                         "script calling plain run() with the model class's stock hooks / with a per-step hook of its own in front of the physics "
+                         "(one native call per step) / with the three-call step a script's own set_parameters or after_timestep hook needs (one GPU)")
     ap.add_argument("--days", type=int, default=20, help="--stepping setup | hooks: days of the timed run()")
     ap.add_argument("--warmup-days", type=int, default=2, help="--stepping setup | hooks: days of the untimed run() in front")
     ap.add_argument("--launch-check", action="store_true",

@@ -8,10 +8,16 @@ from golden_util import compare, load_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_combo", "oned_hetero_heavyrain"])
-def test_setup_step_reproduce_reference(case):
+@pytest.mark.parametrize("case,by_routine", [("svat_uniform_rain", False), ("svat_hetero_combo", False), ("oned_hetero_heavyrain", False),
+                                             ("svat_hetero_combo", True), ("oned_hetero_heavyrain", True)])
+def test_setup_step_reproduce_reference(case, by_routine, monkeypatch):
+    """step() of a script with its own set_forcing: the physics as one native call (rh_svat_step: the model class's set_parameters and
+    after_timestep are the fused kernel's); by_routine: the three-call step of a script that also brings one of those two hooks."""
     import svat_scripts as S
     from golden_util import is_lateral
+
+    if by_routine:
+        monkeypatch.setenv("RH_STEP_BY_ROUTINE", "1")
 
     g, names, forcing = load_case(case)
     ndays = len(forcing["PREC"]) // 144

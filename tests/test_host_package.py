@@ -76,11 +76,18 @@ def test_variables_contract(oracle_backend):
     assert st.backend_context.get_scalars().time == 86400
 
 
-@pytest.mark.parametrize("case", ["svat_uniform_rain", "svat_hetero_snowrain", "oned_hetero_heavyrain", "svat_tutorial"])
-def test_setup_and_run_reproduce_reference(oracle_backend, case):
+@pytest.mark.parametrize("case,by_routine", [("svat_uniform_rain", False), ("svat_hetero_snowrain", False), ("oned_hetero_heavyrain", False),
+                                             ("svat_tutorial", False), ("svat_hetero_snowrain", True), ("oned_hetero_heavyrain", True)])
+def test_setup_and_run_reproduce_reference(oracle_backend, case, by_routine, monkeypatch):
     """The same setup script the golden generator ran through the reference, run through this
-    package: setup() state and the trajectory of step() match the reference."""
+    package: setup() state and the trajectory of step() match the reference.  The script brings its own set_forcing and leaves
+    set_parameters / after_timestep to the model class: step() then runs the physics as ONE native call (rh_svat_step);
+    by_routine: the three-call step (rh_adaptive_dt, rh_step_core, rh_after_timestep) a script with a set_parameters or
+    after_timestep hook of its own gets."""
     import svat_scripts as S
+
+    if by_routine:
+        monkeypatch.setenv("RH_STEP_BY_ROUTINE", "1")
 
     g, names, forcing = load_case(case)
     ndays = len(forcing["PREC"]) // 144

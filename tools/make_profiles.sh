@@ -56,8 +56,8 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   RH_BENCH_FORCE_DIST=1 bench svat_1e6_rccl_one_rank --steps 200 --warmup 10 --no-cpu-baseline
   bench svat_1e6_driver_command --gpus 1 --steps 20 --warmup 5
   RH_NO_SPARSE_STORES=1 bench svat_1e6_full_stores --steps 200 --warmup 10 --no-cpu-baseline
-  # the benchmark as a RogerSetup script calling plain run(): stock hooks (on the device) and a hook of the script's own (the reference's loop)
-  for st in setup hooks; do
+  # the benchmark as a RogerSetup script calling plain run(): stock hooks (on the device), a hook of the script's own in front of the physics (one native call per step) and the three-call step
+  for st in setup hooks routines; do
     python3 bench.py --stepping $st --days 20 --warmup-days 2 > $scratch/svat_1e6_$st.out 2> $scratch/svat_1e6_$st.err && last $scratch/svat_1e6_$st.out > $out/${tag}_bench_svat_1e6_run_$st.json && echo "run() $st ok"
     python3 bench.py --stepping $st --size 80 53 --days 60 --warmup-days 2 > $scratch/svat_80x53_$st.out 2> $scratch/svat_80x53_$st.err && last $scratch/svat_80x53_$st.out > $out/${tag}_bench_svat_80x53_run_$st.json
   done
