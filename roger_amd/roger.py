@@ -205,12 +205,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
                     vs.flush_to_device()
                     state.backend_context.step(monthly)
                     vs.mark_device_newer(None)
-                if getattr(state, "_diag_active", None):
-                    diagnostics.output(state)
-                if rs.profile_mode:
-                    state.backend_context.sync()
-                    logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
-                return
+                return self._end_of_step(state)
             with state.timers["adaptive time-stepping"]:
                 if rst.proc_num > 1:
                     # dt is ONE scalar for the whole domain: the ranks agree on the predicates before it is derived
@@ -225,6 +220,10 @@ class RogerSetup(metaclass=abc.ABCMeta):
             with state.timers["processes"]:
                 run_native(state, "rh_step_core")
         self.after_timestep(state)
+        self._end_of_step(state)
+
+    @staticmethod
+    def _end_of_step(state):
         if getattr(state, "_diag_active", None):   # roger/roger.py:458-465: output at the end of the time step
             diagnostics.output(state)
         if rs.profile_mode:
