@@ -225,7 +225,9 @@ FIRST_TIE = {"sas_power_a40": 11, "sas_families_a50": 6, "sas_gamma_a40": 3, "sa
 MIN_TIGHT = {"sas_gamma_a40": 0.97}
 
 
-# Residue ties of the DEVICE against the reference, measured on MI355X / ROCm 7.2 with the round-2 kernel (tools/sas_tie_rate.py prints
+# Residue ties of the DEVICE against the reference, measured on MI355X / ROCm 7.2 with the round-2 kernel and unchanged by every step of the
+# round-3 kernel (fifth root included); their cause is the ORDER of the kernel's cumulative sums, not its power function (DESIGN.md section 4,
+# tools/sas_tie_causes.py: the oracle ties alike when it sums in the wave scan's order) (tools/sas_tie_rate.py prints
 # them; every GPU test prints its own counts too): (day, column) pairs of a golden case that miss 1e-10 when each day restarts from
 # the reference's state.  The tests allow ONE more than measured: a kernel change that shifts the last bit of Omega moves single ties
 # (re-measure then), a regression that doubles the rate fails.
