@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 3   /* 2: rh_config gained enable_routing_1D + dy, rh_sas_config.solver (round 2); 3: rh_comm_info (round 3) */
+#define RH_ABI_VERSION 4   /* 2: rh_config gained enable_routing_1D + dy, rh_sas_config.solver (round 2); 3: rh_comm_info (round 3); 4: rh_svat_step_scalars (round 4) */
 #define RH_SLOTS_PER_DAY 144 /* roger/variables.py:109 "timesteps_day": 6 * 24 */
 
 typedef enum rh_status {
@@ -229,6 +229,12 @@ int rh_step_phase1(rh_ctx *ctx);
 int rh_step_phase2(rh_ctx *ctx);
 int rh_step_phase3(rh_ctx *ctx, int monthly); /* monthly < 0: use the device-side month-change flag */
 int rh_svat_step(rh_ctx *ctx, int monthly);
+/* rh_svat_step followed by the read-back of the scalars the driver's loop looks at before the next step (`while vs.time - start_time <
+ * runlen`, roger/roger.py:548-556; a script's set_forcing tests `vs.time % 86400`, benchmarks/SVAT_benchmark.py:155-156): ONE call per
+ * step for a driver that keeps its hooks on the host.  The scalars (and the sanity / forcing-series flags) travel through a block of
+ * pinned host memory that a one-thread kernel behind the step writes directly -- no staged copies; the call returns when that block
+ * has arrived (it synchronises like rh_get_scalars, which uses the same block). */
+int rh_svat_step_scalars(rh_ctx *ctx, int monthly, rh_scalars *s);
 /* The same step with ONE exchange (shared forcing only).  The fused kernel leaves, per wavefront, a summary word of
  * its columns' end-of-step state from which both predicate words of the next step follow (the start-of-step snow
  * predicates directly; the event predicates together with the selected prec / ta, which are uniform when the

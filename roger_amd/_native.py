@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROGER_HIP_LIB", os.path.join(PKG, "libroger_hip.so"))  # override: kernel experiments
 
 
-ABI_VERSION = 3   # include/roger_hip.h: RH_ABI_VERSION
+ABI_VERSION = 4   # include/roger_hip.h: RH_ABI_VERSION
 
 
 class RhConfig(C.Structure):
@@ -155,6 +155,7 @@ def load():
     lib.rh_diag_device_ptr.argtypes = [vp, i32, i32]
     lib.rh_diag_device_ptr.restype = vp
     lib.rh_svat_step.argtypes = [vp, i32]
+    lib.rh_svat_step_scalars.argtypes = [vp, i32, C.POINTER(RhScalars)]
     lib.rh_run_steps.argtypes = [vp, i64]
     lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
     lib.rh_predicates_expand.argtypes = [vp, i32, vp]
@@ -396,7 +397,7 @@ DECLARED_SYMBOLS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
-    "rh_svat_step", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
+    "rh_svat_step", "rh_svat_step_scalars", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_selftest_pow", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_set_time_limit", "rh_run_steps_dist",
@@ -587,6 +588,15 @@ class Context:
 
     def step(self, monthly=False):
         self._check(self._lib.rh_svat_step(self._h, int(bool(monthly))), "rh_svat_step")
+
+    def step_scalars(self, monthly=False):
+        """rh_svat_step + the read-back of the scalars in ONE native call (a driver that keeps its hooks on the host needs vs.time
+        before the next step); returns the RhScalars after the step."""
+        s = RhScalars()
+        rc = self._lib.rh_svat_step_scalars(self._h, 1 if monthly else 0, C.byref(s))
+        if rc != 0:
+            self._check(rc, "rh_svat_step_scalars")
+        return s
 
     def step_phase3(self, monthly=False):
         # monthly: False/True, or -1 to use the month-change flag computed on the device

@@ -122,7 +122,19 @@ struct DevState {
     Luts L;
 };
 
+// What the host reads after a step, in pinned host memory that the device writes directly (hipHostMallocMapped): k_export copies the
+// committed scalars and flags and stores `seq` last (system scope), the host waits for its sequence number.  rh_get_scalars used
+// four staged copies into pageable memory (>= 40 us); this is one one-thread kernel.
+struct HostExport {
+    rh_scalars S;
+    unsigned long long bad, bad_last;
+    unsigned int err, pad;
+    unsigned long long seq;
+};
+
 struct rh_ctx {
+    HostExport *hexp = nullptr;      // pinned + mapped
+    unsigned long long hexp_seq = 0;
     rh_config cfg;
     int64_t n;
     Arena arena;
@@ -1043,9 +1055,12 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
 // step of a day (t0 on midnight) overwrites.  Rate planes add this step's value (Rate.diagnose, roger/diagnostics/
 // rate.py:66-84: `rate += var[..., tau]`), collect planes keep the current one.  S.time / S.dt_secs were advanced by
 // the control kernel before the fused kernel ran.
-__global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D) {
+// after_fused: the launch follows a fused k_step, whose prologue has just written D->skipped (the step found the run over,
+// rh_set_time_limit: nothing to add).  Behind the routine-by-routine step (rh_step_core) and the routed passes there is no such
+// launch in front and the flag may be left over from an earlier device run under a limit: they pass 0.
+__global__ __launch_bounds__(RH_BLOCK) void k_diag(Arena a, DevState *D, int after_fused) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
-    if (i >= a.n || D->skipped) return;   // (skipped: the fused launch in front found the run over, rh_set_time_limit)
+    if (i >= a.n || (after_fused && D->skipped)) return;
     const int64_t t0 = D->S.time - D->S.dt_secs, iv = D->diag_interval;
     const int64_t slot = (t0 / iv) % D->diag_slots;
     const bool first = (t0 % iv) == 0;   // steps never straddle an interval boundary they do not start on (adaptive_time_stepping)
@@ -1081,6 +1096,14 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do
     }
 }
 
+__global__ void k_export(const DevState *D, HostExport *H, unsigned long long seq) {
+    H->S = D->S;
+    H->bad = D->words[2];
+    H->bad_last = D->sanity_last;
+    H->err = D->err_flags;
+    __threadfence_system();
+    __hip_atomic_store(&H->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_advance(DevState *D) {  // roger.py:449-450
     D->S.itt += 1;
     D->S.time += D->S.dt_secs;
@@ -2090,6 +2113,8 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     }
     if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
+    if ((e = hipHostMalloc((void **)&ctx->hexp, sizeof(HostExport), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(scalar export block)");
+    std::memset(ctx->hexp, 0, sizeof(HostExport));
     if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     {
         static const long long no_limit = -1;
@@ -2165,6 +2190,7 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->route_i) (void)hipFree(ctx->route_i);
     release_comm(ctx);
     if (ctx->dev) (void)hipFree(ctx->dev);
+    if (ctx->hexp) (void)hipHostFree(ctx->hexp);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -2261,18 +2287,35 @@ int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
     return RH_OK;
 }
 
+// Enqueue the export of the scalars behind whatever is on the stream and wait for it: the host spins on the block's sequence number
+// (the write arrives a few microseconds after the kernel in front has finished; hipStreamSynchronize wakes up later) and looks at the
+// stream from time to time, so that a launch that failed ends the wait with its error instead of hanging.
+static int export_scalars(rh_ctx *ctx, rh_scalars *s) {
+    const unsigned long long seq = ++ctx->hexp_seq;
+    hipLaunchKernelGGL(k_export, dim3(1), dim3(1), 0, ctx->stream, (const DevState *)ctx->dev, ctx->hexp, seq);
+    CHECK_LAUNCH(ctx);
+    const unsigned long long *p = &ctx->hexp->seq;
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xfffful) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) break;
+                return fail(ctx, RH_ERR_HIP, "the scalar export kernel finished without its block arriving in host memory");
+            }
+            if (q != hipErrorNotReady) HIPCHK(ctx, q);
+        }
+    }
+    const HostExport &H = *ctx->hexp;
+    *s = H.S;
+    // word 2 collects the sanity violations of the last step; the fused kernel's tail moves it to sanity_last
+    s->sanity_ok = (H.bad | H.bad_last) ? 0 : 1;
+    return device_error(ctx, H.err);
+}
+
 int rh_get_scalars(rh_ctx *ctx, rh_scalars *s) {
     if (!ctx || !s) return RH_ERR_ARG;
-    unsigned long long bad = 0, bad_last = 0;
-    unsigned err = 0;
-    HIPCHK(ctx, hipMemcpyAsync(s, &ctx->dev->S, sizeof(*s), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&bad, &ctx->dev->words[2], sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&bad_last, &ctx->dev->sanity_last, sizeof(bad_last), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&err, &ctx->dev->err_flags, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // word 2 collects the sanity violations of the last step; the fused kernel's tail moves it to sanity_last
-    s->sanity_ok = (bad | bad_last) ? 0 : 1;
-    return device_error(ctx, err);
+    return export_scalars(ctx, s);
 }
 
 int rh_set_luts(rh_ctx *ctx, const double *ilu, const double *gc, const double *gcm, const double *rdlu) {
@@ -2408,7 +2451,7 @@ int rh_step_core(rh_ctx *ctx) {
     }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
     // the output accumulators follow every step, also in the hook-preserving flow (itt / time were just advanced)
-    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, 0);
     CHECK_LAUNCH(ctx);
     return RH_OK;
 }
@@ -2674,7 +2717,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     ctx->pending_hooks = (flags & RH_TAIL_HOOKS) != 0;
     ctx->exch_valid = dst64 != nullptr;
     if (ctx->diag_n) {
-        hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev);
+        hipLaunchKernelGGL(k_diag, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, 1);
         CHECK_LAUNCH(ctx);
     }
     return RH_OK;
@@ -2811,6 +2854,11 @@ int rh_step_finish_compress(rh_ctx *ctx, int monthly, const int32_t *dev_src64) 
 int rh_svat_step(rh_ctx *ctx, int monthly) {
     if (!ctx) return RH_ERR_ARG;
     return step_fused_launches(ctx, monthly, 0);
+}
+int rh_svat_step_scalars(rh_ctx *ctx, int monthly, rh_scalars *s) {
+    if (!ctx || !s) return RH_ERR_ARG;
+    if (int rc = step_fused_launches(ctx, monthly, 0)) return rc;
+    return export_scalars(ctx, s);
 }
 
 // stand-alone adaptive time stepping: phases 1-2, the scalar kernel and the pet/ta selection
@@ -2957,7 +3005,7 @@ static int routed_core(rh_ctx *ctx, bool with_after) {
     else LAUNCH_CELLS(ctx, k_routed_c);
     LAUNCH_ONE(ctx, k_sanity_to_scalars, ctx->dev);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, ctx->stream, ctx->dev);
-    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+    if (ctx->diag_n) hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, 0);
     if (with_after) {
         if (fuse_after) LAUNCH_ONE(ctx, k_rotate_scalars, ctx->dev);
         else if ((rc = rh_after_timestep(ctx))) return rc;
@@ -3016,7 +3064,7 @@ static int routed_step_device(rh_ctx *ctx, bool sparse_wanted = false) {
     if (ctx->diag_n) {   // the accumulators read the planes between the numerics and the rotation
         if (separate_gathers) LAUNCH_CELLS(ctx, k_routed_c);
         else hipLaunchKernelGGL((k_routed_cg<false, false>), grid, block, 0, ctx->stream, ctx->arena, ctx->dev, nx, ny, route_halo_of(ctx));
-        hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev);
+        hipLaunchKernelGGL(k_diag, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, 0);
         LAUNCH_CELLS(ctx, k_after_timestep_oned);
     } else if (separate_gathers)
         LAUNCH_CELLS(ctx, k_routed_c_after);
@@ -3104,9 +3152,18 @@ static int limit_reached(rh_ctx *ctx, bool *reached) {
     return RH_OK;
 }
 
+// sparse_next is the request of ONE enqueued step; whatever way a stepping call ends (a failing launch, the timing cap, forcing that was
+// never set), it must not survive the call: the next single-step entry point would run the sparse kernel as a call's last step
+struct SparseRequestScope {
+    rh_ctx *ctx;
+    explicit SparseRequestScope(rh_ctx *c) : ctx(c) { ctx->sparse_next = false; }
+    ~SparseRequestScope() { ctx->sparse_next = false; }
+};
+
 int rh_run_steps(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
+    SparseRequestScope sparse_scope(ctx);
     ctx->call_sparse_steps = 0;
     bool over = false;
     if (int rc = limit_reached(ctx, &over)) return rc;
@@ -3179,6 +3236,7 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
     if (!ctx || nsteps < 0) return RH_ERR_ARG;
     if (!ctx->series_buf) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_series must be called first");
     if (!ctx->comm) return fail(ctx, RH_ERR_STATE, "rh_run_steps_dist: no communicator (rh_comm_init / rh_set_comm)");
+    SparseRequestScope sparse_scope(ctx);
     ctx->call_sparse_steps = 0;
     bool over = false;
     if (int rc = limit_reached(ctx, &over)) return rc;

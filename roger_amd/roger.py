@@ -203,8 +203,11 @@ class RogerSetup(metaclass=abc.ABCMeta):
                     vs = state.variables
                     monthly = bool((vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1))
                     vs.flush_to_device()
-                    state.backend_context.step(monthly)
-                    vs.mark_device_newer(None)
+                    if hasattr(state.backend_context, "step_scalars"):
+                        vs.mark_device_newer(None, scalars=state.backend_context.step_scalars(monthly))
+                    else:   # (the oracle double of the CPU tests)
+                        state.backend_context.step(monthly)
+                        vs.mark_device_newer(None)
                 return self._end_of_step(state)
             with state.timers["adaptive time-stepping"]:
                 if rst.proc_num > 1:
@@ -257,20 +260,33 @@ class RogerSetup(metaclass=abc.ABCMeta):
             state.sas_context.sync()
             logger.info(" Time step took {:.2f}s".format(state.timers["main"].last_time))
 
-    # the per-step user hooks; when all of them are the stock ones of the ready-made models (marked `device_equivalent`: the
-    # device-side control part performs exactly these, roger_hip.hip ctrl_wave), run() needs no host code between two steps
+    # the per-step user hooks; when all of them do what the device-side control part does itself (roger_hip.hip ctrl_wave), run()
+    # needs no host code between two steps.  Decided per hook by BEHAVIOUR (roger_amd/hooks.py): every script the reference ships
+    # defines these hooks itself (benchmarks/SVAT_benchmark.py:105-110, 152-181), so inheritance says nothing.
     STEP_HOOKS = ("read_data", "set_boundary_conditions", "set_forcing", "set_parameters", "after_timestep")
+    recognise_hooks = True   # a script sets this to False to keep every hook of its own on the host, unprobed
+
+    def hook_classes(self):
+        """{hook: True if the device performs it} -- the hooks of the ready-made model classes by their mark, a script's own by
+        probing them once against the recording state (after setup(): the probes look at the forcing series and weights)."""
+        self._ensure_setup_done()
+        if getattr(self, "_hook_classes", None) is None:
+            from . import hooks
+
+            self._hook_classes = hooks.classify(self, self.STEP_HOOKS)
+        return self._hook_classes
 
     def _fused_host_step_possible(self):
-        """step(): the hooks BEHIND set_forcing (set_parameters, after_timestep) are the model class's own (`device_equivalent`), one rank,
-        no routing: the physics of the step is one native call (rh_svat_step)."""
+        """step(): the hooks BEHIND set_forcing (set_parameters, after_timestep) are the device's own -- the model class's, or a script's
+        that do the same --, one rank, no routing: the physics of the step is one native call (rh_svat_step)."""
         settings = self.state.settings
         if rst.proc_num > 1 or settings.enable_routing_1D or settings.enable_offline_transport:
             return False
-        if not all(getattr(getattr(type(self), h, None), "device_equivalent", False) for h in ("set_parameters", "after_timestep")):
-            return False
         # (RH_STEP_BY_ROUTINE=1: the three-call step of rounds 1 - 3, for A/B and for the tests of that path)
-        return hasattr(self.state.backend_context, "step") and not os.environ.get("RH_STEP_BY_ROUTINE")
+        if not hasattr(self.state.backend_context, "step") or os.environ.get("RH_STEP_BY_ROUTINE"):
+            return False
+        classes = self.hook_classes()
+        return classes["set_parameters"] and classes["after_timestep"]
 
     def device_run_possible(self):
         """True if `run()` may advance on the device without returning to the host between steps: the setup script left the
@@ -279,9 +295,9 @@ class RogerSetup(metaclass=abc.ABCMeta):
         settings = self.state.settings
         if settings.enable_offline_transport or rs.profile_mode or settings.restart_frequency > 0:
             return False
-        if not all(getattr(getattr(type(self), h, None), "device_equivalent", False) for h in self.STEP_HOOKS):
+        if not hasattr(self.state.backend_context, "run_steps") or os.environ.get("RH_STEP_BY_ROUTINE"):
             return False
-        return hasattr(self.state.backend_context, "run_steps")
+        return all(self.hook_classes().values())
 
     def _run_on_device(self, start_time, runlen):
         """`while vs.time - start_time < runlen: step()` (roger/roger.py:548-556) without the host in the loop.  The step length is
@@ -325,6 +341,40 @@ class RogerSetup(metaclass=abc.ABCMeta):
             if limit:
                 ctx.set_time_limit(None)
 
+    def _lean_host_loop_possible(self):
+        settings = self.state.settings
+        return (self._fused_host_step_possible() and not rs.profile_mode and settings.restart_frequency <= 0
+                and hasattr(self.state.backend_context, "step_scalars") and not os.environ.get("RH_NO_LEAN_LOOP"))
+
+    def _run_host_hooks(self, start_time, runlen):
+        """`while vs.time - start_time < runlen: step()` (roger/roger.py:548-556) for a script whose hooks in FRONT of the physics are
+        its own: those run on the host, step by step, as in the reference; the rest of the step is ONE native call that also brings back
+        the scalars the loop and the hooks look at (rh_svat_step_scalars: no second call, no staged copies).  What step() does around
+        the hooks per step -- five timer contexts, the routine wrappers' unlock, a list of 200 names to mark, three device read-backs
+        -- was 75 - 85 us per step, three times the fused kernel's time on a catchment-sized grid; what is left is the hooks' own work.
+        Hooks the probes found to do nothing (hooks.py) are not called."""
+        state = self.state
+        vs, ctx = state.variables, state.backend_context
+        classes = self.hook_classes()
+        front = [getattr(getattr(type(self), h), "__wrapped__", getattr(type(self), h))
+                 for h in ("read_data", "set_boundary_conditions", "set_forcing")
+                 if not (classes[h] and h != "set_forcing")]
+        diag = bool(getattr(state, "_diag_active", None))
+        timer = state.timers["main"]
+        with vs.unlock(), timer:
+            s = vs._get_scalars()
+            while s.time - start_time < runlen:
+                for hook in front:
+                    hook(self, state)
+                if vs._scalars_dirty or vs._scalars is None:
+                    s = vs._get_scalars()       # (the hook assigned a scalar: its own copy is the current one)
+                monthly = (s.month[1] != s.month[0]) and s.itt > 1   # the stock set_parameters' test (models/svat.py)
+                vs.flush_to_device()
+                s = ctx.step_scalars(monthly)
+                vs.mark_device_newer(None, scalars=s)
+                if diag:
+                    self._end_of_step(state)
+
     def run(self, show_progress_bar=None):
         """roger/roger.py:523-580"""
         self._ensure_setup_done()
@@ -335,6 +385,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
         try:
             if self.device_run_possible():
                 self._run_on_device(int(start_time), int(runlen))
+            elif self._lean_host_loop_possible():
+                self._run_host_hooks(int(start_time), int(runlen))
             else:
                 while vs.time - start_time < runlen:
                     self.step(self.state)

@@ -28,6 +28,10 @@ def _find_state(args, kwargs):
 
 def run_native(state, entry, writes=None):
     vs = state.variables
+    if vs._probe is not None:   # a hook is being probed (roger_amd/hooks.py): the call is recorded, nothing runs
+        from .hooks import record_kernel_call
+
+        return record_kernel_call(state, entry, entry)
     vs.flush_to_device()
     state.backend_context.call(entry)
     vs.mark_device_newer(writes)
@@ -88,6 +92,10 @@ def roger_kernel(function=None, *, static_args=()):
             # name is the transport model's own (models/svat_oxygen18: tau -> taum1 of the snow signal) and runs on the host
             if native is not None and state is not None and not state.settings.enable_offline_transport:
                 return run_native(state, *native)
+            if state is not None and state._variables is not None and state._variables._probe is not None:
+                from .hooks import record_kernel_call   # a host kernel inside a probed hook: recorded (the hook is the host's then)
+
+                return record_kernel_call(state, fn.__name__, None)
             if state is not None and state._variables is not None:
                 with state.variables.unlock():
                     return fn(*args, **kwargs)

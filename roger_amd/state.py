@@ -127,7 +127,14 @@ class RogerVariables(Lockable):
         d(self, "_sas", sas_ctx)
         d(self, "_host", {})
         d(self, "_host_dirty", set())
+        # freshness of the host mirrors.  A native call that may have written ANY plane (a whole step) bumps `_epoch` -- O(1) per step
+        # instead of a set of ~200 names --: a plane variable whose mirror was filled in an earlier epoch is newer on the device.
+        # `_device_newer` names the variables a call marked individually.
         d(self, "_device_newer", set())
+        d(self, "_epoch", 0)
+        d(self, "_mirror_epoch", {})
+        d(self, "_plane_vars", frozenset(k for k, v in var_meta.items() if v.plane is not None))
+        d(self, "_probe", None)            # roger_amd/hooks.py: a recording session (hook recognition), or None
         d(self, "_scalars", None)          # cached rh_scalars (valid until the next native call)
         d(self, "_scalars_dirty", False)
         d(self, "_forcing_dirty", False)
@@ -150,10 +157,20 @@ class RogerVariables(Lockable):
         return self._scalars
 
     # -- attribute protocol ------------------------------------------------------------------
+    def _is_device_newer(self, key):
+        return key in self._device_newer or (key in self._plane_vars and self._mirror_epoch.get(key, 0) != self._epoch)
+
     def __getattr__(self, key):
         meta = object.__getattribute__(self, "__metadata__")
         if key not in meta:
             raise AttributeError(key)
+        probe = self._probe
+        if probe is not None:              # a hook is being probed: reads are recorded, the probe's values stand in for the scalars
+            probe.reads.add(key)
+            if key in probe.writes:
+                return probe.writes[key]
+            if key in probe.values:
+                return probe.values[key]
         if key in var_mod.DEVICE_SCALARS:
             v = getattr(self._get_scalars(), key)
             return float(v) if key == "dt" else int(v)
@@ -161,7 +178,7 @@ class RogerVariables(Lockable):
             a = np.array(list(getattr(self._get_scalars(), key)), dtype=np.int64)
             a.flags.writeable = False
             return a
-        if key in self._device_newer:
+        if self._is_device_newer(key):
             self._download(key)
         return self._host[key]
 
@@ -171,6 +188,9 @@ class RogerVariables(Lockable):
             return object.__setattr__(self, key, val)
         if key not in self.__metadata__:
             raise AttributeError(f"Unknown attribute {key}")
+        if self._probe is not None:        # recorded, not applied
+            self._probe.writes[key] = val
+            return
         var = self.__metadata__[key]
         if key in var_mod.DEVICE_SCALARS:
             s = self._get_scalars()
@@ -198,6 +218,7 @@ class RogerVariables(Lockable):
             arr.flags.writeable = False
         self._host[key] = arr
         self._device_newer.discard(key)
+        self._mirror_epoch[key] = self._epoch
         if var.plane is not None or var.sas is not None:
             self._host_dirty.add(key)
         elif key in ("prec_day", "ta_day", "pet_day"):
@@ -212,6 +233,8 @@ class RogerVariables(Lockable):
     def update(self, other=None, **new_fields):
         """roger/state.py:70-90; a DeviceResult only moves the freshness marker."""
         if isinstance(other, DeviceResult):
+            if self._probe is not None:
+                return self
             self._device_newer.update(other._fields)
             for k in other._fields:
                 self._host_dirty.discard(k)
@@ -253,6 +276,7 @@ class RogerVariables(Lockable):
             host.flags.writeable = False
             self._host[key] = host
             self._device_newer.discard(key)
+            self._mirror_epoch[key] = self._epoch
             return
         for suffix, lvl in self._levels(key):
             flat = self._ctx.download(key + suffix).reshape(nxl, nyl)
@@ -263,9 +287,12 @@ class RogerVariables(Lockable):
         host.flags.writeable = False
         self._host[key] = host
         self._device_newer.discard(key)
+        self._mirror_epoch[key] = self._epoch
 
     def flush_to_device(self):
         """Upload everything assigned on the host since the last native call."""
+        if not (self._host_dirty or self._scalars_dirty or self._forcing_dirty):
+            return
         for key in sorted(self._host_dirty):
             host = self._host[key]
             var = self.__metadata__[key]
@@ -294,13 +321,14 @@ class RogerVariables(Lockable):
                 self._ctx.set_forcing_day(*[np.ascontiguousarray(d).reshape(-1, 144) for d in days])
             object.__setattr__(self, "_forcing_dirty", False)
 
-    def mark_device_newer(self, names=None):
-        """After a native call: `names` (or every arena variable) changed on the device."""
+    def mark_device_newer(self, names=None, scalars=None):
+        """After a native call: `names` (or every arena variable) changed on the device.  `scalars`: the rh_scalars the call
+        read back itself (rh_svat_step_scalars), cached until the next native call."""
         if names is None:
-            names = [k for k, v in self.__metadata__.items() if v.plane is not None]
-        names = [k for k in names if k in self.__metadata__]
-        self._device_newer.update(names)
-        object.__setattr__(self, "_scalars", None)
+            object.__setattr__(self, "_epoch", self._epoch + 1)
+        else:
+            self._device_newer.update(k for k in names if k in self.__metadata__)
+        object.__setattr__(self, "_scalars", scalars)
 
 
 class RogerState:

@@ -4,13 +4,31 @@ class tests/golden/make_golden.py drives through the *reference* (`from roger im
 runs unchanged."""
 import numpy as np
 
-from roger_amd import roger_routine
+from roger_amd import KernelOutput, roger_kernel, roger_routine
 from roger_amd.core.operators import at, numpy as npx, update
+from roger_amd.core.surface import calc_parameters_surface_kernel
 from roger_amd.models.svat import SVATSetup
 
 
-def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights=None, stations=None, routing=None):
-    """global_shape: (nx, ny) of the whole domain when `params` holds this rank's slab only (num_proc = (N, 1))."""
+@roger_kernel
+def after_timestep_kernel(state):
+    """A script-local tau -> taum1 rotation as every script of the reference carries one (benchmarks/SVAT_benchmark.py:183-418,
+    roger/models/svat/svat.py:187-384).  On the hip backend a kernel of this name is the native rotation (roger_amd/routines.py:
+    NATIVE_KERNELS), the body below is what a script author would write and never runs there."""
+    vs = state.variables
+    out = {}
+    for name in ("S_rz", "S_ss", "S_s", "S", "z_sat", "z_wf", "theta_rz", "theta_ss", "theta", "prec", "ta", "swe", "z0"):
+        a = getattr(vs, name)
+        out[name] = update(a, at[2:-2, 2:-2, vs.taum1], a[2:-2, 2:-2, vs.tau])
+    return KernelOutput(**out)
+
+
+def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights=None, stations=None, routing=None, script_hooks=None):
+    """global_shape: (nx, ny) of the whole domain when `params` holds this rank's slab only (num_proc = (N, 1)).
+    script_hooks: the script ALSO defines set_parameters and after_timestep itself, with the bodies every script of the reference has
+    (benchmarks/SVAT_benchmark.py:105-110, 177-181) -- "plain"; or with one deviation each that the device's control part does NOT
+    perform: "set_parameters_assigns" (a variable assigned in the hook), "after_timestep_assigns", "forcing_scaled" (set_forcing
+    doubles the precipitation), "forcing_counts" (set_forcing keeps a counter of its own)."""
     from roger_amd.models.oned import ONEDSetup
 
     nx, ny = global_shape or params["lu_id"].shape
@@ -119,7 +137,64 @@ def make_model(params, forcing, ndays, lateral=False, global_shape=None, weights
                     vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
                 vs.itt_forc = vs.itt_forc + 6 * 24
 
-    return GoldenSVAT(forcing=F, nx=nx, ny=ny, ndays=ndays)
+    if script_hooks is None:
+        return GoldenSVAT(forcing=F, nx=nx, ny=ny, ndays=ndays)
+    assert script_hooks in ("plain", "set_parameters_assigns", "after_timestep_assigns", "forcing_scaled", "forcing_counts")
+
+    class ScriptSVAT(GoldenSVAT):
+        @roger_routine
+        def set_parameters(self, state):
+            vs = state.variables
+
+            if (vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1):
+                vs.update(calc_parameters_surface_kernel(state))
+
+        @roger_routine
+        def after_timestep(self, state):
+            vs = state.variables
+
+            vs.update(after_timestep_kernel(state))
+
+    if script_hooks == "set_parameters_assigns":
+        class ScriptSVAT(ScriptSVAT):   # noqa: F811
+            @roger_routine
+            def set_parameters(self, state):
+                vs = state.variables
+                if (vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1):
+                    vs.update(calc_parameters_surface_kernel(state))
+                vs.c_int = update(vs.c_int, at[2:-2, 2:-2], 1.0)   # (the value it has: the trajectory stays the golden's)
+    elif script_hooks == "after_timestep_assigns":
+        class ScriptSVAT(ScriptSVAT):   # noqa: F811
+            @roger_routine
+            def after_timestep(self, state):
+                vs = state.variables
+                vs.update(after_timestep_kernel(state))
+                vs.irr_demand = update(vs.irr_demand, at[2:-2, 2:-2], 0.0)
+    elif script_hooks == "forcing_scaled":
+        class ScriptSVAT(ScriptSVAT):   # noqa: F811
+            @roger_routine
+            def set_forcing(self, state):
+                vs = state.variables
+                if vs.time % (24 * 60 * 60) == 0:
+                    vs.itt_day = 0
+                    vs.year = update(vs.year, at[1], vs.YEAR[vs.itt_forc])
+                    vs.month = update(vs.month, at[1], vs.MONTH[vs.itt_forc])
+                    vs.doy = update(vs.doy, at[1], vs.DOY[vs.itt_forc])
+                    sl = slice(vs.itt_forc, vs.itt_forc + 6 * 24)
+                    vs.prec_day = update(vs.prec_day, at[:, :, :], 2 * vs.PREC[npx.newaxis, npx.newaxis, sl])
+                    vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, sl])
+                    vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, sl])
+                    vs.itt_forc = vs.itt_forc + 6 * 24
+    elif script_hooks == "forcing_counts":
+        class ScriptSVAT(ScriptSVAT):   # noqa: F811
+            forcing_calls = []
+
+            @roger_routine
+            def set_forcing(self, state):
+                self.forcing_calls.append(int(state.variables.time))
+                GoldenSVAT.set_forcing.__wrapped__(self, state)
+
+    return ScriptSVAT(forcing=F, nx=nx, ny=ny, ndays=ndays)
 
 
 def params_from_golden(g, names):

@@ -86,3 +86,38 @@ def test_svat_to_transport_on_device():
         assert np.isclose(sas.download(k), g.day(g.ndays, k), rtol=5e-3, atol=5e-3, equal_nan=True).all(), k
     sas.close()
     ctx.close()
+
+
+def test_accumulators_keep_summing_on_the_routine_path_after_a_limited_device_run(monkeypatch):
+    """ADVICE r3 (medium): a device run under rh_set_time_limit ends with halted launches, whose prologue leaves DevState::skipped = 1.
+    The accumulator kernel behind the routine-by-routine step (rh_step_core: no fused launch in front) must not look at that flag --
+    it returned at once and the daily sums silently stopped.  Day 1 on the device under a limit, day 2 through the three-call step
+    with the hooks on the host: both days' sums equal the reference's."""
+    from make_golden import hetero_params
+    from roger_amd.forcing import combo_forcing
+    from svat_scripts import make_model
+
+    case = "sas_stats_a30"
+    g = sb.SasGolden(case)
+    seed = SEEDS[case]
+    model = make_model(hetero_params(g.nx, g.ny, seed=seed), combo_forcing(ndays=g.ndays, seed=seed), g.ndays)
+    model.setup()
+    ctx = model.state.backend_context
+    ctx.diag_configure(rate=RATE, collect=COLLECT, n_slots=g.ndays + 1)
+    vs = model.state.variables
+    ctx.set_time_limit(86400)
+    model.run_device(200, final=False)      # far more launches than the day has steps: the trailing ones are halted
+    ctx.set_time_limit(None)
+    assert vs.time == 86400
+    monkeypatch.setenv("RH_STEP_BY_ROUTINE", "1")
+    assert not model._fused_host_step_possible()
+    while vs.time < 2 * 86400:
+        model.step(model.state)
+    ctx.sync()
+    for d in (1, 2):
+        assert ctx.diag_steps(d - 1) >= 1
+        for k in RATE + COLLECT:
+            want = g.z[f"in_{k}"][:, :, d].reshape(-1)
+            got = ctx.diag_download(k, d - 1)
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-10), f"day {d} {k}: {np.abs(got - want).max()}"
+    ctx.close()

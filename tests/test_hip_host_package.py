@@ -315,3 +315,65 @@ def test_run_with_stock_hooks_on_the_device(case, tmp_path):
         compare(S.snapshot_from_vs(vs, names), g[key], names, what=f"{case}: run() on the device, step {nsteps}")
     gs = g["scal"][nsteps - 1]
     assert (int(vs.dt_secs), int(vs.itt_day), int(vs.event_id_counter)) == (gs[2], gs[3], gs[6])
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "oned_hetero_heavyrain"])
+def test_reference_shaped_script_runs_on_the_device(case):
+    """Every script the reference ships defines set_forcing, set_parameters and after_timestep itself (benchmarks/SVAT_benchmark.py:
+    105-110, 152-181); a script of that shape is recognised hook by hook (roger_amd/hooks.py) and its run() advances on the device."""
+    import svat_scripts as S
+    from test_host_package import run_script_case
+
+    model, g, names = run_script_case(case, "plain")
+    rounds = []
+    inner = model.run_device
+    model.run_device = lambda n, final=True: (rounds.append(n), inner(n, final=final))[1]
+    model.run()
+    assert rounds, "run() did not take the device path"
+    vs = model.state.variables
+    nsteps = int(g["nsteps"])
+    assert (int(vs.itt), int(vs.time)) == (nsteps, int(g["scal"][nsteps - 1][1]))
+    compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what=f"{case}: reference-shaped script, run() on the device")
+
+
+@pytest.mark.parametrize("script_hooks", ["set_parameters_assigns", "after_timestep_assigns", "forcing_scaled", "forcing_counts"])
+def test_a_hook_that_does_something_of_its_own_stays_on_the_host(script_hooks):
+    """A hook that assigns a variable, changes the forcing or keeps a counter of its own is the host's: the reference's loop -- through
+    the lean loop (one native call per step that also returns the scalars, rh_svat_step_scalars) when set_parameters and
+    after_timestep are the device's, the three-call step otherwise."""
+    import svat_scripts as S
+    from test_host_package import SCRIPT_CASES, run_script_case
+
+    model, g, names = run_script_case("svat_hetero_combo", script_hooks)
+    assert model._lean_host_loop_possible() is SCRIPT_CASES[script_hooks][2]
+    model.run_device = None
+    model.run()
+    vs = model.state.variables
+    nsteps = int(g["nsteps"])
+    if script_hooks == "forcing_scaled":
+        assert int(vs.time) == int(g["scal"][nsteps - 1][1])
+        return
+    assert (int(vs.itt), int(vs.time)) == (nsteps, int(g["scal"][nsteps - 1][1]))
+    compare(S.snapshot_from_vs(vs, names), g[f"s{nsteps:05d}"], names, what=f"{script_hooks}: hooks on the host")
+    if script_hooks == "forcing_counts":
+        assert type(model).forcing_calls == [int(t) for t in [0] + list(g["scal"][: nsteps - 1, 1])]
+
+
+def test_lean_loop_equals_step_by_step(monkeypatch):
+    """run() through the lean loop (hooks as plain functions, rh_svat_step_scalars) and run() through step() (RH_NO_LEAN_LOOP=1) end in
+    the same state bit for bit, with the daily output of both written alike."""
+    import svat_scripts as S
+    from test_host_package import run_script_case
+
+    snaps = []
+    for lean in (True, False):
+        if not lean:
+            monkeypatch.setenv("RH_NO_LEAN_LOOP", "1")
+        model, g, names = run_script_case("svat_hetero_combo", "forcing_counts")
+        type(model).forcing_calls.clear()
+        assert model._lean_host_loop_possible() is lean
+        model.run()
+        vs = model.state.variables
+        snaps.append((int(vs.itt), int(vs.time), S.snapshot_from_vs(vs, names)))
+    assert snaps[0][:2] == snaps[1][:2]
+    np.testing.assert_array_equal(snaps[0][2], snaps[1][2])

@@ -542,3 +542,105 @@ def test_run_with_stock_hooks_stays_on_the_device(oracle_backend, case, tmp_path
             np.testing.assert_array_equal(fa.variables["Time"][:], fb.variables["Time"][:])
             for k in keys:
                 np.testing.assert_allclose(fa.variables[k][:], fb.variables[k][:], rtol=1e-13, atol=1e-13, err_msg=f"{kind} {k}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# reference-shaped scripts: every script the reference ships defines set_forcing, set_parameters and after_timestep ITSELF
+# (benchmarks/SVAT_benchmark.py:105-110, 152-181).  Which of them the device performs is decided by behaviour (roger_amd/hooks.py).
+# ---------------------------------------------------------------------------------------------------------------------------------
+SCRIPT_CASES = {
+    # script_hooks: (hooks the device performs, run() stays on the device, the step is one native call)
+    "plain": (dict(read_data=True, set_boundary_conditions=True, set_forcing=True, set_parameters=True, after_timestep=True), True, True),
+    "set_parameters_assigns": (dict(set_forcing=True, set_parameters=False, after_timestep=True), False, False),
+    "after_timestep_assigns": (dict(set_forcing=True, set_parameters=True, after_timestep=False), False, False),
+    "forcing_scaled": (dict(set_forcing=False, set_parameters=True, after_timestep=True), False, True),
+    "forcing_counts": (dict(set_forcing=False, set_parameters=True, after_timestep=True), False, True),
+}
+
+
+def run_script_case(case, script_hooks, ndays=None, check_golden=True):
+    """run() of a reference-shaped script; returns (model, golden, names).  Shared with tests/test_hip_host_package.py."""
+    import svat_scripts as S
+    from golden_util import is_lateral
+
+    g, names, forcing = load_case(case)
+    ndays = ndays or len(forcing["PREC"]) // 144
+    model = S.make_model(S.params_from_golden(g, names), forcing, ndays, lateral=is_lateral(g), script_hooks=script_hooks)
+    model.setup()
+    want, on_device, one_call = SCRIPT_CASES[script_hooks]
+    classes = model.hook_classes()
+    for hook, expected in want.items():
+        assert classes[hook] is expected, (script_hooks, hook, classes)
+    assert model.device_run_possible() is on_device
+    assert model._fused_host_step_possible() is one_call
+    return model, g, names
+
+
+@pytest.mark.parametrize("case", ["svat_hetero_combo", "oned_hetero_heavyrain"])
+def test_reference_shaped_script_runs_on_the_device(oracle_backend, case):
+    """Own set_forcing slicing the series at midnight, own set_parameters with the month test, own after_timestep calling a
+    script-local after_timestep_kernel: recognised hook by hook, run() advances on the device and ends where the reference ends."""
+    model, g, names = run_script_case(case, "plain")
+    rounds = []
+    inner = model.run_device
+    model.run_device = lambda n, final=True: (rounds.append(n), inner(n, final=final))[1]
+    model.run()
+    assert rounds, "run() did not take the device path"
+    vs = model.state.variables
+    nsteps = int(g["nsteps"])
+    assert (int(vs.itt), int(vs.time)) == (nsteps, int(g["scal"][nsteps - 1][1]))
+    compare(S_snapshot(vs, names), g[f"s{nsteps:05d}"], names, what=f"{case}: reference-shaped script, run() on the device")
+
+
+def S_snapshot(vs, names):
+    import svat_scripts as S
+
+    return S.snapshot_from_vs(vs, names)
+
+
+@pytest.mark.parametrize("script_hooks", ["set_parameters_assigns", "after_timestep_assigns", "forcing_scaled", "forcing_counts"])
+def test_a_hook_that_does_something_of_its_own_stays_on_the_host(oracle_backend, script_hooks):
+    """A hook that assigns a variable itself, changes the forcing or keeps a counter is NOT the device's: run() keeps the reference's
+    loop (the three-call step when set_parameters / after_timestep are the script's, one native call otherwise) and -- where the
+    deviation leaves the values alone -- still ends in the golden state; a counting hook is called exactly once per step."""
+    model, g, names = run_script_case("svat_hetero_combo", script_hooks)
+    model.run_device = None   # (run() must not take it)
+    model.run()
+    vs = model.state.variables
+    nsteps = int(g["nsteps"])
+    if script_hooks == "forcing_scaled":
+        assert int(vs.time) == int(g["scal"][nsteps - 1][1]) and int(vs.itt) != 0
+        return
+    assert (int(vs.itt), int(vs.time)) == (nsteps, int(g["scal"][nsteps - 1][1]))
+    compare(S_snapshot(vs, names), g[f"s{nsteps:05d}"], names, what=f"{script_hooks}: hooks on the host")
+    if script_hooks == "forcing_counts":
+        assert type(model).forcing_calls == [int(t) for t in [0] + list(g["scal"][: nsteps - 1, 1])]
+
+
+def test_hook_recognition_can_be_switched_off(oracle_backend, monkeypatch):
+    import svat_scripts as S
+
+    monkeypatch.setenv("RH_NO_HOOK_RECOGNITION", "1")
+    g, names, forcing = load_case("svat_hetero_combo")
+    model = S.make_model(S.params_from_golden(g, names), forcing, 24, script_hooks="plain")
+    model.setup()
+    assert not any(model.hook_classes()[h] for h in ("set_forcing", "set_parameters", "after_timestep"))
+    assert not model.device_run_possible() and not model._fused_host_step_possible()
+
+
+def test_probes_leave_no_trace(oracle_backend):
+    """Probing runs the hooks against the RECORDING state: nothing is assigned, no kernel runs, the scalars are untouched."""
+    import svat_scripts as S
+
+    g, names, forcing = load_case("svat_hetero_combo")
+    model = S.make_model(S.params_from_golden(g, names), forcing, 24, script_hooks="plain")
+    model.setup()
+    vs = model.state.variables
+    before = S.snapshot_from_vs(vs, names)
+    scal = [getattr(vs, k) for k in ("itt", "time", "itt_forc", "itt_day")] + [list(vs.month), list(vs.year)]
+    day = np.array(vs.prec_day)
+    model.hook_classes()
+    assert vs._probe is None
+    np.testing.assert_array_equal(before, S.snapshot_from_vs(vs, names))
+    assert scal == [getattr(vs, k) for k in ("itt", "time", "itt_forc", "itt_day")] + [list(vs.month), list(vs.year)]
+    np.testing.assert_array_equal(day, np.array(vs.prec_day))
