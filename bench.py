@@ -418,18 +418,63 @@ def bench_setup(args, torch, device):
         initial_theta = dict(theta_rz=BENCHMARK_PARAMS["theta_rz"], theta_ss=BENCHMARK_PARAMS["theta_ss"])
 
     if args.stepping == "routines":
-        os.environ["RH_STEP_BY_ROUTINE"] = "1"   # (what a script with a set_parameters / after_timestep hook of its own gets)
+        os.environ["RH_STEP_BY_ROUTINE"] = "1"   # (what a script with a set_parameters / after_timestep hook that does something of its own gets)
     if args.stepping in ("hooks", "routines"):
         class Benchmark(Benchmark):   # noqa: F811
+            hook_calls = 0
+
             @roger_routine
-            def read_data(self, state):   # a per-step hook of the script's own: run() must keep calling it
-                pass
+            def read_data(self, state):   # a per-step hook that does something of the script's own: run() must keep calling it
+                type(self).hook_calls += 1
+    if args.stepping == "script":
+        # the hooks every script of the reference defines ITSELF, with the reference's bodies (benchmarks/SVAT_benchmark.py:105-110,
+        # 152-181): recognised hook by hook (roger_amd/hooks.py), run() advances on the device
+        from roger_amd import KernelOutput, roger_kernel
+        from roger_amd.core.operators import at, numpy as npx, update
+        from roger_amd.core.surface import calc_parameters_surface_kernel
+
+        @roger_kernel
+        def after_timestep_kernel(state):   # (a kernel of this name is the native rotation: roger_amd/routines.py)
+            vs = state.variables
+            return KernelOutput(S=update(vs.S, at[2:-2, 2:-2, vs.taum1], vs.S[2:-2, 2:-2, vs.tau]))
+
+        class Benchmark(Benchmark):   # noqa: F811
+            @roger_routine
+            def set_parameters(self, state):
+                vs = state.variables
+
+                if (vs.month[vs.tau] != vs.month[vs.taum1]) & (vs.itt > 1):
+                    vs.update(calc_parameters_surface_kernel(state))
+
+            @roger_routine
+            def set_forcing(self, state):
+                vs = state.variables
+
+                condt = vs.time % (24 * 60 * 60) == 0
+                if condt:
+                    vs.itt_day = 0
+                    vs.year = update(vs.year, at[1], vs.YEAR[vs.itt_forc])
+                    vs.month = update(vs.month, at[1], vs.MONTH[vs.itt_forc])
+                    vs.doy = update(vs.doy, at[1], vs.DOY[vs.itt_forc])
+                    vs.prec_day = update(vs.prec_day, at[:, :, :], vs.PREC[npx.newaxis, npx.newaxis, vs.itt_forc:vs.itt_forc + 6 * 24])
+                    vs.ta_day = update(vs.ta_day, at[:, :, :], vs.TA[npx.newaxis, npx.newaxis, vs.itt_forc:vs.itt_forc + 6 * 24])
+                    vs.pet_day = update(vs.pet_day, at[:, :, :], vs.PET[npx.newaxis, npx.newaxis, vs.itt_forc:vs.itt_forc + 6 * 24])
+                    vs.itt_forc = vs.itt_forc + 6 * 24
+
+            @roger_routine
+            def after_timestep(self, state):
+                vs = state.variables
+
+                vs.update(after_timestep_kernel(state))
 
     total_days = args.warmup_days + args.days
     model = Benchmark(forcing=combo_forcing(ndays=total_days + 2), nx=nx, ny=ny, ndays=total_days, parameters=p)
     model.setup()
     state = model.state
-    assert model.device_run_possible() is (args.stepping == "setup")
+    if os.environ.get("RH_NO_HOOK_RECOGNITION") and args.stepping == "script":
+        assert not model.device_run_possible()   # (A/B: what such a script got before round 4 -- the three-call step)
+    else:
+        assert model.device_run_possible() is (args.stepping in ("setup", "script")), model.hook_classes()
     ctx = state.backend_context
 
     def run_days(days):
@@ -463,14 +508,59 @@ def bench_setup(args, torch, device):
             "workload": f"{'oneD' if args.model == 'oned' else 'SVAT'}_benchmark as a RogerSetup script calling run(): nx*ny={n} ({nx}x{ny}), uniform benchmark "
                         f"parameters, combo forcing (seed 42), {args.days} days after {args.warmup_days} untimed ones",
             "cells_per_gpu": n,
+            "hooks_on_device": model.hook_classes(),
             "stepping": "RogerSetup.run(): " + ("stock per-step hooks, rh_run_steps under rh_set_time_limit (rounds)" if args.stepping == "setup"
-                                                else ("a per-step hook of the script's own in front of the physics: the reference's loop, hooks on the host, the rest of the step one native call (rh_svat_step)" if args.stepping == "hooks"
+                                                else "the script's OWN set_forcing / set_parameters / after_timestep with the reference's bodies (benchmarks/SVAT_benchmark.py:105-110, 152-181), recognised by behaviour: rh_run_steps under rh_set_time_limit" if args.stepping == "script"
+                                                else ("a per-step hook in front of the physics that does something of the script's own: the reference's loop, hooks on the host, the rest of the step one native call that also returns the scalars (rh_svat_step_scalars)" if args.stepping == "hooks"
                                                       else "the reference's loop with the three-call step: hooks on the host, rh_adaptive_dt + rh_step_core + rh_after_timestep per step")),
             "wall_s": elapsed,
         },
     }
     print(json.dumps(out))
     ctx.close()
+
+
+def run_extra(name, argv, need_free_gb, torch, device, timeout_s=150):
+    """One more bench line from a CHILD process of this script (own context, own memory; a failure there leaves the headline alone):
+    returns the parsed line or {"skipped": reason}.  Never exec: the parent stays the process the caller waits for."""
+    import subprocess
+
+    free_b, _total = torch.cuda.mem_get_info(device)
+    if free_b < need_free_gb * 2**30:
+        return {"skipped": f"{name}: {free_b / 2**30:.0f} GiB of device memory free, {need_free_gb} GiB wanted"}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--no-extras", "--no-cpu-baseline"], env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"skipped": f"{name}: no line within {timeout_s} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"skipped": f"{name}: the child ended with status {r.returncode}: {r.stderr.strip().splitlines()[-1:] or ''}"}
+    return json.loads(lines[-1])
+
+
+def bench_extras(torch, device):
+    """what the driver's one command should also witness -- the north-star size (the >= 50 % target is stated at
+    nx * ny = 10^7) and the transport step (BASELINE configs[2]) --, measured AFTER the headline with the headline's own formulas
+    (the same code: a child run of this script), reported under `extras`; the headline fields do not depend on them."""
+    out = {}
+    d = run_extra("svat_1e7", ["--size", "3200", "3125", "--steps", "20", "--warmup", "5", "--prewarm-ms", "0"], 70, torch, device)
+    if "skipped" not in d:
+        r = d["roofline"]
+        d = {"workload": d["config"]["workload"], "value": d["value"], "ms_per_step": d["ms_per_step"], "avg_kernel_ms": r["avg_kernel_ms"],
+             "frac": r["frac"], "bytes_per_cell": r["algorithmic_bytes_per_cell"], "kernel": r["kernel"], "steps": d["steps"],
+             "traffic_frac": r.get("traffic_frac")}
+    out["svat_1e7"] = d
+    d = run_extra("sas_1e5", ["--model", "sas", "--size", "400", "250", "--steps", "4", "--warmup", "2"], 16, torch, device)
+    if "skipped" not in d:
+        r = d["roofline"]
+        d = {"workload": d["config"]["workload"], "value": d["value"], "ms_per_step": d["ms_per_step"], "avg_kernel_ms": r["avg_kernel_ms"],
+             "frac": r["frac"], "compute": {"frac": (r.get("compute") or {}).get("frac"),
+                                            "valu_wave_insts_per_column_day": (r.get("compute") or {}).get("valu_wave_insts_per_column_day")},
+             "steps": d["steps"], "unit": "column-days/s; ms per model day"}
+    out["sas_1e5"] = d
+    return out
 
 
 def launch_ranks(n, argv):
@@ -559,12 +649,17 @@ def main():
                          "first heavy-rain event (step 112 with the default --warmup 5), so that the timed steps of even a 20-step run "
                          "cover all three step classes -- 5 ten-minute, 14 hourly and 1 daily step (SURVEY 8d: per dt-class; VERDICT r2 weak #8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="one GPU, --model svat at the default size: do not add the `extras` object (SVAT at 3200 x 3125 and the SAS step at 10^5 "
+                         "columns, each from a child run of this script after the headline measurement); for profiling runs")
     ap.add_argument("--cpu-cells", type=int, default=1000000,
                     help="columns of the CPU baseline sample (svat / oned; sas uses 1/25 of it)")
-    ap.add_argument("--stepping", choices=("device", "setup", "hooks", "routines"), default="device",
-                    help="device: rh_run_steps driven by this script (the headline line); setup / hooks / routines: the benchmark as a RogerSetup "
-                         "script calling plain run() with the model class's stock hooks / with a per-step hook of its own in front of the physics "
-                         "(one native call per step) / with the three-call step a script's own set_parameters or after_timestep hook needs (one GPU)")
+    ap.add_argument("--stepping", choices=("device", "setup", "script", "hooks", "routines"), default="device",
+                    help="device: rh_run_steps driven by this script (the headline line); setup / script / hooks / routines: the benchmark as a RogerSetup "
+                         "script calling plain run() with the model class's stock hooks / with set_forcing, set_parameters and after_timestep of its OWN "
+                         "as every script of the reference has them (recognised by behaviour: on the device) / with a per-step hook in front of the "
+                         "physics that does something of its own (hooks on the host, one native call per step) / with the three-call step that a "
+                         "set_parameters or after_timestep hook doing something of its own needs (one GPU)")
     ap.add_argument("--days", type=int, default=20, help="--stepping setup | hooks: days of the timed run()")
     ap.add_argument("--warmup-days", type=int, default=2, help="--stepping setup | hooks: days of the untimed run() in front")
     ap.add_argument("--launch-check", action="store_true",
@@ -780,6 +875,11 @@ def main():
                 "sample": f"oracle/svat_oracle.c (OpenMP over the columns), {args.cpu_cells} cells x first {cpu_steps} steps of "
                           f"the same forcing, {secs:.1f} s on {threads} host threads",
             }
+        plain = (world == 1 and args.model == "svat" and tuple(args.size) == (1000, 1000) and args.params == "uniform" and not args.station_weights
+                 and not os.environ.get("RH_BENCH_FORCE_DIST") and not os.environ.get("RH_BENCH_FORCE_PHASED"))
+        if plain and not args.no_extras and not args.no_cpu_baseline:   # (--no-cpu-baseline marks the profiling / A-B runs of tools/*.sh)
+            ctx.close()   # (the headline's arena is not needed any more)
+            out["extras"] = bench_extras(torch, device)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
