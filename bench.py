@@ -43,12 +43,22 @@ REFERENCE_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md sect
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def kernel_bytes_per_cell(model, variant):
+UNIFORM_READ_FRACTION = 1.0 / 8.0   # a wave that reads ONE element of a plane fetches a 64-byte sector instead of 512 bytes
+
+
+def kernel_bytes_per_cell(model, variant, param_stats=None):
     """(load, store) bytes one column moves per fused step of that kernel variant ("eager", "lazy", "sparse"):
-    roger_amd/csrc/rh_step_bytes.json (tools/isa_census.py)."""
+    roger_amd/csrc/rh_step_bytes.json (tools/isa_census.py).  The lazy / sparse variants read the parameter planes through the wave's
+    word (include/roger_hip.h: rh_param_stats): `param_stats` = (fraction of the waves whose derived parameters are not loaded, bytes
+    per column of parameter loads that are one element per wave) of the context that ran."""
     rec = json.load(open(os.path.join(REPO, "roger_amd", "csrc", "rh_step_bytes.json")))
     r = rec[f"{'oned' if model == 'oned' else 'svat'}_{variant}"]
-    return r["load_bytes"], r["store_bytes"]
+    ld = r["load_bytes"]
+    if "load_bytes_all_parameters_loaded" in r:
+        derived, uniform = param_stats if param_stats is not None else (0.0, 0.0)
+        full = r["load_bytes_all_parameters_loaded"]
+        ld = full - derived * (full - r["load_bytes"]) - uniform * (1.0 - UNIFORM_READ_FRACTION)
+    return ld, r["store_bytes"]
 
 
 def measured_traffic(key, n_cells):
@@ -794,13 +804,14 @@ def main():
         n_sparse = sparse_steps if sparse_steps == launches - 1 and launches == len(per_ms) else 0
         kind = "sparse" if n_sparse else ("lazy" if lazy else "eager")
         k_avg_s = (float(per_ms[:n_sparse].mean()) / 1e3) if n_sparse else kernel_ms / 1e3 / max(launches, 1)
-        ld_b, st_b = kernel_bytes_per_cell(args.model, kind)
+        pstats = ctx.param_stats() if kind != "eager" else None
+        ld_b, st_b = kernel_bytes_per_cell(args.model, kind, pstats)
         algo = (ld_b + st_b) * n_local
         achieved = algo / k_avg_s / 1e9
         variant = f"k_step_{'oned' if args.model == 'oned' else 'svat'}_{kind}"
         full = None
         if n_sparse:
-            fl, fs = kernel_bytes_per_cell(args.model, "lazy")
+            fl, fs = kernel_bytes_per_cell(args.model, "lazy", pstats)
             full = {"kernel": variant.replace("sparse", "lazy"), "launches": launches - n_sparse, "avg_kernel_ms": float(per_ms[n_sparse:].mean()),
                     "algorithmic_bytes_per_cell": {"load": fl, "store": fs},
                     "frac": (fl + fs) * n_local / (float(per_ms[n_sparse:].mean()) / 1e3) / 1e9 / HBM_PEAK_GBS}
@@ -855,6 +866,11 @@ def main():
                 "traffic_source": trec["source"] if trec else None,
                 "algorithmic_bytes_per_launch": algo,
                 "algorithmic_bytes_per_cell": {"load": ld_b, "store": st_b},
+                # how the kernel read the parameter planes (rh_param_stats): the 15 parameters calc_parameters_soil derives from the
+                # primaries are evaluated in the kernel where the planes hold exactly those values (120 B per column not loaded), and
+                # a parameter plane with ONE value over a wave's 64 columns is read as one element (priced at 1/8 of its bytes)
+                "parameters": None if pstats is None else {"derived_fraction_of_waves": pstats[0], "bytes_per_cell_read_as_one_element_per_wave": pstats[1],
+                                                           "uniform_read_priced_at": UNIFORM_READ_FRACTION},
                 "reference_equivalent": {"bytes_per_cell_step": REFERENCE_BYTES_PER_CELL_STEP, "achieved": ref_achieved,
                                          "ratio_to_peak": ref_achieved / HBM_PEAK_GBS},
                 "avg_kernel_ms": k_avg_s * 1e3,

@@ -235,6 +235,17 @@ int rh_svat_step(rh_ctx *ctx, int monthly);
  * pinned host memory that a one-thread kernel behind the step writes directly -- no staged copies; the call returns when that block
  * has arrived (it synchronises like rh_get_scalars, which uses the same block). */
 int rh_svat_step_scalars(rh_ctx *ctx, int monthly, rh_scalars *s);
+/* The parameter planes as the lazy variants of the fused kernel will read them (round 4): per wavefront of 64 columns the kernel keeps a
+ * word saying which parameter planes (read by the step, assigned by none of its stages, or by the monthly surface parameters only) hold
+ * ONE value over the wave -- those are read as one element per wave instead of 512 bytes -- and whether the 15 parameters that
+ * calc_parameters_soil derives from the primaries (roger/core/soil.py:143-557: theta_sat, theta_fc, m_bc, n_salv, wfs, rew, z_evap,
+ * tew, S_{ac,ufc,pwp}_{rz,ss}, S_pwp_s) still hold exactly those values, bit for bit -- then the stages evaluate the same expressions
+ * instead of loading the planes.  The words are formed from the planes on the device whenever somebody other than the fused kernel may
+ * have changed them; a plane uploaded with other values simply clears the bits of the waves it touches.
+ *   derived_fraction        waves whose derived parameters are not loaded
+ *   uniform_bytes_per_cell  bytes per column and step of parameter loads that are one element per wave (of what is loaded at all)
+ * RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE (environment, read by rh_create) switch the two off. */
+int rh_param_stats(rh_ctx *ctx, double *derived_fraction, double *uniform_bytes_per_cell);
 /* The same step with ONE exchange (shared forcing only).  The fused kernel leaves, per wavefront, a summary word of
  * its columns' end-of-step state from which both predicate words of the next step follow (the start-of-step snow
  * predicates directly; the event predicates together with the selected prec / ta, which are uniform when the

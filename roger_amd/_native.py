@@ -156,6 +156,7 @@ def load():
     lib.rh_diag_device_ptr.restype = vp
     lib.rh_svat_step.argtypes = [vp, i32]
     lib.rh_svat_step_scalars.argtypes = [vp, i32, C.POINTER(RhScalars)]
+    lib.rh_param_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rh_run_steps.argtypes = [vp, i64]
     lib.rh_set_forcing_series.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
     lib.rh_predicates_expand.argtypes = [vp, i32, vp]
@@ -397,7 +398,7 @@ DECLARED_SYMBOLS = (
     "rh_topo", "rh_params_surface", "rh_params_soil", "rh_initial_conditions", "rh_adaptive_dt", "rh_interception",
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
-    "rh_svat_step", "rh_svat_step_scalars", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
+    "rh_svat_step", "rh_svat_step_scalars", "rh_param_stats", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
     "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_selftest_pow", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_set_time_limit", "rh_run_steps_dist",
@@ -662,6 +663,13 @@ class Context:
     def set_time_limit(self, t_end):
         """No step begins at or beyond model time t_end (None / negative: no limit): rh_run_steps(n) then runs at most n steps."""
         self._check(self._lib.rh_set_time_limit(self._h, -1 if t_end is None else int(t_end)), "rh_set_time_limit")
+
+    def param_stats(self):
+        """(fraction of the wavefronts whose derived parameters are not loaded, bytes per column of parameter loads that are one element
+        per wave) -- how the lazy variants of the fused kernel will read the parameter planes as they are now."""
+        d, u = C.c_double(), C.c_double()
+        self._check(self._lib.rh_param_stats(self._h, C.byref(d), C.byref(u)), "rh_param_stats")
+        return d.value, u.value
 
     def sparse_steps(self):
         return int(self._lib.rh_sparse_steps(self._h))

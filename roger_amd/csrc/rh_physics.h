@@ -1122,6 +1122,48 @@ RH_DEV void rt_params_surface(Col &c, const Luts &L, const StepCtx &X) {
     c.throughfall_coeff_ground = ((lu >= 500 && lu < 598) ? tf : 0.0) * mk;
 }
 
+// The parameters of calc_parameters_soil / _root_zone / _subsoil (soil.py:143-557) that follow from the primaries by a handful of IEEE
+// operations, grouped by the stage of the fused step that needs them first.  rt_params_soil (the setup kernel) is built from these
+// helpers, and the fused step evaluates THE SAME helpers instead of loading the 15 planes (k_step, DevState::pmask bit 63: the wave's
+// planes were found to hold exactly these values) -- one definition, so the bits agree by construction (-ffp-contract=off: no
+// contraction; division and comparison are IEEE on the device).  
+RH_DEV void h_der_porosity(Col &c, double mk) {        // first needed by the evapotranspiration stage
+    const double por = c.theta_ac + c.theta_ufc + c.theta_pwp, fc = c.theta_ufc + c.theta_pwp;
+    c.theta_sat = por * mk;
+    c.theta_fc = fc * mk;
+}
+RH_DEV void h_der_evap_depth(Col &c, const Consts &K, double rew_before, double mk) {
+    double rew = (c.theta_pwp < K.theta_rew_min ? K.rew_min : rew_before) * mk;
+    rew = ((c.theta_pwp >= K.theta_rew_min) && (c.theta_pwp <= K.theta_rew_max) ? c.theta_pwp / K.theta_rew_max : rew) * mk;
+    c.rew = (c.theta_pwp > K.theta_rew_max ? K.rew_max : rew) * mk;
+    c.z_evap = ((c.rew / K.rew_max) * K.z_evap_max) * mk;
+    c.tew = ((c.theta_fc - 0.5 * c.theta_pwp) * c.z_evap) * mk;
+}
+RH_DEV void h_der_wfs(Col &c, double mk) {   // from lambda_bc and ha
+    c.wfs = (((2 + 3 * c.lambda_bc) / (1 + 3 * c.lambda_bc) * c.ha / 2) * (-10)) * mk;
+}
+RH_DEV void h_der_n_salv(Col &c, const Consts &K, double mk) {
+    const double nb = K.a_bc + K.b_bc * c.lambda_bc;
+    c.n_salv = nb * mk;
+}
+RH_DEV void h_der_m_bc(Col &c, const Consts &K, double mk) {
+    const double nb = K.a_bc + K.b_bc * c.lambda_bc;
+    c.m_bc = (nb / c.lambda_bc) * mk;
+}
+RH_DEV void h_der_S_ac_rz(Col &c, double zr, double mk) { c.S_ac_rz = (c.theta_ac * zr) * mk; }
+RH_DEV void h_der_S_ufc_rz(Col &c, double zr, double mk) { c.S_ufc_rz = (c.theta_ufc * zr) * mk; }
+RH_DEV void h_der_S_pwp_rz(Col &c, double zr, double mk) { c.S_pwp_rz = (c.theta_pwp * zr) * mk; }
+RH_DEV void h_der_S_ac_ufc_ss(Col &c, double zr, double mk) {
+    const double dz = c.z_soil - zr;
+    c.S_ac_ss = (c.theta_ac * dz) * mk;
+    c.S_ufc_ss = (c.theta_ufc * dz) * mk;
+}
+RH_DEV void h_der_S_pwp_ss_s(Col &c, double zr, double mk) {
+    const double dz = c.z_soil - zr;
+    c.S_pwp_ss = (c.theta_pwp * dz) * mk;
+    c.S_pwp_s = (c.z_soil * c.theta_pwp) * mk;
+}
+
 // soil.py:143-557 (calc_parameters_soil/root_zone/subsoil kernels)
 RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     const double mk = (double)c.maskCatch;
@@ -1129,17 +1171,14 @@ RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     const double por = c.theta_ac + c.theta_ufc + c.theta_pwp, fc = c.theta_ufc + c.theta_pwp;
     c.S_ac_s = (c.z_soil * c.theta_ac) * mk;
     c.S_ufc_s = (c.z_soil * c.theta_ufc) * mk;
-    c.S_pwp_s = (c.z_soil * c.theta_pwp) * mk;
     c.S_fc_s = (c.z_soil * fc) * mk;
     c.S_sat_s = (c.z_soil * por) * mk;
-    c.theta_sat = por * mk;
-    c.theta_fc = fc * mk;
+    h_der_porosity(c, mk);
     c.lambda_bc = ((log(c.theta_fc / c.theta_sat) - log(c.theta_pwp / c.theta_sat)) / (log(15850.0) - log(63.0))) * mk;
     c.ha = (RH_POW(c.theta_pwp / c.theta_sat, 1.0 / c.lambda_bc) * (-15850)) * mk;
-    const double nb = K.a_bc + K.b_bc * c.lambda_bc;
-    c.m_bc = (nb / c.lambda_bc) * mk;
-    c.n_salv = nb * mk;
-    c.wfs = (((2 + 3 * c.lambda_bc) / (1 + 3 * c.lambda_bc) * c.ha / 2) * (-10)) * mk;
+    h_der_m_bc(c, K, mk);
+    h_der_n_salv(c, K, mk);
+    h_der_wfs(c, mk);
     c.theta_27 = (RH_POW(c.ha / (-501.18723362727246), c.lambda_bc) * c.theta_sat) * mk;  // 10**2.7
     c.theta_4 = (RH_POW(c.ha / (-10000.0), c.lambda_bc) * c.theta_sat) * mk;
     c.theta_6 = (RH_POW(c.ha / (-1000000.0), c.lambda_bc) * c.theta_sat) * mk;
@@ -1150,12 +1189,7 @@ RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     c.clay = (cl < K.clay_min ? K.clay_min : cl) * mk;
     c.z_sc_max = (c.clay * 700) * mk;
     c.mp_drain_area = 1 - exp((-1) * RH_POW(c.dmpv / 82, 0.887)) * mk;
-
-    double rew = (c.theta_pwp < K.theta_rew_min ? K.rew_min : c.rew) * mk;
-    rew = ((c.theta_pwp >= K.theta_rew_min) && (c.theta_pwp <= K.theta_rew_max) ? c.theta_pwp / K.theta_rew_max : rew) * mk;
-    c.rew = (c.theta_pwp > K.theta_rew_max ? K.rew_max : rew) * mk;
-    c.z_evap = ((c.rew / K.rew_max) * K.z_evap_max) * mk;
-    c.tew = ((c.theta_fc - 0.5 * c.theta_pwp) * c.z_evap) * mk;
+    h_der_evap_depth(c, K, c.rew, mk);
 
     // rooting depth from land use :338-440
     const bool conifer = (lu == 10) || (lu == 11) || (lu == 12);
@@ -1171,18 +1205,51 @@ RH_DEV void rt_params_soil(Col &c, const Consts &K, const Luts &L) {
     zr = (zr < c.z_soil ? zr : c.z_soil * 0.9);
     c.z_root = zr;
     c.z_root_m1 = zr;
-    c.S_ac_rz = (c.theta_ac * zr) * mk;
-    c.S_ufc_rz = (c.theta_ufc * zr) * mk;
-    c.S_pwp_rz = (c.theta_pwp * zr) * mk;
+    h_der_S_ac_rz(c, zr, mk);
+    h_der_S_ufc_rz(c, zr, mk);
+    h_der_S_pwp_rz(c, zr, mk);
     c.S_sat_rz = (por * zr) * mk;
     c.S_fc_rz = (fc * zr) * mk;
+    h_der_S_ac_ufc_ss(c, zr, mk);
+    h_der_S_pwp_ss_s(c, zr, mk);
     const double dz = c.z_soil - zr;
-    c.S_ac_ss = (c.theta_ac * dz) * mk;
-    c.S_ufc_ss = (c.theta_ufc * dz) * mk;
-    c.S_pwp_ss = (c.theta_pwp * dz) * mk;
     c.S_sat_ss = (por * dz) * mk;
     c.S_fc_ss = (fc * dz) * mk;
 }
+
+// The fused step's own evaluation of those parameters: every stage derives what it is the FIRST to mention (tools/gen_sets.py checks
+// that against the sequences), so a derived value is live exactly as long as the loaded one was.  The primaries -- theta_ac, theta_ufc,
+// theta_pwp, z_soil, z_root, lambda_bc, ha, maskCatch -- are in registers by then (RH_DERIVE_EARLY_* in roger_hip.hip moves theta_ac,
+// lambda_bc and ha forward).  rew's "value before" only survives where theta_pwp is NaN: 0 here, and the check that sets the wave's
+// bit (k_param_mask) compares every result with the planes bit for bit.
+RH_DEV void rd_rt_evapotranspiration(Col &c, const Consts &K) {
+    const double mk = (double)c.maskCatch;
+    h_der_porosity(c, mk);
+    h_der_evap_depth(c, K, 0.0, mk);
+    h_der_S_ac_rz(c, c.z_root, mk);
+}
+RH_DEV void rd_rt_inf_matrix(Col &c, const Consts &K) {
+    const double mk = (double)c.maskCatch;
+    h_der_wfs(c, mk);
+    h_der_S_ufc_rz(c, c.z_root, mk);
+}
+RH_DEV void rd_rt_inf_macropores(Col &c, const Consts &K) { h_der_S_ac_ufc_ss(c, c.z_root, (double)c.maskCatch); }
+RH_DEV void rd_rt_subsurface_runoff(Col &c, const Consts &K) { h_der_n_salv(c, K, (double)c.maskCatch); }
+RH_DEV void rd_rt_storage(Col &c, const Consts &K) {
+    const double mk = (double)c.maskCatch;
+    h_der_m_bc(c, K, mk);
+    h_der_S_pwp_rz(c, c.z_root, mk);
+    h_der_S_pwp_ss_s(c, c.z_root, mk);
+}
+// all of them at once (the check kernel)
+RH_DEV void rd_all(Col &c, const Consts &K) {
+    rd_rt_evapotranspiration(c, K);
+    rd_rt_inf_matrix(c, K);
+    rd_rt_inf_macropores(c, K);
+    rd_rt_subsurface_runoff(c, K);
+    rd_rt_storage(c, K);
+}
+RH_DEV void rd_rt_subsurface_runoff_lateral(Col &c, const Consts &K) { rd_rt_subsurface_runoff(c, K); }
 
 // soil.py:560-641: horizontal macropore flow velocity per layer from the slope look-up table
 // lut_mlms (rows: slope in percent, then m/h of layers 8..1), converted to mm/h

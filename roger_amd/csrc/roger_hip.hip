@@ -116,6 +116,12 @@ struct DevState {
     const int *station_idx;
     double *forc_multi;
 
+    // Parameter planes of the fused step (RH_PARAM_BITS): one 64-bit word per wavefront's 64 columns.  Bit b: the wave's columns hold
+    // ONE value of parameter plane b, so the wave reads one element instead of 512 bytes; bit 63: the planes of RH_DERIVED_FIELDS hold
+    // exactly what the stages' rd_* functions compute from the primaries, so they are derived instead of loaded.  Written by
+    // k_param_mask whenever somebody other than the fused kernel may have changed planes; all zeros = the plain loads.
+    const unsigned long long *pmask;
+
     const double *mlms;                // lut_mlms rows (oneD model), device copy
     int64_t mlms_rows;
     int max_slope_per;
@@ -133,6 +139,9 @@ struct HostExport {
 };
 
 struct rh_ctx {
+    unsigned long long *pmask_buf = nullptr;   // DevState::pmask
+    bool pmask_valid = false;                   // ... describes the planes as they are now
+    int pmask_flags = 3;                        // bit 0: uniform loads, bit 1: derived parameters (RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE clear them)
     HostExport *hexp = nullptr;      // pinned + mapped
     unsigned long long hexp_seq = 0;
     rh_config cfg;
@@ -1136,6 +1145,100 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 // ---------------------------------------------------------------------------------------------
 #define LD(name) rh_ld(a, RH_P_##name, i, c.name);
 #define ST(name) rh_st(a, RH_P_##name, i, c.name);
+
+// ---- parameter planes: uniform over a wave -> one element; derivable -> not loaded at all (DevState::pmask) ----
+constexpr int rh_param_bit(int plane) {
+    switch (plane) {
+#define RH_PB(name, bit) case RH_P_##name: return bit;
+        RH_PARAM_BITS(RH_PB)
+#undef RH_PB
+        default: return -1;
+    }
+}
+constexpr bool rh_param_derived(int plane) {
+    switch (plane) {
+#define RH_PD(name) case RH_P_##name:
+        RH_DERIVED_FIELDS(RH_PD)
+#undef RH_PD
+        return true;
+        default: return false;
+    }
+}
+#if defined(RH_CENSUS)   // tools/isa_census.py: the wave's word as a compile-time constant (RH_CENSUS_PMASK), so that the count is of ONE path
+#ifndef RH_CENSUS_PMASK
+#define RH_CENSUS_PMASK 0ull
+#endif
+#endif
+// Load of plane PLANE for the LAZY kernels: a parameter plane whose bit is set in the wave's word is read at the wave's FIRST column by
+// every lane (one 64-byte sector from HBM instead of 512 bytes: the values are equal, k_param_mask compared them bit for bit); a
+// derived parameter is not loaded when bit 63 is set (the stage's rd_* function assigns it).
+template <int PLANE, typename T>
+RH_DEV void rh_ld_p(const Arena &a, int64_t i, T &dst, unsigned long long um) {
+    constexpr int bit = rh_param_bit(PLANE);
+    if constexpr (bit < 0) {
+        rh_ld(a, PLANE, i, dst);
+    } else {
+        if constexpr (rh_param_derived(PLANE)) {
+            if (um >> 63) return;
+        }
+        const bool uni = (um >> bit) & 1ull;
+#if RH_TILED
+        const int tile = __builtin_amdgcn_readfirstlane((int)(i >> RH_TILE_SHIFT));
+        const int piece = __builtin_amdgcn_readfirstlane((int)(i & (RH_TILE_CELLS - 1)) & ~63);
+        const T *p = reinterpret_cast<const T *>(a.base + (size_t)tile * a.stride + (size_t)PLANE * RH_SLOT_BYTES) + piece + (uni ? 0 : (int)(i & 63));
+#else
+        const T *p = reinterpret_cast<const T *>(a.base + (size_t)PLANE * a.stride) + (uni ? (i & ~(int64_t)63) : i);
+#endif
+        dst = (RH_NT & 1) ? __builtin_nontemporal_load(p) : *p;
+    }
+}
+#define LDP(name) rh_ld_p<RH_P_##name>(a, i, c.name, um);
+RH_DEV unsigned long long bits_of(double v) { return (unsigned long long)__double_as_longlong(v); }
+RH_DEV unsigned long long bits_of(int v) { return (unsigned long long)(unsigned)v; }
+// The wave's word of DevState::pmask.  flags bit 0: uniformity bits, bit 1: the derive bit.  One thread per column; a wave whose upper
+// lanes lie beyond the grid compares its active lanes only (the uniform load reads the wave's first column, which exists).
+__global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, unsigned long long *out, int flags) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    const bool active = i < a.n;
+    const int64_t ii = active ? i : a.n - 1;   // (a lane beyond the grid looks at the last column: it does not vote)
+    if ((int64_t)blockIdx.x * RH_BLOCK + (threadIdx.x & ~63) >= a.n) return;   // the whole wave lies beyond the grid
+    Col c;
+    unsigned long long um = 0;
+#define RH_PU(name, bit)                                                                                       \
+    {                                                                                                          \
+        rh_ld(a, RH_P_##name, ii, c.name);                                                                     \
+        const unsigned long long mine = bits_of(c.name);                                                       \
+        const unsigned long long first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) | \
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)mine);                  \
+        if (__ballot(active && mine != first) == 0) um |= 1ull << bit;                                         \
+    }
+    RH_PARAM_BITS(RH_PU)
+#undef RH_PU
+    // a plane the monthly surface parameters assign stays uniform over the wave only if what they are computed from is
+    unsigned long long in_bits = 0, mon_bits = 0;
+#define RH_PB(name, bit) const unsigned long long pbit_##name = 1ull << bit;
+    RH_PARAM_BITS(RH_PB)
+#undef RH_PB
+#define RH_PI(name) in_bits |= pbit_##name;
+    RH_PARAM_MONTHLY_INPUTS(RH_PI)
+#undef RH_PI
+#define RH_PM(name) mon_bits |= pbit_##name;
+    RH_PARAM_MONTHLY(RH_PM)
+#undef RH_PM
+    if ((um & in_bits) != in_bits) um &= ~mon_bits;
+    if (!(flags & 1)) um = 0;
+    if (flags & 2) {
+        // the derived parameters: what the stages would compute from the primaries (already in c) against what the planes hold
+        Col d = c;
+        rd_all(d, D->K);
+        bool same = true;
+#define RH_PD(name) same = same && bits_of(d.name) == bits_of(c.name);
+        RH_DERIVED_FIELDS(RH_PD)
+#undef RH_PD
+        if (__ballot(active && !same) == 0) um |= 1ull << 63;
+    }
+    if ((threadIdx.x & 63) == 0) out[i >> 6] = um;
+}
 #define ROT(name) rh_st(a, RH_P_##name##_m1, i, c.name);  // tau -> taum1 copy of after_timestep, done early
 
 // THE hot kernel.  Loads every plane the step reads once, runs the whole step in registers,
@@ -1155,10 +1258,12 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
 #define AL(xm1, x) c.xm1 = c.x;
 #define RH_LOADS(seq, rt)                                          \
     if constexpr (LAZY) {                                          \
-        RH_SEQ_##seq##_LLOAD_##rt(LD) RH_SEQ_##seq##_ALIAS_##rt(AL) \
+        RH_SEQ_##seq##_LLOAD_##rt(LDP) RH_SEQ_##seq##_ALIAS_##rt(AL) \
     } else {                                                       \
         RH_SEQ_##seq##_LOAD_##rt(LD)                               \
     }
+// the stage's derived parameters (rh_physics.h rd_<stage>), where the wave's planes were found to hold exactly these values
+#define RH_DERIVE(rt) if (LAZY && (um >> 63)) rd_##rt(c, K);
 #ifdef RH_CENSUS   // (tools/isa_census.py counts what the sparse kernel stores when no accumulator asks for more)
 #define STK(name)
 #else
@@ -1189,26 +1294,26 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     RH_LOADS(seq, rt_evapotranspiration) RH_PIN                                                                 \
     rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
     RH_LOADS(seq, rt_snow) RH_PIN                                                                               \
-    rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)                                   \
+    RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)  \
     RH_LOADS(seq, rt_inf_events) RH_PIN                                                                         \
     rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
     q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
     RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                         \
     rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
     RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                                     \
-    rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                                                \
+    RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                       \
     RH_LOADS(seq, rt_inf_cracks) RH_PIN                                                                         \
-    rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)                                        \
+    RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)           \
     RH_LOADS(seq, rt_inf_finish) RH_PIN                                                                         \
     rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
     RH_LOADS(seq, sub_rt) RH_PIN                                                                                \
     rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
     RH_LOADS(seq, rt_capillary_rise) RH_PIN                                                                     \
-    sub_call; RH_STORES(seq, sub_rt)                                                                     \
+    RH_DERIVE(sub_rt) sub_call; RH_STORES(seq, sub_rt)                                                   \
     RH_LOADS(seq, rt_storage) RH_PIN                                                                            \
     rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
     RH_LOADS(seq, ne_rt) RH_PIN                                                                                 \
-    rt_storage(c, X); RH_STORES(seq, rt_storage)                                                         \
+    RH_DERIVE(rt_storage) rt_storage(c, X); RH_STORES(seq, rt_storage)                                   \
     RH_LOADS(seq, at_rt) RH_PIN                                                                                 \
     bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
     at_call; RH_STORES(seq, at_rt)
@@ -1232,17 +1337,17 @@ __global__ void k_zero_words(DevState *D) { D->words[0] = D->words[1] = D->words
     RH_DBG_SUM(q = summary_bits_pt(c.prec, c.ta, K);)                                                    \
     MON_LOADS MON_RUN                                                                                    \
     RH_STAGE(seq, rt_interception, rt_interception(c, K))                                                \
-    RH_STAGE(seq, rt_evapotranspiration, rt_evapotranspiration(c, K))                                    \
+    RH_STAGE(seq, rt_evapotranspiration, RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K))   \
     RH_STAGE(seq, rt_snow, rt_snow(c, K, X))                                                             \
     RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);)                       \
     RH_STAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                 \
-    RH_STAGE(seq, rt_inf_matrix, rt_inf_matrix(c, K, X))                                                 \
-    RH_STAGE(seq, rt_inf_macropores, rt_inf_macropores(c, K, X))                                         \
+    RH_STAGE(seq, rt_inf_matrix, RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X))                        \
+    RH_STAGE(seq, rt_inf_macropores, RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X))            \
     RH_STAGE(seq, rt_inf_cracks, rt_inf_cracks(c, K, X))                                                 \
     RH_STAGE(seq, rt_inf_finish, rt_inf_finish(c, K, X))                                                 \
-    RH_STAGE(seq, sub_rt, sub_call)                                                                      \
+    RH_STAGE(seq, sub_rt, RH_DERIVE(sub_rt) sub_call)                                                    \
     RH_STAGE(seq, rt_capillary_rise, rt_capillary_rise(c, X))                                            \
-    RH_STAGE(seq, rt_storage, rt_storage(c, X))                                                          \
+    RH_STAGE(seq, rt_storage, RH_DERIVE(rt_storage) rt_storage(c, X))                                    \
     RH_STAGE(seq, ne_rt, bad = ne_call)                                                                  \
     RH_STAGE(seq, at_rt, at_call)
 #endif
@@ -1269,6 +1374,16 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
     const Consts K = D->K;
     const StepCtx X = *Xp;
     Col c;
+    // the wave's word of the parameter planes (uniform / derivable; zero: plain loads) -- wave-uniform, in scalar registers
+    unsigned long long um = 0;
+    if constexpr (LAZY) {
+#ifdef RH_CENSUS
+        um = RH_CENSUS_PMASK;
+#else
+        const unsigned long long w = D->pmask[__builtin_amdgcn_readfirstlane((int)(i >> 6))];
+        um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+#endif
+    }
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     if (D->per_cell && X.sel_w >= 0) {
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
@@ -1836,6 +1951,7 @@ static void materialise_m1(rh_ctx *ctx) {
 // somebody other than the fused kernel is about to change planes: X_m1 == X cannot be taken for granted afterwards
 static void planes_touched(rh_ctx *ctx) {
     materialise_m1(ctx);
+    ctx->pmask_valid = false;   // (a parameter plane may be about to change: the wave words are formed again before the next lazy step)
     ctx->rot_consistent = false;
     ctx->summary_valid = false;
     ctx->routed_summary = false;
@@ -2113,6 +2229,15 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     }
     if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
+    {   // the parameter words of the fused step's wavefronts (all zero: plain loads) and their address in the control block
+        const size_t words = ((size_t)ctx->n + 63) / 64;
+        if ((e = hipMalloc((void **)&ctx->pmask_buf, words * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(parameter words)");
+        if ((e = hipMemsetAsync(ctx->pmask_buf, 0, words * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+        if ((e = hipMemcpyAsync(&ctx->dev->pmask, &ctx->pmask_buf, sizeof(ctx->pmask_buf), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return bail(e, "hipMemcpy(pmask)");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+        ctx->pmask_flags = (std::getenv("RH_NO_PARAM_UNIFORM") ? 0 : 1) | (std::getenv("RH_NO_PARAM_DERIVE") ? 0 : 2);
+    }
     if ((e = hipHostMalloc((void **)&ctx->hexp, sizeof(HostExport), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(scalar export block)");
     std::memset(ctx->hexp, 0, sizeof(HostExport));
     if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -2191,6 +2316,7 @@ void rh_destroy(rh_ctx *ctx) {
     release_comm(ctx);
     if (ctx->dev) (void)hipFree(ctx->dev);
     if (ctx->hexp) (void)hipHostFree(ctx->hexp);
+    if (ctx->pmask_buf) (void)hipFree(ctx->pmask_buf);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -2677,6 +2803,11 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     const bool sparse = lazy && ctx->sparse_next && monthly < 0;   // (planes an accumulator reads are kept: DevState::keep, the KEEP variant)
     const bool keep = sparse && ctx->diag_reads_sparse;
     ctx->sparse_next = false;
+    if (lazy && !ctx->pmask_valid) {   // the lazy kernels read the parameter planes through the wave words: formed from the planes as they are
+        hipLaunchKernelGGL(k_param_mask, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, ctx->pmask_buf, ctx->pmask_flags);
+        CHECK_LAUNCH(ctx);
+        ctx->pmask_valid = true;
+    }
 #define RH_LAUNCH_STEP(MODE)                                          \
     do {                                                              \
         if (MODE == 2 && lat && keep)                                 \
@@ -3494,6 +3625,39 @@ int rh_plane_is_pure_output(int model, int plane) {
     return (plane >= 0 && plane < RH_NPLANES && model >= 0 && model <= 2) ? pure_output_planes()[model][plane] : -1;
 }
 int64_t rh_sparse_steps(const rh_ctx *ctx) { return ctx ? ctx->call_sparse_steps : 0; }
+int rh_param_stats(rh_ctx *ctx, double *derived_fraction, double *uniform_bytes_per_cell) {
+    if (!ctx || !derived_fraction || !uniform_bytes_per_cell) return ctx ? fail(ctx, RH_ERR_ARG, "rh_param_stats: null pointer") : RH_ERR_ARG;
+    if (!ctx->pmask_valid) {
+        hipLaunchKernelGGL(k_param_mask, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pmask_buf, ctx->pmask_flags);
+        CHECK_LAUNCH(ctx);
+        ctx->pmask_valid = true;
+    }
+    const size_t words = ((size_t)ctx->n + 63) / 64;
+    std::vector<unsigned long long> w(words);
+    HIPCHK(ctx, hipMemcpyAsync(w.data(), ctx->pmask_buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the parameter planes the step loads unless the month changes, by element size; the derived ones apart
+    unsigned long long f64_bits = 0, i32_bits = 0, derived_bits = 0;
+#define RH_PB(name, bit) const unsigned long long pbit_##name = 1ull << bit;
+    RH_PARAM_BITS(RH_PB)
+#undef RH_PB
+#define RH_PL(name) (PLANE_IS_INT[RH_P_##name] ? i32_bits : f64_bits) |= pbit_##name;
+    if (ctx->cfg.enable_lateral_flow) { RH_PARAM_LOADED_ONED(RH_PL) } else { RH_PARAM_LOADED_SVAT(RH_PL) }
+#undef RH_PL
+#define RH_PD(name) derived_bits |= pbit_##name;
+    RH_DERIVED_FIELDS(RH_PD)
+#undef RH_PD
+    double derived = 0, bytes = 0;
+    for (size_t k = 0; k < words; ++k) {
+        const bool der = (w[k] >> 63) & 1ull;
+        derived += der ? 1 : 0;
+        const unsigned long long u = w[k] & (der ? ~derived_bits : ~0ull);   // (a derived plane is not loaded at all)
+        bytes += 8.0 * __builtin_popcountll(u & f64_bits) + 4.0 * __builtin_popcountll(u & i32_bits);
+    }
+    *derived_fraction = derived / (double)words;
+    *uniform_bytes_per_cell = bytes / (double)words;
+    return RH_OK;
+}
 int rh_step_mode(const rh_ctx *ctx) {
     if (!ctx) return 0;
     return (ctx->m1_stale ? RH_STEP_MODE_LAZY : 0) | (ctx->pending_valid ? RH_STEP_MODE_TAIL : 0) | (ctx->last_sparse ? RH_STEP_MODE_SPARSE : 0);

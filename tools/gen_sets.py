@@ -61,7 +61,7 @@ def split_args(s):
 
 def parse_functions(src):
     funcs = {}
-    for m in re.finditer(r"RH_DEV\s+[\w\s]+?\b((?:rt|h)_\w+)\s*\(([^)]*)\)\s*\{", src):
+    for m in re.finditer(r"RH_DEV\s+[\w\s]+?\b((?:rt|rd|h)_\w+)\s*\(([^)]*)\)\s*\{", src):
         name, params = m.group(1), m.group(2)
         i = m.end()
         depth = 1
@@ -97,7 +97,7 @@ def analyse(funcs):
         mention = set(re.findall(r"\bc\.(\w+)", body))
         write = set(re.findall(r"\bc\.(\w+)\s*(?:=(?!=)|\+=|-=|\*=|/=)", body))
         calls = []
-        for m in re.finditer(r"\b((?:rt|h)_\w+)\s*\(", body):
+        for m in re.finditer(r"\b((?:rt|rd|h)_\w+)\s*\(", body):
             callee = m.group(1)
             if callee not in funcs:
                 continue
@@ -123,7 +123,7 @@ def analyse(funcs):
             write |= w2
         return mention, write
 
-    return {name: closure(name) for name in funcs if name.startswith("rt_")}
+    return {name: closure(name) for name in funcs if name.startswith(("rt_", "rd_"))}
 
 
 # The fused step as a sequence of stages.  For a sequence the generator emits per-stage sets so that
@@ -191,6 +191,14 @@ def main():
     sets = analyse(funcs)
     pairs = rotation_pairs(funcs)
     lines = ["// GENERATED by tools/gen_sets.py from rh_physics.h -- do not edit.", "#pragma once", ""]
+    # Parameters the fused step DERIVES instead of loading (rd_<stage> in rh_physics.h: the stage's own evaluation of what the setup
+    # kernel rt_params_soil computed from the primaries): rd_writes[stage] = the planes, rd_reads[stage] = the primaries it needs.
+    rd = {name[3:]: sets.pop(name) for name in [n for n in sets if n.startswith("rd_")]}
+    rd.pop("all", None)
+    rd["rt_subsurface_runoff_lateral"] = rd["rt_subsurface_runoff"]   # (the oneD stage in the same position)
+    rd_writes = {rt: w for rt, (m, w) in rd.items()}
+    rd_reads = {rt: m - w for rt, (m, w) in rd.items()}
+    derived = set().union(*rd_writes.values())
     for name in sorted(sets):
         mention, write = sets[name]
         unknown = (mention | write) - set(fields)
@@ -273,10 +281,19 @@ def main():
                 continue
             first_write = next((i for i, rt in enumerate(stages) if x in sets[rt][1]), last)
             alias_at.setdefault(min(need, first_write), []).append((xm1, x))
+        # a stage that derives parameters (rd_<stage>) is the first to mention each of them (or comes before it) -- the derived value then
+        # lives about as long as the loaded one did --, no stage assigns one, and the primaries it reads are loaded with the stage's own planes at the latest
+        for i, rt in enumerate(stages):
+            for f in sorted(rd_writes.get(rt, ())):
+                first = next(j for j, r in enumerate(stages) if f in sets[r][0])
+                if first < i:   # (theta_fc is derived a stage early: tew needs it)
+                    sys.exit(f"sequence {seq}: {f} is derived by rd_{rt} (stage {i}) but mentioned before, by {stages[first]} (stage {first})")
+        if derived & all_w:
+            sys.exit(f"sequence {seq}: derived parameters are assigned by a stage: {sorted(derived & all_w)}")
         resident_l = set()
         for i, rec in enumerate(recs):
             mention, write = sets[rec["rt"]]
-            need_l = (mention - rotated) | {x for _, x in alias_at.get(i, [])}
+            need_l = (mention - rotated) | {x for _, x in alias_at.get(i, [])} | rd_reads.get(rec["rt"], set())
             rec["lld"] = need_l - resident_l
             resident_l |= need_l
             rec["lst"] = rec["st"] - rotated
@@ -355,6 +372,39 @@ def main():
     for model in ("svat", "oned"):
         lines.append(f"// planes the fused {model} step only produces ({len(sparse[model])}): not stored by the steps of an rh_run_steps call that another step follows")
         lines.append(f"#define RH_SPARSE_FIELDS_{model.upper()}(X) " + " ".join(f"X({n})" for n in sorted(sparse[model], key=order.get)))
+    lines.append("")
+    # Parameter planes of the fused step: read by a stage, assigned by none (static) or by the monthly surface parameters only.  A wave
+    # whose 64 columns hold ONE value of such a plane reads one element instead of 512 bytes (DevState::pmask, k_param_mask): bit b of
+    # the wave's word.  A monthly plane keeps its bit only while the inputs of rt_params_surface are uniform over the wave as well.
+    m_all, w_mon, w_other = set(), set(), set()
+    for seq, stages in SEQUENCES.items():
+        for rt in stages:
+            mention, write = sets[rt]
+            m_all |= mention
+            if rt == "rt_params_surface":
+                w_mon |= write
+            else:
+                w_other |= write
+    static = m_all - w_mon - w_other
+    monthly = (w_mon - w_other) & m_all
+    monthly_inputs = (sets["rt_params_surface"][0] - sets["rt_params_surface"][1]) - {"ta"}   # (ta feeds swe_top_tot only, a state)
+    if not monthly_inputs <= static:
+        sys.exit(f"rt_params_surface reads planes that are no static parameters: {sorted(monthly_inputs - static)}")
+    if not derived <= static:
+        sys.exit(f"derived parameters that are not static parameters of the step: {sorted(derived - static)}")
+    bits = sorted(static | monthly, key=order.get)
+    if len(bits) > 62:
+        sys.exit(f"{len(bits)} parameter planes do not fit the wave's 64-bit word (bit 63: derived parameters valid)")
+    lines.append(f"// parameter planes of the fused step ({len(static)} static, {len(monthly)} assigned by the monthly surface parameters only): X(name, bit)")
+    lines.append("#define RH_PARAM_BITS(X) " + " ".join(f"X({n}, {b})" for b, n in enumerate(bits)))
+    lines.append("#define RH_PARAM_MONTHLY(X) " + " ".join(f"X({n})" for n in sorted(monthly, key=order.get)))
+    lines.append("#define RH_PARAM_MONTHLY_INPUTS(X) " + " ".join(f"X({n})" for n in sorted(monthly_inputs, key=order.get)))
+    for model, seq in (("SVAT", "step"), ("ONED", "step_lateral")):   # what the step loads of them unless the month changes
+        loaded = set().union(*[sets[rt][0] for rt in SEQUENCES[seq]]) & (static | monthly)
+        lines.append(f"#define RH_PARAM_LOADED_{model}(X) " + " ".join(f"X({n})" for n in sorted(loaded, key=order.get)))
+    lines.append(f"// parameters a stage of the fused step derives from the primaries instead of loading them ({len(derived)})")
+    lines.append("#define RH_DERIVED_FIELDS(X) " + " ".join(f"X({n})" for n in sorted(derived, key=order.get)))
+    lines.append("#define RH_DERIVE_PRIMARIES(X) " + " ".join(f"X({n})" for n in sorted(set().union(*rd_reads.values()), key=order.get)))
     lines.append("")
     # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x
     lines.append("// tau -> taum1 rotation of after_timestep (h_rotate): " + str(len(pairs)) + " pairs")

@@ -25,9 +25,9 @@ OUT = os.path.join(CSRC, "rh_step_bytes.json")
 WIDTH = {"ubyte": 1, "sbyte": 1, "ushort": 2, "sshort": 2, "short": 2, "byte": 1, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}
 
 
-def census():
+def census(extra=()):
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run([HIPCC] + FLAGS + ["-DRH_CENSUS", "-S", "--cuda-device-only", os.path.join(CSRC, "roger_hip.hip"), "-o", os.path.join(tmp, "k.s")],
+        subprocess.run([HIPCC] + FLAGS + ["-DRH_CENSUS"] + list(extra) + ["-S", "--cuda-device-only", os.path.join(CSRC, "roger_hip.hip"), "-o", os.path.join(tmp, "k.s")],
                        check=True, stderr=subprocess.DEVNULL)
         txt = open(os.path.join(tmp, "k.s")).read()
     out = {}
@@ -64,13 +64,31 @@ def census():
 
 
 if __name__ == "__main__":
-    rec = census()
+    # The lazy kernels read the parameter planes through the wave's word (DevState::pmask): counted with the word as a compile-time
+    # constant -- bit 63 set (the derived parameters are not loaded: what runs after a setup whose planes are what the setup kernels
+    # computed), all zero (every parameter loaded), and with the parameter planes' loads compiled out (what is left is state).
+    rec = census(["-DRH_CENSUS_PMASK=0x8000000000000000ull"])
+    plain = census()
+    sets_txt = open(os.path.join(CSRC, "rh_sets.inc")).read()
+    fields_txt = open(os.path.join(REPO, "include", "rh_fields.def")).read()
+    ints = set(re.findall(r"RH_FIELD\((\w+),\s*I32", fields_txt))
+    listed = lambda macro: re.findall(r"X\((\w+)\)", re.search(rf"#define {macro}\(X\) (.*)", sets_txt).group(1))   # noqa: E731
+    derived = set(listed("RH_DERIVED_FIELDS"))
+    for k, v in rec.items():
+        if v["load_bytes"] != plain[k]["load_bytes"]:
+            v["load_bytes_all_parameters_loaded"] = plain[k]["load_bytes"]
+            # the parameter planes among the loads (tools/gen_sets.py: RH_PARAM_LOADED_*), the derived ones left out
+            names = listed("RH_PARAM_LOADED_ONED" if "oned" in k else "RH_PARAM_LOADED_SVAT")
+            v["parameter_load_bytes"] = sum(4 if n in ints else 8 for n in names if n not in derived)
     for k in sorted(rec):
         print(f"{k:28s} loads {rec[k]['load_bytes']:5d} B  stores {rec[k]['store_bytes']:5d} B  total {rec[k]['load_bytes'] + rec[k]['store_bytes']:5d} B per column and launch"
               )
     # the non-monthly pipeline (mode 0) is what a step executes unless the month changes; mode 2 holds both pipelines
-    keep = {k[6:]: {"load_bytes": v["load_bytes"], "store_bytes": v["store_bytes"]} for k, v in rec.items() if k.startswith("mode0_")}
-    keep["_note"] = "bytes one column loads / stores per fused step (k_step, non-monthly pipeline), counted from the gfx950 ISA by tools/isa_census.py"
+    keep = {k[6:]: {kk: vv for kk, vv in v.items() if kk != "in_loops"} for k, v in rec.items() if k.startswith("mode0_")}
+    keep["_note"] = ("bytes one column loads / stores per fused step (k_step, non-monthly pipeline), counted from the gfx950 ISA by tools/isa_census.py; "
+                     "lazy / sparse variants: load_bytes with the derived parameters not loaded (the wave's bit 63 set), "
+                     "load_bytes_all_parameters_loaded with it clear, parameter_load_bytes = the part of load_bytes that is parameter planes "
+                     "(read as ONE element per wave and plane where the wave's columns hold one value)")
     txt = json.dumps(keep, indent=1, sort_keys=True) + "\n"
     if not os.path.exists(OUT) or open(OUT).read() != txt:
         open(OUT, "w").write(txt)
