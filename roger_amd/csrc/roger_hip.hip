@@ -1380,7 +1380,8 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
 #ifdef RH_CENSUS
         um = RH_CENSUS_PMASK;
 #else
-        const unsigned long long w = D->pmask[__builtin_amdgcn_readfirstlane((int)(i >> 6))];
+        const unsigned long long *pm = D->pmask;
+        const unsigned long long w = pm ? pm[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : 0ull;
         um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
 #endif
     }
@@ -2229,7 +2230,10 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     }
     if ((e = hipMalloc((void **)&ctx->stage_buf, (size_t)ctx->n * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(staging plane)");
     if ((e = hipMalloc((void **)&ctx->dev, sizeof(DevState))) != hipSuccess) return bail(e, "hipMalloc(DevState)");
-    {   // the parameter words of the fused step's wavefronts (all zero: plain loads) and their address in the control block
+    if ((e = hipHostMalloc((void **)&ctx->hexp, sizeof(HostExport), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(scalar export block)");
+    std::memset(ctx->hexp, 0, sizeof(HostExport));
+    if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    {   // the parameter words of the fused step's wavefronts (all zero: plain loads; AFTER the control block was cleared) and their address in the control block
         const size_t words = ((size_t)ctx->n + 63) / 64;
         if ((e = hipMalloc((void **)&ctx->pmask_buf, words * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(parameter words)");
         if ((e = hipMemsetAsync(ctx->pmask_buf, 0, words * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -2238,9 +2242,6 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
         ctx->pmask_flags = (std::getenv("RH_NO_PARAM_UNIFORM") ? 0 : 1) | (std::getenv("RH_NO_PARAM_DERIVE") ? 0 : 2);
     }
-    if ((e = hipHostMalloc((void **)&ctx->hexp, sizeof(HostExport), hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(scalar export block)");
-    std::memset(ctx->hexp, 0, sizeof(HostExport));
-    if ((e = hipMemsetAsync(ctx->dev, 0, sizeof(DevState), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     {
         static const long long no_limit = -1;
         if ((e = hipMemcpyAsync(&ctx->dev->t_end, &no_limit, sizeof(no_limit), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
@@ -3588,6 +3589,7 @@ int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b) {
     std::swap(a->arena_alloc, b->arena_alloc);
     std::swap(a->arena_offset, b->arena_offset);
     std::swap(a->arena_pad, b->arena_pad);
+    a->pmask_valid = b->pmask_valid = false;   // (the wave words describe the planes of the arena a context steps on)
     return RH_OK;
 }
 

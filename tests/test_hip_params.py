@@ -106,3 +106,48 @@ def test_parameter_changed_between_calls_is_seen(native):  # noqa: F811
     stats = run_both(native, "svat_uniform_rain", edit=edit)
     assert stats[0][0] == 1.0 and stats[-1][0] < 1.0, stats
     assert stats[1][1] < stats[0][1], stats
+
+
+@pytest.mark.parametrize("lateral", [False, True])
+@pytest.mark.parametrize("layout", ["random", "blocks"])
+def test_many_wavefronts_with_a_ragged_last_one(lateral, layout):
+    """1 000 columns = 15 full wavefronts and one of 40 lanes, heterogeneous parameters drawn per column ("random": no wave is uniform)
+    or per block of 96 columns ("blocks": soil / land-use units -- some waves uniform, some straddle a boundary), 150 device-driven steps
+    over the combo forcing incl. a month change: fast and plain contexts agree on every plane, bit for bit."""
+    from roger_amd.forcing import combo_forcing
+    from roger_amd.svat import create_svat, hetero_params
+
+    nx, ny = 40, 25
+    n = nx * ny
+    p = hetero_params(n, seed=5)
+    if layout == "blocks":
+        block = np.arange(n) // 96
+        p = {k: np.asarray(v)[block * 96] for k, v in p.items()}
+    if lateral:
+        p.update(slope=0.05, slope_per=5, dmph=50.0)
+        p["z_soil"] = np.maximum(p["z_soil"], 800.0)
+    forcing = combo_forcing(ndays=45)
+    res, stats = [], []
+    for plain in (False, True):
+        for k in SWITCHES:
+            os.environ.pop(k, None)
+            if plain:
+                os.environ[k] = "1"
+        try:
+            ctx = create_svat(nx, ny, params=p, lateral=lateral)
+        finally:
+            for k in SWITCHES:
+                os.environ.pop(k, None)
+        ctx.set_forcing_series(forcing)
+        ctx.run_steps(100)
+        ctx.run_steps(50)
+        stats.append(ctx.param_stats())
+        s = ctx.get_scalars()
+        assert s.sanity_ok == 1 and s.itt == 150
+        res.append({nm: ctx.download(nm) for nm, _ in ctx.planes[: ctx.planes_held]})
+        ctx.close()
+    assert stats[1] == (0.0, 0.0) and stats[0][0] == 1.0
+    if layout == "blocks":
+        assert stats[0][1] > 40.0, stats     # the waves inside a block read their parameters as one element
+    for nm in res[0]:
+        np.testing.assert_array_equal(res[0][nm], res[1][nm], err_msg=nm)
