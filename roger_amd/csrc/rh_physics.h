@@ -902,6 +902,20 @@ RH_DEV double h_h_bc(double ha, double theta, double theta_sat, double lambda_bc
     return ha / RH_POW(theta / theta_sat, 1 / lambda_bc);
 }
 
+// Conductivity and suction of the root zone and of the subsoil from their water contents (root_zone.py:113-166, subsoil.py:84-137): the
+// last thing a step computes of them and the first thing the NEXT step's percolation and capillary rise read.  A lazy fused step (the
+// planes were last touched by a complete step: roger_hip.hip) therefore evaluates these helpers from theta_rz / theta_ss in front of its
+// subsurface stage instead of loading the five planes, and a sparse step does not store them (rl_rt_subsurface_runoff below).
+RH_DEV void h_kh_rz(Col &c, double mk) {
+    c.k_rz = h_k_bc(c.ks, c.theta_rz, c.theta_sat, c.m_bc) * mk;
+    c.h_rz = h_h_bc(c.ha, c.theta_rz, c.theta_sat, c.lambda_bc) * mk;
+}
+RH_DEV void h_kh_ss(Col &c, double mk) {
+    c.ks_ss = c.ks;
+    c.k_ss = h_k_bc(c.ks, c.theta_ss, c.theta_sat, c.m_bc) * mk;
+    c.h_ss = h_h_bc(c.ha, c.theta_ss, c.theta_sat, c.lambda_bc) * mk;
+}
+
 RH_DEV void rt_storage(Col &c, const StepCtx &X) {
     const double mk = (double)c.maskCatch;
     c.S_sur = (c.S_int_top + c.S_int_ground + c.S_dep + c.S_snow + c.z0) * mk;
@@ -915,14 +929,11 @@ RH_DEV void rt_storage(Col &c, const StepCtx &X) {
     } else {
         c.irr_demand = 0.0;
     }
-    c.k_rz = h_k_bc(c.ks, c.theta_rz, c.theta_sat, c.m_bc) * mk;
-    c.h_rz = h_h_bc(c.ha, c.theta_rz, c.theta_sat, c.lambda_bc) * mk;
+    h_kh_rz(c, mk);
     c.S_ss = (c.S_pwp_ss + c.S_fp_ss + c.S_lp_ss) * mk;
     c.dS_ss = (c.S_ss - c.S_ss_m1) * mk;
     c.theta_ss = ((c.S_fp_ss + c.S_lp_ss) / (c.z_soil - c.z_root) + c.theta_pwp) * mk;
-    c.ks_ss = c.ks;
-    c.k_ss = h_k_bc(c.ks, c.theta_ss, c.theta_sat, c.m_bc) * mk;
-    c.h_ss = h_h_bc(c.ha, c.theta_ss, c.theta_sat, c.lambda_bc) * mk;
+    h_kh_ss(c, mk);
     c.S_fp_s = (c.S_fp_rz + c.S_fp_ss) * mk;
     c.S_lp_s = (c.S_lp_rz + c.S_lp_ss) * mk;
     c.S_s = (c.S_pwp_s + c.S_fp_s + c.S_lp_s) * mk;
@@ -1234,10 +1245,13 @@ RH_DEV void rd_rt_inf_matrix(Col &c, const Consts &K) {
     h_der_S_ufc_rz(c, c.z_root, mk);
 }
 RH_DEV void rd_rt_inf_macropores(Col &c, const Consts &K) { h_der_S_ac_ufc_ss(c, c.z_root, (double)c.maskCatch); }
-RH_DEV void rd_rt_subsurface_runoff(Col &c, const Consts &K) { h_der_n_salv(c, K, (double)c.maskCatch); }
+RH_DEV void rd_rt_subsurface_runoff(Col &c, const Consts &K) {
+    const double mk = (double)c.maskCatch;
+    h_der_n_salv(c, K, mk);
+    h_der_m_bc(c, K, mk);   // (rl_rt_subsurface_runoff needs it)
+}
 RH_DEV void rd_rt_storage(Col &c, const Consts &K) {
     const double mk = (double)c.maskCatch;
-    h_der_m_bc(c, K, mk);
     h_der_S_pwp_rz(c, c.z_root, mk);
     h_der_S_pwp_ss_s(c, c.z_root, mk);
 }
@@ -1250,6 +1264,19 @@ RH_DEV void rd_all(Col &c, const Consts &K) {
     rd_rt_storage(c, K);
 }
 RH_DEV void rd_rt_subsurface_runoff_lateral(Col &c, const Consts &K) { rd_rt_subsurface_runoff(c, K); }
+// STATE that a lazy step derives instead of loading (rl_<stage>: every lazy kernel, whatever the wave's word says): conductivity and
+// suction at the water contents the previous step left.  Valid because the previous operation on the planes was a complete step, whose
+// storage stage computed exactly these from the same theta_rz / theta_ss and the same parameters.
+RH_DEV void rl_rt_subsurface_runoff(Col &c, const Consts &K) {
+    const double mk = (double)c.maskCatch;
+    h_kh_rz(c, mk);
+    h_kh_ss(c, mk);
+}
+RH_DEV void rl_rt_subsurface_runoff_lateral(Col &c, const Consts &K) { rl_rt_subsurface_runoff(c, K); }
+RH_DEV void rl_rt_evapotranspiration(Col &c, const Consts &K) {}
+RH_DEV void rl_rt_inf_matrix(Col &c, const Consts &K) {}
+RH_DEV void rl_rt_inf_macropores(Col &c, const Consts &K) {}
+RH_DEV void rl_rt_storage(Col &c, const Consts &K) {}
 
 // soil.py:560-641: horizontal macropore flow velocity per layer from the slope look-up table
 // lut_mlms (rows: slope in percent, then m/h of layers 8..1), converted to mm/h

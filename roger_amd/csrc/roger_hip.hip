@@ -1263,7 +1263,12 @@ __global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, u
         RH_SEQ_##seq##_LOAD_##rt(LD)                               \
     }
 // the stage's derived parameters (rh_physics.h rd_<stage>), where the wave's planes were found to hold exactly these values
-#define RH_DERIVE(rt) if (LAZY && (um >> 63)) rd_##rt(c, K);
+// ... and the state every lazy step derives itself (rl_<stage>: k / h of root zone and subsoil from the previous step's water contents)
+#define RH_DERIVE(rt)                        \
+    if constexpr (LAZY) {                    \
+        if (um >> 63) rd_##rt(c, K);         \
+        rl_##rt(c, K);                       \
+    }
 #ifdef RH_CENSUS   // (tools/isa_census.py counts what the sparse kernel stores when no accumulator asks for more)
 #define STK(name)
 #else
@@ -3623,8 +3628,19 @@ int rh_placement_report(const rh_ctx *ctx, double *ms, int cap) {
     return n;
 }
 
+// planes NO variant of the fused step reads (the sparse kernels additionally leave out the state the next lazy step derives itself:
+// RH_LAZY_DERIVED_FIELDS, which the eager kernel still loads)
 int rh_plane_is_pure_output(int model, int plane) {
-    return (plane >= 0 && plane < RH_NPLANES && model >= 0 && model <= 2) ? pure_output_planes()[model][plane] : -1;
+    static const std::vector<unsigned char> tab[2] = {
+        [] { std::vector<unsigned char> t(RH_NPLANES, 0);
+#define RH_MARK(name) t[RH_P_##name] = 1;
+             RH_NEVER_READ_FIELDS_SVAT(RH_MARK) return t; }(),
+        [] { std::vector<unsigned char> t(RH_NPLANES, 0);
+             RH_NEVER_READ_FIELDS_ONED(RH_MARK)
+#undef RH_MARK
+             return t; }()};
+    if (plane < 0 || plane >= RH_NPLANES || model < 0 || model > 2) return -1;
+    return model == 2 ? pure_output_planes()[2][plane] : tab[model][plane];
 }
 int64_t rh_sparse_steps(const rh_ctx *ctx) { return ctx ? ctx->call_sparse_steps : 0; }
 int rh_param_stats(rh_ctx *ctx, double *derived_fraction, double *uniform_bytes_per_cell) {

@@ -61,7 +61,7 @@ def split_args(s):
 
 def parse_functions(src):
     funcs = {}
-    for m in re.finditer(r"RH_DEV\s+[\w\s]+?\b((?:rt|rd|h)_\w+)\s*\(([^)]*)\)\s*\{", src):
+    for m in re.finditer(r"RH_DEV\s+[\w\s]+?\b((?:rt|rd|rl|h)_\w+)\s*\(([^)]*)\)\s*\{", src):
         name, params = m.group(1), m.group(2)
         i = m.end()
         depth = 1
@@ -97,7 +97,7 @@ def analyse(funcs):
         mention = set(re.findall(r"\bc\.(\w+)", body))
         write = set(re.findall(r"\bc\.(\w+)\s*(?:=(?!=)|\+=|-=|\*=|/=)", body))
         calls = []
-        for m in re.finditer(r"\b((?:rt|rd|h)_\w+)\s*\(", body):
+        for m in re.finditer(r"\b((?:rt|rd|rl|h)_\w+)\s*\(", body):
             callee = m.group(1)
             if callee not in funcs:
                 continue
@@ -123,7 +123,7 @@ def analyse(funcs):
             write |= w2
         return mention, write
 
-    return {name: closure(name) for name in funcs if name.startswith(("rt_", "rd_"))}
+    return {name: closure(name) for name in funcs if name.startswith(("rt_", "rd_", "rl_"))}
 
 
 # The fused step as a sequence of stages.  For a sequence the generator emits per-stage sets so that
@@ -199,6 +199,12 @@ def main():
     rd_writes = {rt: w for rt, (m, w) in rd.items()}
     rd_reads = {rt: m - w for rt, (m, w) in rd.items()}
     derived = set().union(*rd_writes.values())
+    # State a LAZY step derives instead of loading (rl_<stage>: k / h of root zone and subsoil from the water contents the previous step
+    # left): never loaded by the lazy kernels, not stored by the sparse ones.
+    rl = {name[3:]: sets.pop(name) for name in [n for n in sets if n.startswith("rl_")]}
+    rl_writes = {rt: w for rt, (m, w) in rl.items()}
+    rl_reads = {rt: m - w for rt, (m, w) in rl.items()}
+    lazy_derived = set().union(*rl_writes.values())
     for name in sorted(sets):
         mention, write = sets[name]
         unknown = (mention | write) - set(fields)
@@ -217,13 +223,22 @@ def main():
     analyser = liveness.Analyser(funcs)
     rotated_all = {xm1 for xm1, _ in pairs}
 
-    def sparse_of(stages):
+    def sparse_of(stages, lazy=False):
+        if lazy:   # the lazy kernels' own sequence: rl_<stage> in front of the stages that have one
+            stages = [x for rt in stages for x in (["rl_" + rt] if rt in rl else []) + [rt]]
         pure, summ = liveness.pure_outputs(analyser, stages, pairs)
         alias_src = {x for xm1, x in pairs if xm1 in summ.ue}
         return (pure - rotated_all) - alias_src
 
-    sparse = {"svat": sparse_of(SEQUENCES["step"]) & sparse_of(SEQUENCES["step_monthly"]),
-              "oned": sparse_of(SEQUENCES["step_lateral"]) & sparse_of(SEQUENCES["step_lateral_monthly"])}
+    # never_read: what NO variant of the fused kernel reads (rh_plane_is_pure_output: the planes the tests poison); sparse: what the
+    # sparse (lazy) kernels do not store -- the state a lazy step derives itself is not stored, what it derives it from is
+    never_read = {"svat": sparse_of(SEQUENCES["step"]) & sparse_of(SEQUENCES["step_monthly"]),
+                  "oned": sparse_of(SEQUENCES["step_lateral"]) & sparse_of(SEQUENCES["step_lateral_monthly"])}
+    sparse = {"svat": sparse_of(SEQUENCES["step"], True) & sparse_of(SEQUENCES["step_monthly"], True),
+              "oned": sparse_of(SEQUENCES["step_lateral"], True) & sparse_of(SEQUENCES["step_lateral_monthly"], True)}
+    for model in sparse:
+        if not lazy_derived <= sparse[model]:
+            sys.exit(f"{model}: state derived by the lazy kernels is read before that: {sorted(lazy_derived - sparse[model])}")
     for seq, stages in SEQUENCES.items():
         resident, all_m, all_w = set(), set(), set()
         lines.append(f"// sequence {seq}: " + " -> ".join(stages))
@@ -293,7 +308,8 @@ def main():
         resident_l = set()
         for i, rec in enumerate(recs):
             mention, write = sets[rec["rt"]]
-            need_l = (mention - rotated) | {x for _, x in alias_at.get(i, [])} | rd_reads.get(rec["rt"], set())
+            need_l = ((mention - rotated - lazy_derived) | {x for _, x in alias_at.get(i, [])} | rd_reads.get(rec["rt"], set())
+                      | (rl_reads.get(rec["rt"], set()) - rotated))
             rec["lld"] = need_l - resident_l
             resident_l |= need_l
             rec["lst"] = rec["st"] - rotated
@@ -370,8 +386,10 @@ def main():
     lines.append(f"// planes the routed step only produces ({len(routed_sparse)}): left out by the last pass that assigns them unless a later pass loads them")
     lines.append("#define RH_SPARSE_FIELDS_ROUTED(X) " + " ".join(f"X({n})" for n in sorted(routed_sparse, key=order.get)))
     for model in ("svat", "oned"):
-        lines.append(f"// planes the fused {model} step only produces ({len(sparse[model])}): not stored by the steps of an rh_run_steps call that another step follows")
+        lines.append(f"// planes the sparse fused {model} step does not store ({len(sparse[model])}): produced only, or derived by the next lazy step itself")
         lines.append(f"#define RH_SPARSE_FIELDS_{model.upper()}(X) " + " ".join(f"X({n})" for n in sorted(sparse[model], key=order.get)))
+        lines.append(f"// planes NO variant of the fused {model} step reads ({len(never_read[model])})")
+        lines.append(f"#define RH_NEVER_READ_FIELDS_{model.upper()}(X) " + " ".join(f"X({n})" for n in sorted(never_read[model], key=order.get)))
     lines.append("")
     # Parameter planes of the fused step: read by a stage, assigned by none (static) or by the monthly surface parameters only.  A wave
     # whose 64 columns hold ONE value of such a plane reads one element instead of 512 bytes (DevState::pmask, k_param_mask): bit b of
@@ -404,6 +422,7 @@ def main():
         lines.append(f"#define RH_PARAM_LOADED_{model}(X) " + " ".join(f"X({n})" for n in sorted(loaded, key=order.get)))
     lines.append(f"// parameters a stage of the fused step derives from the primaries instead of loading them ({len(derived)})")
     lines.append("#define RH_DERIVED_FIELDS(X) " + " ".join(f"X({n})" for n in sorted(derived, key=order.get)))
+    lines.append("#define RH_LAZY_DERIVED_FIELDS(X) " + " ".join(f"X({n})" for n in sorted(lazy_derived, key=order.get)))
     lines.append("#define RH_DERIVE_PRIMARIES(X) " + " ".join(f"X({n})" for n in sorted(set().union(*rd_reads.values()), key=order.get)))
     lines.append("")
     # the rotation pairs themselves (materialising the X_m1 planes after lazy steps): X(x) for every c.x_m1 = c.x

@@ -24,7 +24,7 @@ import re
 
 ASSIGN_RE = re.compile(r"\bc\.(\w+)\s*(=(?!=)|\+=|-=|\*=|/=)")
 MENTION_RE = re.compile(r"\bc\.(\w+)")
-CALL_RE = re.compile(r"\b((?:rt|h)_\w+)\s*\(")
+CALL_RE = re.compile(r"\b((?:rt|rl|h)_\w+)\s*\(")
 
 
 class Summary:
