@@ -250,7 +250,7 @@ def bench_sas(args, torch, dist, rank, local_rank, world, device):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -367,7 +367,7 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -375,6 +375,7 @@ def bench_routed(args, torch, dist, rank, local_rank, world, device):
                 "workload": f"oneD_benchmark synthetic grid nx*ny={n_local} per GPU ({nx}x{ny}) with enable_routing_1D (every cell drains "
                             f"towards +y, Strickler coefficient 15, dx = dy = 5 m), {args.params} benchmark parameters, combo forcing (seed 42), adaptive dt",
                 "cells_per_gpu": n_local,
+                "global_cells": args.global_cells if args.global_cells else world * n_local,
                 "simulated_seconds": int(s1.time - s0.time),
                 "decomposition": f"({world},1) along x, " + ("one summary all-reduce and two edge-column exchanges per step" if world > 1
                                                               else "single GPU: no exchange"),
@@ -582,32 +583,54 @@ def launch_ranks(n, argv):
     import socket
     import subprocess
 
-    with socket.socket() as s:   # a free port on the loopback interface
-        s.bind(("127.0.0.1", 0))
+    import signal
+
+    with socket.socket() as s:   # a free port on the loopback interface (released just before the ranks bind it: a taken port fails the
+        s.bind(("127.0.0.1", 0))   # rendezvous loudly, the ranks exit non-zero and so does this launcher)
         port = s.getsockname()[1]
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop_all(grace=5.0):
+        """Exactly the processes started here: terminate, then kill what is still there after `grace` seconds."""
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_end = time.monotonic() + grace
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_signal(signum, _frame):   # a driver's timeout (SIGTERM) or Ctrl-C must not leave ranks behind holding the GPUs (ADVICE r3)
+        raise SystemExit(128 + signum)
+
+    previous = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     status, failed_at = 0, None
-    while True:
-        codes = [p.poll() for p in procs]
-        if all(c is not None for c in codes):
-            break
-        time.sleep(0.2)
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad and failed_at is None:
-            failed_at = time.monotonic()
-            print(f"bench: rank {bad[0][0]} exited with status {bad[0][1]}; stopping the other ranks", file=sys.stderr)
-        if failed_at is not None and time.monotonic() - failed_at > 5.0:   # a rank waiting in a collective for the failed one
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()   # exactly the processes started here
-    for r, p in enumerate(procs):
-        rc = p.wait()
-        if rc != 0 and status == 0:
-            status = rc if rc > 0 else 1
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            time.sleep(0.2)
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.monotonic()
+                print(f"bench: rank {bad[0][0]} exited with status {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+            if failed_at is not None and time.monotonic() - failed_at > 5.0:   # a rank waiting in a collective for the failed one
+                stop_all(grace=2.0)
+        for r, p in enumerate(procs):
+            rc = p.wait()
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+    finally:
+        stop_all()
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
     return status
 
 
@@ -615,6 +638,9 @@ def launch_check(dist, torch, rank, world):
     """--launch-check: what a rank does up to the first collective, without a GPU (gloo)."""
     if os.environ.get("RH_BENCH_TEST_FAIL_RANK") == str(rank):   # the launcher's failure path (tests)
         raise SystemExit(3)
+    if os.environ.get("RH_BENCH_TEST_HANG"):   # the launcher's signal path (tests): a rank that never finishes by itself
+        print(f"rank-pid {os.getpid()}", flush=True)
+        time.sleep(600)
     if world > 1:
         dist.init_process_group("gloo")
     t = torch.tensor([rank + 1], dtype=torch.int64)
@@ -634,6 +660,10 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, nargs=2, default=(1000, 1000), metavar=("NX", "NY"))
+    ap.add_argument("--global-size", type=int, nargs=2, default=None, metavar=("NX", "NY"),
+                    help="STRONG scaling (BASELINE configs[3]: `oneD_benchmark nx*ny = 10^7 over 8 GPUs`; benchmarks/run_benchmarks.py:27-31 fixes "
+                         "the global size and varies the ranks): the size of the WHOLE domain, split along x over --gpus ranks (num_proc = "
+                         "(N, 1)); refused if the ranks do not divide nx (roger/distributed.py:121-138).  Replaces --size (per rank, weak scaling)")
     ap.add_argument("--params", choices=("uniform", "hetero"), default="uniform")
     ap.add_argument("--model", choices=("svat", "oned", "sas"), default="svat",
                     help="svat: SVAT_benchmark (BASELINE configs[1]); oned: oneD_benchmark (lateral subsurface flow); "
@@ -676,6 +706,20 @@ def main():
                     help="the launcher's own test: start the ranks, form the process group over gloo, all-reduce the rank ids and print "
                          "one line -- no GPU work, no model (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+
+    scaling, global_cells = "weak", None
+    if args.global_size is not None:
+        # the reference's decomposition rule, before anything is started (roger/distributed.py:121-138)
+        from roger_amd.distributed import get_chunk_size, validate_decomposition
+
+        gnx, gny = args.global_size
+        try:
+            validate_decomposition(gnx, gny, (args.gpus, 1), args.gpus)
+        except (ValueError, RuntimeError) as e:
+            raise SystemExit(f"bench: --global-size {gnx} {gny} over {args.gpus} ranks: {e}")
+        args.size = get_chunk_size(gnx, gny, (args.gpus, 1))
+        scaling, global_cells = "strong", gnx * gny
+    args.scaling, args.global_cells = scaling, global_cells
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the bare command `python bench.py --gpus N`: this process becomes the launcher (nothing here has touched torch or the GPU)
@@ -826,14 +870,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{'oneD' if args.model == 'oned' else 'SVAT'}_benchmark synthetic grid nx*ny={n_local} per GPU ({nx}x{ny}), {args.params} "
+                "workload": f"{'oneD' if args.model == 'oned' else 'SVAT'}_benchmark synthetic grid " + (f"nx*ny={args.global_cells} in all ({args.global_size[0]}x{args.global_size[1]}), " if args.global_cells else "")
+                            + f"nx*ny={n_local} per GPU ({nx}x{ny}), {args.params} "
                             "benchmark parameters, combo forcing (seed 42), adaptive dt" + (", per-cell station weights" if args.station_weights else ""),
                 "cells_per_gpu": n_local,
+                "global_cells": args.global_cells if args.global_cells else world * n_local,
                 "simulated_seconds": int(s1.time - s0.time),
                 "spinup_steps": args.spinup,
                 "decomposition": f"({world},1) along x, " + ("one 256-byte predicate all-reduce per step" if world > 1 else "single GPU: no exchange"),

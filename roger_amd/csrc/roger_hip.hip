@@ -141,7 +141,7 @@ struct HostExport {
 struct rh_ctx {
     unsigned long long *pmask_buf = nullptr;   // DevState::pmask
     bool pmask_valid = false;                   // ... describes the planes as they are now
-    int pmask_flags = 3;                        // bit 0: uniform loads, bit 1: derived parameters (RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE clear them)
+    int pmask_flags = 7;                        // bit 0: uniform loads, bit 1: derived parameters, bit 2: the catchment mask as a constant (RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE / RH_NO_MASK_CONSTANT clear them)
     HostExport *hexp = nullptr;      // pinned + mapped
     unsigned long long hexp_seq = 0;
     rh_config cfg;
@@ -1172,10 +1172,14 @@ constexpr bool rh_param_derived(int plane) {
 // Load of plane PLANE for the LAZY kernels: a parameter plane whose bit is set in the wave's word is read at the wave's FIRST column by
 // every lane (one 64-byte sector from HBM instead of 512 bytes: the values are equal, k_param_mask compared them bit for bit); a
 // derived parameter is not loaded when bit 63 is set (the stage's rd_* function assigns it).
-template <int PLANE, typename T>
+// MK1: the wave's columns all lie in the catchment (bit 62: maskCatch == 1 on every one): the mask is the constant 1, not loaded, and
+// the ~ 350 multiplications by it per column and step (the reference masks every assignment) fold away -- x * 1.0 is x, bit for bit.
+template <int PLANE, bool MK1, typename T>
 RH_DEV void rh_ld_p(const Arena &a, int64_t i, T &dst, unsigned long long um) {
     constexpr int bit = rh_param_bit(PLANE);
-    if constexpr (bit < 0) {
+    if constexpr (MK1 && PLANE == RH_P_maskCatch) {
+        dst = 1;
+    } else if constexpr (bit < 0) {
         rh_ld(a, PLANE, i, dst);
     } else {
         if constexpr (rh_param_derived(PLANE)) {
@@ -1192,7 +1196,7 @@ RH_DEV void rh_ld_p(const Arena &a, int64_t i, T &dst, unsigned long long um) {
         dst = (RH_NT & 1) ? __builtin_nontemporal_load(p) : *p;
     }
 }
-#define LDP(name) rh_ld_p<RH_P_##name>(a, i, c.name, um);
+#define LDP(name) rh_ld_p<RH_P_##name, MK1>(a, i, c.name, um);
 RH_DEV unsigned long long bits_of(double v) { return (unsigned long long)__double_as_longlong(v); }
 RH_DEV unsigned long long bits_of(int v) { return (unsigned long long)(unsigned)v; }
 // The wave's word of DevState::pmask.  flags bit 0: uniformity bits, bit 1: the derive bit.  One thread per column; a wave whose upper
@@ -1226,7 +1230,9 @@ __global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, u
     RH_PARAM_MONTHLY(RH_PM)
 #undef RH_PM
     if ((um & in_bits) != in_bits) um &= ~mon_bits;
+    const bool all_in = __ballot(active && c.maskCatch != 1) == 0;   // every column of the wave lies in the catchment
     if (!(flags & 1)) um = 0;
+    if (all_in && (flags & 4)) um |= 1ull << 62;
     if (flags & 2) {
         // the derived parameters: what the stages would compute from the primaries (already in c) against what the planes hold
         Col d = c;
@@ -1373,23 +1379,12 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
 // KEEP (with SPARSE): an accumulator was given planes the sparse kernel does not store -- those are stored after all (DevState::keep)
-template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE, bool KEEP = false>
-RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep) {
+template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE, bool KEEP = false, bool MK1 = false>
+RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep, unsigned long long um) {
     {
     const Consts K = D->K;
     const StepCtx X = *Xp;
     Col c;
-    // the wave's word of the parameter planes (uniform / derivable; zero: plain loads) -- wave-uniform, in scalar registers
-    unsigned long long um = 0;
-    if constexpr (LAZY) {
-#ifdef RH_CENSUS
-        um = RH_CENSUS_PMASK;
-#else
-        const unsigned long long *pm = D->pmask;
-        const unsigned long long w = pm ? pm[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : 0ull;
-        um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-#endif
-    }
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     if (D->per_cell && X.sel_w >= 0) {
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
@@ -1459,6 +1454,19 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     unsigned dep = 1;
     if (i < a.n) {
         const bool monthly = MODE == 1 || (MODE == 2 && D->monthly != 0);
+        // the wave's word of the parameter planes (uniform / derivable / all in the catchment; zero: plain loads) -- wave-uniform, in
+        // scalar registers
+        unsigned long long um = 0;
+        if constexpr (LAZY) {
+#ifdef RH_CENSUS
+            um = RH_CENSUS_PMASK;
+#else
+            const unsigned long long *pm = D->pmask;
+            const unsigned long long w = pm ? pm[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : 0ull;
+            um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+#endif
+        }
+        const bool mk1 = LAZY && ((um >> 62) & 1ull);   // (the monthly pipeline, once a month, keeps the generic code)
         // the SPARSE kernel holds the full-store pipeline too: the step that reaches the time limit is the run's last one
         // (X.last, decided by the control part on the device) and stores every plane -- a wave-uniform branch
 #ifdef RH_CENSUS
@@ -1466,11 +1474,13 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #else
         if (SPARSE && !Xp->last) {
 #endif
-            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep);
-            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep);
+            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
+            else if (mk1) step_column<false, LATERAL, LAZY, SPARSE, KEEP, LAZY>(a, D, Xp, i, q, bad, dep, um);
+            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
         } else {
-            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
-            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep);
+            // (the full-store pipeline keeps the generic code: with a third copy the full-store kernels spill registers)
+            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
+            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
         }
     } else {
         post_summary(D, 0ull, dep);
@@ -2245,7 +2255,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
         if ((e = hipMemcpyAsync(&ctx->dev->pmask, &ctx->pmask_buf, sizeof(ctx->pmask_buf), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpy(pmask)");
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
-        ctx->pmask_flags = (std::getenv("RH_NO_PARAM_UNIFORM") ? 0 : 1) | (std::getenv("RH_NO_PARAM_DERIVE") ? 0 : 2);
+        ctx->pmask_flags = (std::getenv("RH_NO_PARAM_UNIFORM") ? 0 : 1) | (std::getenv("RH_NO_PARAM_DERIVE") ? 0 : 2) | (std::getenv("RH_NO_MASK_CONSTANT") ? 0 : 4);
     }
     {
         static const long long no_limit = -1;

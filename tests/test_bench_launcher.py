@@ -65,3 +65,50 @@ def test_one_rank_communicator_is_counted():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["config"]["n_ranks_in_comm"] == 1 and "rh_run_steps_dist" in rec["config"]["stepping"]
+
+
+def test_global_size_is_refused_when_the_ranks_do_not_divide_it():
+    """--global-size: the reference's decomposition rule (roger/distributed.py:121-138), applied before any rank is started."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--model", "oned", "--global-size", "3200", "3125", "--launch-check"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "do not divide domain evenly in x-direction" in r.stderr
+
+
+@pytest.mark.gpu
+def test_strong_scaling_command_rehearsed_with_two_ranks_on_one_gpu():
+    """BASELINE configs[3] as ONE command: `python bench.py --gpus N --model oned --global-size NX NY` gives each rank NX / N x NY columns
+    (num_proc = (N, 1)) and reports strong scaling; rehearsed here at a small global size with two ranks sharing device 0
+    (RH_BENCH_SINGLE_DEVICE=1).  On an 8-GPU node: python bench.py --gpus 8 --model oned --global-size 3200 3125."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--model", "oned", "--global-size", "512", "250", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline"], env=_env(RH_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["steps"] == 6
+    assert rec["config"]["global_cells"] == 512 * 250 and rec["config"]["cells_per_gpu"] == 256 * 250
+    assert abs(rec["value"] - 512 * 250 * 6 / (rec["ms_per_step"] * 6 / 1e3)) < 1e-6 * rec["value"]
+
+
+def test_a_terminated_launcher_takes_its_ranks_with_it():
+    """SIGTERM to the parent (a driver's timeout): the ranks it started are stopped, none is left behind."""
+    import signal
+    import time
+
+    env = _env(RH_BENCH_TEST_HANG="1")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    pids = []
+    t_end = time.monotonic() + 120
+    while len(pids) < 2 and time.monotonic() < t_end:   # the ranks announce themselves, then wait
+        line = p.stdout.readline()
+        if line.startswith("rank-pid "):
+            pids.append(int(line.split()[1]))
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, f"rank process {pid} survived its launcher"

@@ -5,7 +5,9 @@
     of being loaded, where the planes hold exactly what the setup kernel computed.
 
 Both are decided per wavefront from the planes themselves, on the device, whenever somebody other than the fused kernel may have changed
-them.  What a caller can observe must not change: every plane after rh_run_steps equals, BIT FOR BIT, what a context with both switched
+them; so is a third bit: every column of the wave lies in the catchment (maskCatch == 1), and the wave runs the copy of the pipeline in
+which the mask is the constant 1 (the reference multiplies every assignment by the mask: ~ 350 multiplications by 1.0 per column and step
+fold away).  What a caller can observe must not change: every plane after rh_run_steps equals, BIT FOR BIT, what a context with both switched
 off (RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE at rh_create) leaves -- on the golden cases as they are, with a derived plane overwritten
 by other values on some columns, and with a parameter changed between two calls."""
 import os
@@ -17,7 +19,7 @@ from golden_util import CASES, load_case
 from test_hip_parity import _ctx, native  # noqa: F401
 
 pytestmark = pytest.mark.gpu
-SWITCHES = ("RH_NO_PARAM_UNIFORM", "RH_NO_PARAM_DERIVE")
+SWITCHES = ("RH_NO_PARAM_UNIFORM", "RH_NO_PARAM_DERIVE", "RH_NO_MASK_CONSTANT")
 
 
 def make_ctx(native, g, names, forcing, plain):  # noqa: F811

@@ -411,8 +411,8 @@ def main():
     if not derived <= static:
         sys.exit(f"derived parameters that are not static parameters of the step: {sorted(derived - static)}")
     bits = sorted(static | monthly, key=order.get)
-    if len(bits) > 62:
-        sys.exit(f"{len(bits)} parameter planes do not fit the wave's 64-bit word (bit 63: derived parameters valid)")
+    if len(bits) > 61:
+        sys.exit(f"{len(bits)} parameter planes do not fit the wave's 64-bit word (bit 63: derived parameters valid, bit 62: every column in the catchment)")
     lines.append(f"// parameter planes of the fused step ({len(static)} static, {len(monthly)} assigned by the monthly surface parameters only): X(name, bit)")
     lines.append("#define RH_PARAM_BITS(X) " + " ".join(f"X({n}, {b})" for b, n in enumerate(bits)))
     lines.append("#define RH_PARAM_MONTHLY(X) " + " ".join(f"X({n})" for n in sorted(monthly, key=order.get)))
