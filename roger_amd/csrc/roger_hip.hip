@@ -99,6 +99,10 @@ struct DevState {
     const double *forc_cell[3];        // per-cell forcing, TRANSPOSED on upload to (144, n): slot s of column i at [s * n + i], unit stride over
                                        // the columns (a wave reads 512 contiguous bytes per slot instead of 64 values 1152 bytes apart); or null
     double *agg_cell;                  // per-cell aggregates, 9 planes of n (written by k_cell_agg)
+    // per-cell forcing, one launch in front of the fused kernel (k_cell_front): frontw = the waves' column bits of the step (word 0's
+    // snow bits, word 1's terms for each candidate selection), dayw = the forcing bits of the DAY over all columns and slots (formed
+    // once a day, folded into day_word by the front kernel's last wavefront)
+    unsigned long long frontw[64], dayw[64], day_word;
     int per_cell;
     // whole forcing series resident on the device (rh_set_forcing_series): 10-minute PREC/TA/PET
     // and the calendar vectors, as the benchmark's set_forcing_setup holds them in vs.PREC, ...
@@ -179,6 +183,9 @@ struct rh_ctx {
     int64_t call_sparse_steps = 0;   // steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores
     bool agg_daily_stale;   // per-cell daily forcing sums must be re-formed (new weights; first use)
     bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
+    bool front_daily_stale = true;   // ... and for the one-launch front (k_cell_front: daily sums + DevState::day_word)
+    bool cell_front_ok = true;       // RH_PER_CELL_OLD_FRONT unset: per-cell forcing takes k_cell_front instead of the five predicate-generation launches
+    int last_front = 0;              // which of the two formed the day's cached parts last (1 old, 2 new): the other re-forms them when it takes over
     double *diag_buf;
     long long *diag_steps_buf;
     long long diag_interval;
@@ -648,6 +655,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
 
+
 // mode: RH_SELECT_M1_PENDING = the tau -> taum1 copies of the last fused step are still pending (lazy rotation): prec_m1 / swe_m1 are
 // the tau planes as they stand; RH_SELECT_DEFER = the selected prec / ta are not stored, the fused kernel applies the selection itself
 // (StepCtx.apply_sel = 2) -- the planes stay untouched between two fused steps, so the rotation can stay pending
@@ -1045,6 +1053,195 @@ RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
         D->X_next = X;
     }
 }
+// ---- per-cell forcing: ONE per-column launch in front of the fused kernel (round 4) --------------------------------
+// What k_pred1 -> k_agg -> k_cell_agg<1> -> k_select -> k_scalars did in five launches (four of them passes over the columns or
+// single-workgroup reductions waiting for each other).  The two global decisions of a step depend on each other -- word 0 (snow state +
+// the day's forcing over all columns) decides which aggregate a column takes as its prec / ta, word 1 is formed from THOSE --, so a
+// column evaluates word 1's terms for every candidate selection (keep, daily, hourly, ten minutes: 6 bits each) next to its
+// aggregates; the wavefront that finishes last folds the words, takes the candidate word 0 selects and does the bookkeeping
+// (agg_body's decisions + scalars_update, the same device functions).  The day's forcing bits are formed once a day by the part that
+// forms the daily sums and kept in day_word.
+enum { FC_RAIN = 0, FC_SNOWMELT, FC_PREC_NOT_LE0, FC_NOT_PGT0_TALE, FC_P_EQ0, FC_P_NE0, FC_PER_CANDIDATE };
+#define FC_COMMON 24   // bits 24..: PC_SWEM1_GT0, PC_SWE_NOT_LE0, PC_PM1_NE0, PC_PM1_EQ0, then word 0's four snow bits
+RH_DEV unsigned long long front_candidate_bits(double prec, double ta, bool snow, double ta_fm) {
+    unsigned long long b = 0;
+    const bool warm = ta > ta_fm;
+    b |= ((prec > 0) && warm) ? BIT(FC_RAIN) : 0;
+    b |= (snow && warm) ? BIT(FC_SNOWMELT) : 0;
+    b |= !(prec <= 0) ? BIT(FC_PREC_NOT_LE0) : 0;
+    b |= !((prec > 0) && (ta <= ta_fm)) ? BIT(FC_NOT_PGT0_TALE) : 0;
+    b |= (prec == 0) ? BIT(FC_P_EQ0) : 0;
+    b |= (prec != 0) ? BIT(FC_P_NE0) : 0;
+    return b;
+}
+// the daily part of a column: its daily sums (aggregate planes 0..2) and the forcing bits of its 144 slots
+template <class P, class T, class E>
+RH_DEV unsigned long long front_daily(P p, T t, E e, double *agg, const Consts &K) {
+    forcing_aggregates_of(p, t, e, 0, agg, true, false);
+    unsigned long long b = 0;
+    for (int k = 0; k < RH_SLOTS_PER_DAY; ++k) b |= forcing_bits(p(k), t(k), K);
+    return b;
+}
+// the control part by the last wavefront: S / X as k_agg's thread 0 and k_scalars form them
+RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long day = D->day_word;
+    if (daily_due) {
+        day = wave_or(dev_load(&D->dayw[lane]));
+        dev_store(&D->dayw[lane], 0ull);
+    }
+    if (lane != 0) return;
+    D->day_word = day;
+    rh_scalars S = D->S;
+    StepCtx X = D->X;
+    const unsigned long long w = ((cells >> (FC_COMMON + 4)) & 0xFull) | day;   // word 0: bits 0..3 are the columns' snow bits
+    {
+        const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
+        const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
+        const bool any_pgt0_tale = bit(w, PB_PGT0_TALE), all_ple0_tale = !bit(w, PB_NOT_PLE0_TALE);
+        const bool all_swe_le0 = !bit(w, PB_SWE_NOT_LE0), all_swetop_le0 = !bit(w, PB_SWETOP_NOT_LE0);
+        const bool snow_any = (bit(w, PB_SWE_GT0) || bit(w, PB_SWETOP_GT0)) && any_ta_gt;
+        const bool cond0 = all_p_le0 && all_swe_le0 && all_swetop_le0 && all_ta_gt;
+        const bool cond00 = any_pgt0_tale || all_ple0_tale;
+        const bool cond1 = any_p_gthpi && any_p_gt0 && any_ta_gt;
+        const bool cond2 = all_p_lehpi && any_p_gt0 && any_ta_gt;
+        const bool cond3 = any_p_gthpi && any_p_gt0 && snow_any;
+        const bool cond4 = all_p_lehpi && any_p_gt0 && snow_any;
+        const bool cond5 = all_p_le0 && snow_any;
+        X.cond_time = (S.time % 86400 == 0);
+        X.sel_daily = cond0 || cond00;
+        X.sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
+        X.sel_10min = (cond1 || cond3) && !cond2 && !cond4 && !cond5;
+        int64_t dts = X.cond_time ? 86400 : 3600;   // adaptive_time_stepping.py:143-144, :166, :190 (agg_body)
+        if (X.sel_hourly) dts = 3600;
+        if (X.sel_10min) dts = 600;
+        X.dt_secs_prelim = dts;
+        X.itt_day = S.itt_day;
+        X.sel_p = X.sel_10min ? 2 : (X.sel_hourly ? 1 : (X.sel_daily ? 0 : -1));
+    }
+    // word 1 from the candidate the selection takes (candidate 0: keep; 1 + sel_p otherwise) and the common terms
+    const unsigned long long cand = (cells >> (FC_PER_CANDIDATE * (X.sel_p + 1))) & ((1ull << FC_PER_CANDIDATE) - 1);
+    unsigned long long w1 = 0;
+    w1 |= bit(cand, FC_RAIN) ? BIT(PC_RAIN) : 0;
+    w1 |= bit(cand, FC_SNOWMELT) ? BIT(PC_SNOWMELT) : 0;
+    w1 |= bit(cand, FC_PREC_NOT_LE0) ? BIT(PC_PREC_NOT_LE0) : 0;
+    w1 |= bit(cand, FC_NOT_PGT0_TALE) ? BIT(PC_NOT_PGT0_TALE) : 0;
+    w1 |= bit(cand, FC_P_EQ0) ? BIT(PC_P_EQ0) : 0;
+    w1 |= bit(cand, FC_P_NE0) ? BIT(PC_P_NE0) : 0;
+    w1 |= bit(cells, FC_COMMON + 0) ? BIT(PC_SWEM1_GT0) : 0;
+    w1 |= bit(cells, FC_COMMON + 1) ? BIT(PC_SWE_NOT_LE0) : 0;
+    w1 |= bit(cells, FC_COMMON + 2) ? BIT(PC_PM1_NE0) : 0;
+    w1 |= bit(cells, FC_COMMON + 3) ? BIT(PC_PM1_EQ0) : 0;
+    const int64_t dts = scalars_update(S, X, w1, 1, 2, true, D->K.end_event);
+    D->words[0] = 0;
+    D->words[1] = 0;
+    D->words[2] = 0;
+    D->S = S;
+    D->X = X;
+    log_dt(D, dts);
+}
+// WITH_DAILY: the daily part inline (small grids: one launch); otherwise k_cell_agg<2>-like k_cell_daily runs in front (the daily sums'
+// code needs > 200 registers, which would leave every step's part two waves per SIMD).  m1_pending as k_select's RH_SELECT_M1_PENDING.
+template <bool WITH_DAILY>
+__global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, int force_daily, int m1_pending, int grp_shift, int daily_only) {
+    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    const bool weighted = D->weights[0] != nullptr;
+    const bool daily_due = !weighted || force_daily || D->S.itt_day == 0;   // (uniform over the grid; k_cell_agg's rule)
+    __shared__ unsigned wg_done;
+    __shared__ DaySeries day;
+    if (daily_only && !daily_due) return;
+    if (threadIdx.x == 0) wg_done = 0;
+    if (weighted) stage_day(D, day);
+    else __syncthreads();
+    const Consts K = D->K;
+    const int64_t itd = D->S.itt_day;
+    unsigned long long b = 0, db = 0;
+    if (i < a.n) {
+        double agg[9];
+        if (weighted) {
+            const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
+            const DayView F = day_view(D, day, i);
+            auto p = [&](int k) { return F(0, k) * pw; };
+            auto t = [&](int k) { return F(1, k) + toff; };
+            auto e = [&](int k) { return F(2, k) * ew; };
+            if ((WITH_DAILY || daily_only) && daily_due) db = front_daily(p, t, e, agg, K);
+            if (!daily_only) forcing_aggregates_of(p, t, e, itd, agg, false, true);
+        } else {
+            const double *pp = D->forc_cell[0] + i, *tp = D->forc_cell[1] + i, *ep = D->forc_cell[2] + i;
+            const size_t n = (size_t)a.n;
+            auto p = [&](int k) { return pp[k * n]; };
+            auto t = [&](int k) { return tp[k * n]; };
+            auto e = [&](int k) { return ep[k * n]; };
+            if ((WITH_DAILY || daily_only) && daily_due) db = front_daily(p, t, e, agg, K);
+            if (!daily_only) forcing_aggregates_of(p, t, e, itd, agg, false, true);
+        }
+        if ((WITH_DAILY || daily_only) && daily_due)
+            for (int k = 0; k < 3; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
+        if (!daily_only) {
+            for (int k = 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
+            if (!((WITH_DAILY) && daily_due)) {   // the daily sums of the day: formed earlier
+                agg[0] = D->agg_cell[i];
+                agg[1] = D->agg_cell[(size_t)a.n + i];
+            }
+            double prec, ta, swe, swe_top, prec_m1, swe_m1;
+            rh_ld(a, RH_P_prec, i, prec);
+            rh_ld(a, RH_P_ta, i, ta);
+            rh_ld(a, RH_P_swe, i, swe);
+            rh_ld(a, RH_P_swe_top, i, swe_top);
+            if (m1_pending) {
+                prec_m1 = prec;
+                swe_m1 = swe;
+            } else {
+                rh_ld(a, RH_P_prec_m1, i, prec_m1);
+                rh_ld(a, RH_P_swe_m1, i, swe_m1);
+            }
+            const bool snow = (swe > 0) || (swe_top > 0);
+            b |= front_candidate_bits(prec, ta, snow, K.ta_fm);                                   // keep (sel_p < 0)
+            b |= front_candidate_bits(agg[0], agg[1], snow, K.ta_fm) << FC_PER_CANDIDATE;        // daily
+            b |= front_candidate_bits(agg[3], agg[4], snow, K.ta_fm) << (2 * FC_PER_CANDIDATE);  // hourly
+            b |= front_candidate_bits(agg[6], agg[7], snow, K.ta_fm) << (3 * FC_PER_CANDIDATE);  // ten minutes
+            b |= (swe_m1 > 0) ? BIT(FC_COMMON + 0) : 0;
+            b |= !(swe <= 0) ? BIT(FC_COMMON + 1) : 0;
+            b |= (prec_m1 != 0) ? BIT(FC_COMMON + 2) : 0;
+            b |= (prec_m1 == 0) ? BIT(FC_COMMON + 3) : 0;
+            b |= !(swe <= 0) ? BIT(FC_COMMON + 4 + PB_SWE_NOT_LE0) : 0;
+            b |= (swe > 0) ? BIT(FC_COMMON + 4 + PB_SWE_GT0) : 0;
+            b |= !(swe_top <= 0) ? BIT(FC_COMMON + 4 + PB_SWETOP_NOT_LE0) : 0;
+            b |= (swe_top > 0) ? BIT(FC_COMMON + 4 + PB_SWETOP_GT0) : 0;
+        }
+    }
+    // the wave's bits into the device-wide words (atomics that have RETURNED before the wave counts itself done: k_step's completion scheme)
+    unsigned dep = 1;
+    b = wave_or(b);
+    db = wave_or(db);
+    if ((threadIdx.x & 63) == 0) {
+        if (db) dep |= (unsigned)(__hip_atomic_fetch_or(&D->dayw[blockIdx.x & 63], db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
+        if (b) dep |= (unsigned)(__hip_atomic_fetch_or(&D->frontw[blockIdx.x & 63], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
+    }
+    if (daily_only) return;   // (the front kernel behind this launch folds dayw)
+    bool last = false;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned o = atomicAdd(&wg_done, dep);   // LDS; dep == 1 (bit 63 of the words is never set)
+        if (o == (RH_BLOCK / 64) - 1) {
+            const unsigned nblk = gridDim.x, g = blockIdx.x >> grp_shift, ng = ((nblk - 1) >> grp_shift) + 1;
+            const unsigned cnt = (g == ng - 1) ? nblk - (g << grp_shift) : (1u << grp_shift);
+            if (__hip_atomic_fetch_add(&D->done_grp[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1) {
+                __hip_atomic_store(&D->done_grp[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {
+                    __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = true;
+                }
+            }
+        }
+    }
+    if (__shfl((int)last, 0)) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long cells = wave_or(dev_load(&D->frontw[lane]));
+        dev_store(&D->frontw[lane], 0ull);
+        front_ctrl(D, cells, daily_due);
+    }
+}
+
 // summary bits straight from the arena (first step, or after the host changed planes), OR-ed into sumw (zeroed by the host)
 __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
@@ -2127,6 +2324,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->m1_stale = false;
     ctx->agg_daily_stale = true;
     ctx->pred_daily_stale = true;
+    ctx->front_daily_stale = true;
     ctx->diag_reads_m1 = false;
     ctx->lazy_ok = std::getenv("RH_NO_LAZY_ROTATION") == nullptr;
     ctx->sparse_ok = std::getenv("RH_NO_SPARSE_STORES") == nullptr;
@@ -2291,6 +2489,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
     ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
     ctx->defer_select_ok = std::getenv("RH_NO_DEFERRED_SELECT") == nullptr;
+    ctx->cell_front_ok = std::getenv("RH_PER_CELL_OLD_FRONT") == nullptr && ctx->defer_select_ok;
     if (const char *v = std::getenv("RH_CELL_AGG_SPLIT_MIN")) ctx->cell_agg_split_min = std::atoll(v);
     ctx->grp_shift = 6;
     while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
@@ -2874,6 +3073,8 @@ int rh_step_phase1(rh_ctx *ctx) {
     if (!ctx) return RH_ERR_ARG;
     if (!ctx->forcing_set) return fail(ctx, RH_ERR_STATE, "rh_set_forcing_day / rh_set_forcing_series must be called before the first step");
     planes_touched(ctx);
+    if (ctx->last_front != 1) ctx->agg_daily_stale = ctx->pred_daily_stale = true;   // (the one-launch front formed the day's parts last)
+    ctx->last_front = 1;
     hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
     ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_reduce, ctx->dev, 0);
@@ -2940,6 +3141,30 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         launch_hooks(ctx);
         hooks = 0;
     }
+    if (ctx->cell_front_ok) {
+        // ONE per-column launch in front of the fused kernel (k_cell_front; a second one, returning at once unless a new day began, for the
+        // daily sums of large grids).  Nothing in front of the fused kernel writes a plane: its lazy rotation stays.
+        ctx->summary_valid = false;
+        ctx->pending_valid = false;
+        ctx->exch_valid = false;
+        const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
+        const int force = (ctx->front_daily_stale || ctx->last_front != 2) ? 1 : 0, m1 = ctx->m1_stale ? 1 : 0;
+        if (ctx->n >= ctx->cell_agg_split_min) {
+            hipLaunchKernelGGL(k_cell_front<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 1);
+            hipLaunchKernelGGL(k_cell_front<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 0);
+        } else {
+            hipLaunchKernelGGL(k_cell_front<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 0);
+        }
+        CHECK_LAUNCH(ctx);
+        ctx->front_daily_stale = false;
+        ctx->last_front = 2;
+        int rc = launch_fused_kernel(ctx, monthly);
+        if (rc) return rc;
+        CHECK_LAUNCH(ctx);
+        return RH_OK;
+    }
+    if (ctx->last_front != 1) ctx->agg_daily_stale = ctx->pred_daily_stale = true;
+    ctx->last_front = 1;
     // None of the kernels in front of the fused one writes a plane: the selected prec / ta are applied inside the fused kernel
     // (apply_sel = 2, from the per-cell aggregates), the predicate kernels read tau planes only -- with the rotation pending, prec_m1 /
     // swe_m1 are the tau planes themselves.  So the fused kernel keeps its lazy rotation in the per-cell path too.
@@ -3095,6 +3320,7 @@ int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, c
     ctx->per_cell = true;
     ctx->agg_daily_stale = true;
     ctx->pred_daily_stale = true;
+    ctx->front_daily_stale = true;
     return RH_OK;
 }
 
@@ -3271,6 +3497,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
     ctx->agg_daily_stale = true;
     ctx->pred_daily_stale = true;
+    ctx->front_daily_stale = true;
     return RH_OK;
 }
 

@@ -689,6 +689,44 @@ def test_per_cell_forcing_keeps_the_rotation_pending(native, monkeypatch):
     assert np.array_equal(out["deferred"][1], out["stored"][1], equal_nan=True)
 
 
+@pytest.mark.parametrize("case", [WEIGHTED_CASES[0], STATION_CASES[0]])
+def test_one_launch_front_equals_the_predicate_kernels(native, monkeypatch, case, cell_agg_split):
+    """Per-cell forcing, round 4: ONE per-column launch in front of the fused kernel (k_cell_front: the columns' aggregates, word 1's
+    terms for every candidate selection, the bookkeeping by its last wavefront) against the five launches of the predicate-kernel
+    generation (RH_PER_CELL_OLD_FRONT=1): the same scalars after every call and the same planes, bit for bit -- device-side hooks, in
+    pieces that end inside days."""
+    import hip_util as H
+
+    g, names, forcing = load_case(case)
+    w = load_weights(g)
+    nsteps = int(g["nsteps"])
+    out = {}
+    for mode in ("front", "old"):
+        if mode == "old":
+            monkeypatch.setenv("RH_PER_CELL_OLD_FRONT", "1")
+        else:
+            monkeypatch.delenv("RH_PER_CELL_OLD_FRONT", raising=False)
+        ctx = _ctx(native, g, names)
+        st = load_stations(g)
+        if st is not None:
+            ctx.set_forcing_stations(dict(PREC=st["PREC"], TA=st["TA"], PET=st["PET"], YEAR=forcing["YEAR"], MONTH=forcing["MONTH"],
+                                          DOY=forcing["DOY"]), st["station_index"])
+        else:
+            ctx.set_forcing_series(forcing)
+        ctx.set_forcing_weights(w["prec_weight"], w["ta_offset"], w["pet_weight"])
+        rows, done = [], 0
+        for stop in sorted({7, 50, 51, nsteps // 2, nsteps}):
+            ctx.run_steps(stop - done)
+            done = stop
+            rows.append((H.scalars_to_row(ctx.get_scalars()), H.download_snapshot(ctx, names)))
+        out[mode] = rows
+        ctx.close()
+    for (sa, pa), (sb, pb) in zip(out["front"], out["old"]):
+        np.testing.assert_array_equal(sa, sb)
+        assert np.array_equal(pa, pb, equal_nan=True)
+    np.testing.assert_array_equal(out["front"][-1][0], g["scal"][nsteps - 1])
+
+
 def test_hooks_phase_between_fused_steps(native):
     """rh_hooks_phase rewrites the control scalars (itt_forc, itt_day, the calendar) and the day's forcing: a control part that the
     previous fused kernel's tail formed for the next step is stale after it.  [rh_hooks_phase; rh_svat_step] per step
