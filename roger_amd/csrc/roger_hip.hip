@@ -185,6 +185,10 @@ struct rh_ctx {
     bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
     bool front_daily_stale = true;   // ... and for the one-launch front (k_cell_front: daily sums + DevState::day_word)
     bool cell_front_ok = true;       // RH_PER_CELL_OLD_FRONT unset: per-cell forcing takes k_cell_front instead of the five predicate-generation launches
+    int64_t cell_front_max = 131072; // ... on grids up to this many columns (RH_CELL_FRONT_MAX).  Measured, round 4 (profiles/r04_per_cell_front.txt):
+                                     // 80 x 53 columns 0.055 -> 0.046 ms per step (launch-bound: two launches instead of six in front of the fused
+                                     // kernel), 10^6 columns 0.280 -> 0.320 ms -- one thread doing a column's aggregates, plane reads and bits in
+                                     // sequence is latency-bound (108 us against 85 us for the five kernels, two of which are grid-stride)
     int last_front = 0;              // which of the two formed the day's cached parts last (1 old, 2 new): the other re-forms them when it takes over
     double *diag_buf;
     long long *diag_steps_buf;
@@ -2490,6 +2494,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
     ctx->defer_select_ok = std::getenv("RH_NO_DEFERRED_SELECT") == nullptr;
     ctx->cell_front_ok = std::getenv("RH_PER_CELL_OLD_FRONT") == nullptr && ctx->defer_select_ok;
+    if (const char *v = std::getenv("RH_CELL_FRONT_MAX")) ctx->cell_front_max = std::atoll(v);
     if (const char *v = std::getenv("RH_CELL_AGG_SPLIT_MIN")) ctx->cell_agg_split_min = std::atoll(v);
     ctx->grp_shift = 6;
     while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
@@ -3141,7 +3146,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         launch_hooks(ctx);
         hooks = 0;
     }
-    if (ctx->cell_front_ok) {
+    if (ctx->cell_front_ok && ctx->n <= ctx->cell_front_max) {
         // ONE per-column launch in front of the fused kernel (k_cell_front; a second one, returning at once unless a new day began, for the
         // daily sums of large grids).  Nothing in front of the fused kernel writes a plane: its lazy rotation stays.
         ctx->summary_valid = false;
