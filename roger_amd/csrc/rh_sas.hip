@@ -223,6 +223,8 @@ int rh_sas_sync(rh_sas_ctx *ctx) {
     int bad = 0;
     SHIPCHK(ctx, hipMemcpyAsync(&bad, ctx->unsupported, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SHIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad & 2)   // (the invariant blk_cumsum's top value rests on, checked by every day's kernel before it stores: ADVICE r3)
+        return sfail(ctx, RH_ERR_STATE, "internal: an age class above ages - 1 (register padding of the age axis) holds water after a day's fluxes");
     if (bad)
         return sfail(ctx, RH_ERR_STATE,
                      "a column's sas_params select a code that is none of the reference's SAS families (1, 2, 3, 31-37, 4, 51, 52, 6, 61, 62)");

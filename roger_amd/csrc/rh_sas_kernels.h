@@ -96,7 +96,7 @@ SAS_DEV void calc_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux, 
         // 52, the exponential with reversed age order (sas.py:186-190): Omega DEcreases from 1 to 0 along the age axis,
         // calc_tt clips every difference to 0 (:430-433) -- no water is selected, like Omega = 0.  Any other code is
         // unknown to the reference's families (all masked out: Omega = 0 as well) and is reported.
-        if (code != 52 && B.tid == 0 && flux * (1 / (double)P.substeps) > 0) *P.unsupported = 1;
+        if (code != 52 && B.tid == 0 && flux * (1 / (double)P.substeps) > 0) atomicOr(P.unsupported, 1);
         calc_tt_family<W, E, FAM_NONE>(B, P, p, flux, sa, mk, base, tt);
     }
 }
@@ -673,6 +673,13 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     }
 
     {
+        // The classes above ages - 1 are padding of the register layout: no flux can fill them, and blk_cumsum takes the top of the stored
+        // water from the last partial sum of the thread that owns class ages - 1 BECAUSE they hold exact zeros.  Checked once per column
+        // and day, where it costs nothing (rh_sas_sync reports it).
+        bool padded_water = false;
+#pragma unroll
+        for (int j = 0; j < E; ++j) padded_water |= (base + j >= A) && ((sa_rz[j] != 0.0) || (sa_ss[j] != 0.0));
+        if (padded_water) atomicOr(P.unsupported, 2);
         double *g0 = (double *)P.a[SA_sa_rz] + cell * A, *g1 = (double *)P.a[SA_msa_rz] + cell * A;
         double *g2 = (double *)P.a[SA_sa_ss] + cell * A, *g3 = (double *)P.a[SA_msa_ss] + cell * A;
 #pragma unroll

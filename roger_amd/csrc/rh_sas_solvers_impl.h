@@ -78,7 +78,7 @@ SAS_DEV void euler_tt(Blk<W> &B, const SasArgs &P, const double *p, double flux_
         // 52 (the exponential with reversed age order, sas.py:186-190) selects nothing: its Omega decreases along the age axis, every
         // difference is negative and `where(ttq_nonneg > 0, ., 0)` (:931-934) leaves 0 -- evaluated as Omega = 0.  Any other code is none
         // of the reference's families.
-        if (code != 52 && B.tid == 0) *P.unsupported = 1;
+        if (code != 52 && B.tid == 0) atomicOr(P.unsupported, 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) Om[j] = 0.0;
     }

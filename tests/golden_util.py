@@ -139,23 +139,46 @@ def residue_columns(snap, names, eps=1e-9):
 
 
 class TieTracker:
-    """Compares trajectories column by column: tie-exposed columns (residue_columns of either side, from the step they show one) are
-    left alone, every other column must meet the tolerance."""
+    """Compares trajectories column by column: every column that is not tie-exposed (residue_columns of either side, from the step they
+    show one) must meet the golden tolerance.  An exposed column is BOUNDED, not exempted -- but not by a small
+    relative tolerance: a flipped tie sends the column down another branch of the lateral-flow routine, and the two trajectories, both
+    legitimate, drift apart for good (measured, oracle against the reference on oned_hetero_combo: column 13 holds 258.9 instead of
+    278.2 mm of water at step 159, 7 %; S_lp_s 30.4 instead of 49.7 mm; 1.1e-3 relative in S_lp_rz at the very step of the tie).  What
+    such a column must still satisfy is what any valid trajectory satisfies: the step's water balance closes (dS_num_error below 1e-9
+    mm; measured 1.4e-13), every store is finite and not negative beyond the snapping threshold, and its total water stays within 15 % of
+    the reference's.  At most `max_exposed` columns may become exposed: the number measured for the case + 1 (ONED_TIE_COLUMNS)."""
 
-    def __init__(self, names, n_columns, max_exposed_fraction=1 / 3):
-        self.names, self.n, self.cap = names, n_columns, max_exposed_fraction
+    BALANCE, TOTAL_RTOL = 1e-9, 0.15
+
+    def __init__(self, names, n_columns, max_exposed):
+        self.names, self.n, self.cap = names, n_columns, int(max_exposed)
         self.exposed = {}     # column -> first stored step with a residue
+        self.stores = [p for p, nm in enumerate(names) if nm in TIE_STATE_PLANES or nm in ("S_rz", "S_ss", "S_s", "S")]
+
+    @classmethod
+    def for_case(cls, case, names, n_columns):
+        return cls(names, n_columns, ONED_TIE_COLUMNS[case] + 1) if case in ONED_TIE_COLUMNS else None
 
     def check(self, got, ref, step, what=""):
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
         for c in sorted(residue_columns(got, self.names) | residue_columns(ref, self.names)):
             self.exposed.setdefault(c, step)
         bad = deviating_columns(got, ref) - set(self.exposed)
         if bad:
             c = sorted(bad)[0]
-            rows = [(self.names[p], float(np.asarray(got)[p, c]), float(np.asarray(ref)[p, c])) for p in range(len(self.names))
-                    if not (np.asarray(got)[p, c] == np.asarray(ref)[p, c] or abs(np.asarray(got)[p, c] - np.asarray(ref)[p, c]) <= ATOL + RTOL * abs(np.asarray(ref)[p, c]))][:6]
+            rows = [(self.names[p], float(got[p, c]), float(ref[p, c])) for p in range(len(self.names))
+                    if not (got[p, c] == ref[p, c] or abs(got[p, c] - ref[p, c]) <= ATOL + RTOL * abs(ref[p, c]))][:6]
             raise AssertionError(f"{what} step {step}: columns {sorted(bad)} deviate without a residue in any store; column {c}: {rows}")
-        assert len(self.exposed) <= self.cap * self.n, f"{what}: {len(self.exposed)} of {self.n} columns tie-exposed: {self.exposed}"
+        assert len(self.exposed) <= self.cap, f"{what}: {len(self.exposed)} columns tie-exposed (measured for the case + 1 = {self.cap}): {self.exposed}"
+        p_err, p_tot = self.names.index("dS_num_error"), self.names.index("S")
+        for c in sorted(self.exposed):
+            where = f"{what} step {step}: tie-exposed column {c} (since step {self.exposed[c]})"
+            assert abs(got[p_err, c]) <= self.BALANCE, f"{where}: the water balance does not close: dS_num_error = {got[p_err, c]!r}"
+            v = got[self.stores, c]
+            assert np.isfinite(v).all() and (v >= -1e-6).all(), \
+                f"{where}: a store is not finite or negative: {[(self.names[p], float(got[p, c])) for p in self.stores if not (got[p, c] >= -1e-6)]}"
+            assert abs(got[p_tot, c] - ref[p_tot, c]) <= self.TOTAL_RTOL * abs(ref[p_tot, c]), \
+                f"{where}: total water {got[p_tot, c]!r} against the reference's {ref[p_tot, c]!r}"
 
 
 def compare_bulk(got, ref, names, what="", rtol_bulk=RTOL, atol_bulk=ATOL, frac_bulk=0.999, rtol_max=1e-3, atol_max=1e-6):

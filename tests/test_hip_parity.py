@@ -43,7 +43,7 @@ def test_trajectory_golden(native, case):
     drv = H.HipForcingDriver(ctx, forcing)
     nsteps = int(g["nsteps"])
     checked = 0
-    ties = TieTracker(names, ctx.n) if case in ONED_TIE_COLUMNS else None
+    ties = TieTracker.for_case(case, names, ctx.n)
     for step in range(1, nsteps + 1):
         monthly = drv.before_step()
         ctx.step(monthly)

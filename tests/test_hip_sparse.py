@@ -28,7 +28,7 @@ def test_pure_output_planes_are_never_read(native, case):  # noqa: F811
     assert len(poison) >= 60
     nan = np.full(ctx.n, np.nan)
     drv = H.HipForcingDriver(ctx, forcing)
-    ties, checked = (TieTracker(names, ctx.n) if case in ONED_TIE_COLUMNS else None), 0
+    ties, checked = (TieTracker.for_case(case, names, ctx.n)), 0
     for step in range(1, int(g["nsteps"]) + 1):
         for nm in poison:
             ctx.upload(nm, nan)
@@ -78,7 +78,7 @@ def test_run_steps_in_pieces_leaves_every_plane_as_full_steps_do(native, case): 
     a, used = _pieces(native, g, names, forcing, stops, sparse=True)
     b, none = _pieces(native, g, names, forcing, stops, sparse=False)
     assert used > 0 and none == 0
-    ties = TieTracker(names, int(np.prod(g["nx_ny"]))) if case in ONED_TIE_COLUMNS else None
+    ties = TieTracker.for_case(case, names, int(np.prod(g["nx_ny"])))
     for stop, (sa, pa), (sb, pb) in zip(stops, a, b):
         np.testing.assert_array_equal(sa, sb, err_msg=f"{case} scalars after step {stop}")
         np.testing.assert_array_equal(pa, pb, err_msg=f"{case} planes after step {stop}: sparse stores changed what the caller sees")

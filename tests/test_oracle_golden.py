@@ -65,7 +65,7 @@ def test_trajectory(oracle, case):
     drv = oracle.ForcingDriver(forcing, weights=load_weights(g), stations=load_stations(g))
     nsteps = int(g["nsteps"])
     checked = 0
-    ties = TieTracker(names, st.n) if case in ONED_TIE_COLUMNS else None   # oneD: columns exposed to a residue tie (golden_util)
+    ties = TieTracker.for_case(case, names, st.n)   # oneD: columns exposed to a residue tie (golden_util)
     for step in range(1, nsteps + 1):
         pd, td, ed, monthly = drv.before_step(st)
         st.step(pd, td, ed, monthly)
