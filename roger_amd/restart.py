@@ -137,7 +137,10 @@ def collect(state):
     vs = state.variables
     core = {}
     multi = rst.proc_num > 1
-    midnight = int(np.asarray(vs.time)) % 86400 == 0
+    # The day's 3 x (x, y, 144) forcing arrays are left out at midnight ONLY where the script's set_forcing is known to re-derive them
+    # there (the stock hook, or one recognised as doing the same: roger_amd/hooks.py); a set_forcing of the script's own that does
+    # not must find the arrays it left.
+    midnight = int(np.asarray(vs.time)) % 86400 == 0 and bool(getattr(state, "_stock_set_forcing", False))
     more = {}
     for key, var in state.var_meta.items():
         if key in _NOT_STATE or key in _FORCING_SERIES or (midnight and key in _FORCING_DAY):

@@ -274,6 +274,7 @@ class RogerSetup(metaclass=abc.ABCMeta):
             from . import hooks
 
             self._hook_classes = hooks.classify(self, self.STEP_HOOKS)
+            self.state._stock_set_forcing = bool(self._hook_classes["set_forcing"])   # (restart.collect: the day arrays at midnight)
         return self._hook_classes
 
     def _fused_host_step_possible(self):
@@ -318,6 +319,8 @@ class RogerSetup(metaclass=abc.ABCMeta):
         if getattr(state, "_diag_active", None) and not getattr(state, "_diag_transport", False):
             slots, iv = state._diag_slots, state._diag_interval   # output intervals resident on the device; their length
         limit = hasattr(ctx, "set_time_limit") and not getattr(self, "_per_cell_forcing", False) and not state.settings.enable_routing_1D
+        if rst.proc_num > 1 and not hasattr(ctx, "run_steps_dist"):
+            limit = False   # (the Python orchestration of the rehearsals, distributed.PhasedStepper, does not observe the device-side limit)
         try:
             steps0, first = int(vs.itt), True
             while True:
