@@ -859,7 +859,7 @@ def main():
             full = {"kernel": variant.replace("sparse", "lazy"), "launches": launches - n_sparse, "avg_kernel_ms": float(per_ms[n_sparse:].mean()),
                     "algorithmic_bytes_per_cell": {"load": fl, "store": fs},
                     "frac": (fl + fs) * n_local / (float(per_ms[n_sparse:].mean()) / 1e3) / 1e9 / HBM_PEAK_GBS}
-        traffic, trec = measured_traffic(variant, n_local)
+        traffic, trec = measured_traffic(variant + ("_hetero" if args.params == "hetero" else ""), n_local)
         ref_achieved = REFERENCE_BYTES_PER_CELL_STEP * n_local / k_avg_s / 1e9
         out = {
             "metric": "cell-timesteps/sec on SVAT_benchmark grid",

@@ -5,7 +5,7 @@
 # SAS bench, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated) of every benched kernel variant and size, and the VALU
 # instruction counters of the SAS kernel.  rocprofv3 is always given the program itself (python3 ...), never a wrapper.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 export RH_TAG=$tag
 what=${2:-all}
 out=gpurun_out/profiles
@@ -38,6 +38,8 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
     RH_NO_SPARSE_STORES=1 pmc_pair k_step_$1_lazy "k_step<2, $lat, true, false, false>" $3 $3 python3 tools/pmc_workload.py
   }
   svat_pairs svat 1000x1000 1000000
+  # heterogeneous parameters (drawn per column: no wave reads a parameter plane as one element; the derived parameters are still not loaded)
+  RH_PMC_PARAMS=hetero RH_PMC_MODEL=svat RH_PMC_SIZE=1000x1000 pmc_pair k_step_svat_sparse_hetero "k_step<2, false, true, true, false>" 1000000 1000000 python3 tools/pmc_workload.py
   svat_pairs oned 1000x1000 1000000
   svat_pairs svat 3200x3125 10000000
   svat_pairs oned 3200x3125 10000000
@@ -53,14 +55,19 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
   bench oned_1e7 --model oned --size 3200 3125 --steps 60 --warmup 5 --no-cpu-baseline
   bench svat_80x53 --size 80 53 --params hetero --steps 2000 --warmup 50 --no-cpu-baseline
   bench svat_80x53_station_weights --size 80 53 --params hetero --station-weights --steps 2000 --warmup 50 --no-cpu-baseline
+  bench svat_1e6_station_weights --station-weights --steps 200 --warmup 10 --no-cpu-baseline
   RH_BENCH_FORCE_DIST=1 bench svat_1e6_rccl_one_rank --steps 200 --warmup 10 --no-cpu-baseline
   bench svat_1e6_driver_command --gpus 1 --steps 20 --warmup 5
   RH_NO_SPARSE_STORES=1 bench svat_1e6_full_stores --steps 200 --warmup 10 --no-cpu-baseline
   # the benchmark as a RogerSetup script calling plain run(): stock hooks (on the device), a hook of the script's own in front of the physics (one native call per step) and the three-call step
-  for st in setup hooks routines; do
+  for st in setup script hooks routines; do
     python3 bench.py --stepping $st --days 20 --warmup-days 2 > $scratch/svat_1e6_$st.out 2> $scratch/svat_1e6_$st.err && last $scratch/svat_1e6_$st.out > $out/${tag}_bench_svat_1e6_run_$st.json && echo "run() $st ok"
     python3 bench.py --stepping $st --size 80 53 --days 60 --warmup-days 2 > $scratch/svat_80x53_$st.out 2> $scratch/svat_80x53_$st.err && last $scratch/svat_80x53_$st.out > $out/${tag}_bench_svat_80x53_run_$st.json
   done
+  # the parameter fast paths of the fused step, alternating in this very call
+  tools/ab_params.sh "--steps 200 --warmup 10" 2 ${tag}_u1e6 > $out/${tag}_ab_param_paths.txt 2>&1
+  tools/ab_params.sh "--steps 200 --warmup 10 --params hetero" 1 ${tag}_h1e6 >> $out/${tag}_ab_param_paths.txt 2>&1
+  tools/ab_params.sh "--steps 60 --warmup 5 --size 3200 3125" 1 ${tag}_u1e7 >> $out/${tag}_ab_param_paths.txt 2>&1
   # BASELINE configs[4] as written: the Eberbaechle shape over the station's full 2019-2022 series
   python3 tools/eberbaechle_full.py > $out/${tag}_eberbaechle_full_80x53.json 2> $scratch/eberbaechle_full.err && echo "eberbaechle full ok"
   # what bounds the fused step: SQ counters per launch of every k_step variant

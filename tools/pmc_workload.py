@@ -17,6 +17,7 @@ from roger_amd.svat import create_svat        # noqa: E402
 
 NX, NY = (int(v) for v in os.environ.get("RH_PMC_SIZE", "1000x1000").split("x"))
 MODEL = os.environ.get("RH_PMC_MODEL", "svat")   # svat | oned (lateral subsurface flow, benchmarks/oneD_benchmark.py:99-135) | routed (oned + enable_routing_1D)
+PARAMS = os.environ.get("RH_PMC_PARAMS", "uniform")   # uniform: the benchmark's (every wave reads its parameter planes as one element); hetero: drawn per column
 CALIB_PLANES = 96
 
 if __name__ == "__main__":
@@ -27,6 +28,10 @@ if __name__ == "__main__":
     scratch.sync()
     scratch.close()
     params = dict(z_soil=1000.0, lmpv=600.0, slope=0.05, slope_per=5, dmph=50.0) if MODEL in ("oned", "routed") else None
+    if PARAMS == "hetero":
+        from roger_amd.svat import hetero_params
+
+        params = dict(hetero_params(NX * NY, seed=42), **(params or {}))
     if MODEL == "routed":   # the workload of bench.py --model oned --routing
         params.update(flow_dir_topo=4, k_st=15.0)
         ctx = create_svat(NX, NY, params=params, lateral=True, enable_routing_1D=1, dx=5.0, dy=5.0)
