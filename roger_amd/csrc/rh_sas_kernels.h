@@ -662,6 +662,16 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
         }
     }
 
+    {
+        // The classes above ages - 1 are padding of the register layout: no flux can fill them, and blk_cumsum takes the top of the stored
+        // water from the last partial sum of the thread that owns class ages - 1 BECAUSE they hold exact zeros.  Checked once per column
+        // and day behind the fluxes (the ageing below shifts the oldest class into the padding, which is never stored); rh_sas_sync
+        // reports a violation.
+        bool padded_water = false;
+#pragma unroll
+        for (int j = 0; j < E; ++j) padded_water |= (base + j >= A) && ((sa_rz[j] != 0.0) || (sa_ss[j] != 0.0));
+        if (padded_water) atomicOr(P.unsupported, 2);
+    }
     if (P.stages & RH_SAS_AGEING) {
         if constexpr (ANION) {
             ageing_anion<W, E>(B, A, base, sa_rz, msa_rz);
@@ -673,13 +683,6 @@ __device__ __forceinline__ void sas_body(const SasArgs &P) {
     }
 
     {
-        // The classes above ages - 1 are padding of the register layout: no flux can fill them, and blk_cumsum takes the top of the stored
-        // water from the last partial sum of the thread that owns class ages - 1 BECAUSE they hold exact zeros.  Checked once per column
-        // and day, where it costs nothing (rh_sas_sync reports it).
-        bool padded_water = false;
-#pragma unroll
-        for (int j = 0; j < E; ++j) padded_water |= (base + j >= A) && ((sa_rz[j] != 0.0) || (sa_ss[j] != 0.0));
-        if (padded_water) atomicOr(P.unsupported, 2);
         double *g0 = (double *)P.a[SA_sa_rz] + cell * A, *g1 = (double *)P.a[SA_msa_rz] + cell * A;
         double *g2 = (double *)P.a[SA_sa_ss] + cell * A, *g3 = (double *)P.a[SA_msa_ss] + cell * A;
 #pragma unroll
