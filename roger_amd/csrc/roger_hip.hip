@@ -1491,73 +1491,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, u
     } else {                                                             \
         RH_SEQ_##seq##_STORE_##rt(ST) RH_SEQ_##seq##_ROT_##rt(ROT)       \
     }
-#if RH_STEP_PREFETCH >= 3
-// distance two through the short early stages (experiment, round 4): the loads of stage k + 2 are requested before stage k computes
-#define RH_PIN __builtin_amdgcn_sched_barrier(0);
-#define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
-    RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception) RH_LOADS(seq, rt_evapotranspiration) RH_PIN  \
-    rt_select_prec(c, X, prec_s, ta_s); RH_STORES(seq, rt_select_prec)                                                \
-    rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
-    q = summary_bits_pt(c.prec, c.ta, K);                                                                \
-    MON_RUN                                                                                              \
-    RH_LOADS(seq, rt_snow) RH_LOADS(seq, rt_inf_events) RH_PIN                                           \
-    rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
-    RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                  \
-    RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)  \
-    RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                              \
-    rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
-    q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
-    RH_LOADS(seq, rt_inf_cracks) RH_PIN                                                                  \
-    rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
-    RH_LOADS(seq, rt_inf_finish) RH_PIN                                                                  \
-    RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                       \
-    RH_LOADS(seq, sub_rt) RH_PIN                                                                         \
-    RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)           \
-    RH_LOADS(seq, rt_capillary_rise) RH_PIN                                                              \
-    rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
-    RH_LOADS(seq, rt_storage) RH_PIN                                                                     \
-    rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
-    RH_LOADS(seq, ne_rt) RH_PIN                                                                          \
-    RH_DERIVE(sub_rt) sub_call; RH_STORES(seq, sub_rt)                                                   \
-    RH_LOADS(seq, at_rt) RH_PIN                                                                          \
-    rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
-    RH_DERIVE(rt_storage) rt_storage(c, X); RH_STORES(seq, rt_storage)                                   \
-    bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
-    at_call; RH_STORES(seq, at_rt)
-#elif RH_STEP_PREFETCH == -4
-// distance two through interception / evapotranspiration / snow only (few registers are live there), distance one from the events on
-#define RH_PIN __builtin_amdgcn_sched_barrier(0);
-#define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
-    RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception) RH_LOADS(seq, rt_evapotranspiration) RH_PIN  \
-    rt_select_prec(c, X, prec_s, ta_s); RH_STORES(seq, rt_select_prec)                                                \
-    rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
-    q = summary_bits_pt(c.prec, c.ta, K);                                                                \
-    MON_RUN                                                                                              \
-    RH_LOADS(seq, rt_snow) RH_LOADS(seq, rt_inf_events) RH_PIN                                           \
-    rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
-    RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)  \
-    rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
-    q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
-    RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                  \
-    rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
-    RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                              \
-    RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                       \
-    RH_LOADS(seq, rt_inf_cracks) RH_PIN                                                                  \
-    RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)           \
-    RH_LOADS(seq, rt_inf_finish) RH_PIN                                                                  \
-    rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
-    RH_LOADS(seq, sub_rt) RH_PIN                                                                         \
-    rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
-    RH_LOADS(seq, rt_capillary_rise) RH_PIN                                                              \
-    RH_DERIVE(sub_rt) sub_call; RH_STORES(seq, sub_rt)                                                   \
-    RH_LOADS(seq, rt_storage) RH_PIN                                                                     \
-    rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
-    RH_LOADS(seq, ne_rt) RH_PIN                                                                          \
-    RH_DERIVE(rt_storage) rt_storage(c, X); RH_STORES(seq, rt_storage)                                   \
-    RH_LOADS(seq, at_rt) RH_PIN                                                                          \
-    bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
-    at_call; RH_STORES(seq, at_rt)
-#elif RH_STEP_PREFETCH
+#if RH_STEP_PREFETCH
 #if RH_STEP_PREFETCH >= 2
 #define RH_PIN __builtin_amdgcn_sched_barrier(0);
 #else
