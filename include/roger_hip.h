@@ -280,8 +280,11 @@ int rh_run_steps(rh_ctx *ctx, int64_t nsteps);
  * every step (`vs.q_ss = update(...)`), and inside ONE call nothing but the next step looks at the planes; so every step of a call
  * that another step follows leaves out the stores of the planes the step only PRODUCES -- planes no step reads before assigning
  * them, derived from rh_physics.h by the flow analysis of tools/liveness.py (72 of the SVAT step's 124 stored planes).  The last step
- * of a call stores everything: after the call every plane holds what n full steps leave.  Off when an accumulator
- * (rh_diag_configure) was given such a plane, and with RH_NO_SPARSE_STORES=1.
+ * of a call stores everything: after the call every plane holds what n full steps leave.  An accumulator (rh_diag_configure) that was
+ * given such a plane gets it stored after all (a third variant of the kernel); off with RH_NO_SPARSE_STORES=1.  Round 4: a sparse step
+ * also leaves out conductivity and suction of root zone and subsoil (k_rz, k_ss, h_rz, h_ss, ks_ss), which the next step -- a LAZY step:
+ * the planes were last touched by a complete step -- derives from the stored water contents instead of loading them; the first step
+ * after the host touched planes still loads them, so these five are NOT "pure outputs" in the sense below.
  *   rh_plane_is_pure_output  1 if the step of the model only produces the plane: model 0 = SVAT, 1 = oneD (fused steps), 2 = the routed
  *                            step (settings.enable_routing_1D: there a pass also keeps what a later pass of the same step loads)
  *   rh_sparse_steps          steps of the most recent rh_run_steps / rh_run_steps_dist call that ran with sparse stores */
