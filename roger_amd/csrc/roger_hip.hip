@@ -1144,31 +1144,55 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due) {
     D->X = X;
     log_dt(D, dts);
 }
-// WITH_DAILY: the daily part inline (small grids: one launch); otherwise k_cell_agg<2>-like k_cell_daily runs in front (the daily sums'
-// code needs > 200 registers, which would leave every step's part two waves per SIMD).  m1_pending as k_select's RH_SELECT_M1_PENDING.
-template <bool WITH_DAILY>
-__global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, int force_daily, int m1_pending, int grp_shift, int daily_only) {
+// PART 0: every step's part; 1: with the daily part inline (small grids: one launch); 2: the daily part alone (in front of PART 0 on large
+// grids, returning at once unless it is due: the daily sums' code needs > 200 registers, which would leave every step's part two waves per
+// SIMD).  m1_pending as k_select's RH_SELECT_M1_PENDING.  The column's planes, weights and daily sums are requested FIRST, so that their
+// round trips to HBM run under the staging of the day and the window sums.
+template <int PART>
+__global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, int force_daily, int m1_pending, int grp_shift) {
+    constexpr bool daily_only = PART == 2, with_daily = PART != 0;
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const bool weighted = D->weights[0] != nullptr;
     const bool daily_due = !weighted || force_daily || D->S.itt_day == 0;   // (uniform over the grid; k_cell_agg's rule)
     __shared__ unsigned wg_done;
     __shared__ DaySeries day;
     if (daily_only && !daily_due) return;
+    const bool in = i < a.n;
+    const int64_t ii = in ? i : a.n - 1;
+    double prec = 0, ta = 0, swe = 0, swe_top = 0, prec_m1 = 0, swe_m1 = 0, pw = 0, toff = 0, ew = 0, day0 = 0, day1 = 0;
+    if (!daily_only) {
+        rh_ld(a, RH_P_prec, ii, prec);
+        rh_ld(a, RH_P_ta, ii, ta);
+        rh_ld(a, RH_P_swe, ii, swe);
+        rh_ld(a, RH_P_swe_top, ii, swe_top);
+        if (!m1_pending) {
+            rh_ld(a, RH_P_prec_m1, ii, prec_m1);
+            rh_ld(a, RH_P_swe_m1, ii, swe_m1);
+        }
+        if (!(with_daily && daily_due)) {   // the daily sums of the day: formed earlier
+            day0 = D->agg_cell[ii];
+            day1 = D->agg_cell[(size_t)a.n + ii];
+        }
+    }
+    if (weighted) {
+        pw = D->weights[0][ii];
+        toff = D->weights[1][ii];
+        ew = D->weights[2][ii];
+    }
     if (threadIdx.x == 0) wg_done = 0;
     if (weighted) stage_day(D, day);
     else __syncthreads();
     const Consts K = D->K;
     const int64_t itd = D->S.itt_day;
     unsigned long long b = 0, db = 0;
-    if (i < a.n) {
+    if (in) {
         double agg[9];
         if (weighted) {
-            const double pw = D->weights[0][i], toff = D->weights[1][i], ew = D->weights[2][i];
             const DayView F = day_view(D, day, i);
             auto p = [&](int k) { return F(0, k) * pw; };
             auto t = [&](int k) { return F(1, k) + toff; };
             auto e = [&](int k) { return F(2, k) * ew; };
-            if ((WITH_DAILY || daily_only) && daily_due) db = front_daily(p, t, e, agg, K);
+            if (with_daily && daily_due) db = front_daily(p, t, e, agg, K);
             if (!daily_only) forcing_aggregates_of(p, t, e, itd, agg, false, true);
         } else {
             const double *pp = D->forc_cell[0] + i, *tp = D->forc_cell[1] + i, *ep = D->forc_cell[2] + i;
@@ -1176,28 +1200,20 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
             auto p = [&](int k) { return pp[k * n]; };
             auto t = [&](int k) { return tp[k * n]; };
             auto e = [&](int k) { return ep[k * n]; };
-            if ((WITH_DAILY || daily_only) && daily_due) db = front_daily(p, t, e, agg, K);
+            if (with_daily && daily_due) db = front_daily(p, t, e, agg, K);
             if (!daily_only) forcing_aggregates_of(p, t, e, itd, agg, false, true);
         }
-        if ((WITH_DAILY || daily_only) && daily_due)
+        if (with_daily && daily_due)
             for (int k = 0; k < 3; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
         if (!daily_only) {
             for (int k = 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
-            if (!((WITH_DAILY) && daily_due)) {   // the daily sums of the day: formed earlier
-                agg[0] = D->agg_cell[i];
-                agg[1] = D->agg_cell[(size_t)a.n + i];
+            if (!(with_daily && daily_due)) {
+                agg[0] = day0;
+                agg[1] = day1;
             }
-            double prec, ta, swe, swe_top, prec_m1, swe_m1;
-            rh_ld(a, RH_P_prec, i, prec);
-            rh_ld(a, RH_P_ta, i, ta);
-            rh_ld(a, RH_P_swe, i, swe);
-            rh_ld(a, RH_P_swe_top, i, swe_top);
             if (m1_pending) {
                 prec_m1 = prec;
                 swe_m1 = swe;
-            } else {
-                rh_ld(a, RH_P_prec_m1, i, prec_m1);
-                rh_ld(a, RH_P_swe_m1, i, swe_m1);
             }
             const bool snow = (swe > 0) || (swe_top > 0);
             b |= front_candidate_bits(prec, ta, snow, K.ta_fm);                                   // keep (sel_p < 0)
@@ -3155,10 +3171,10 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
         const int force = (ctx->front_daily_stale || ctx->last_front != 2) ? 1 : 0, m1 = ctx->m1_stale ? 1 : 0;
         if (ctx->n >= ctx->cell_agg_split_min) {
-            hipLaunchKernelGGL(k_cell_front<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 1);
-            hipLaunchKernelGGL(k_cell_front<false>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 0);
+            hipLaunchKernelGGL(k_cell_front<2>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
+            hipLaunchKernelGGL(k_cell_front<0>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
         } else {
-            hipLaunchKernelGGL(k_cell_front<true>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift, 0);
+            hipLaunchKernelGGL(k_cell_front<1>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
         }
         CHECK_LAUNCH(ctx);
         ctx->front_daily_stale = false;
