@@ -43,7 +43,9 @@ REFERENCE_BYTES_PER_CELL_STEP = 2779  # 1555 read + 1224 written, SURVEY.md sect
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-UNIFORM_READ_FRACTION = 1.0 / 8.0   # a wave that reads ONE element of a plane fetches a 64-byte sector instead of 512 bytes
+# a wave that reads ONE element of a plane fetches a 128-byte line instead of 512 bytes: priced at 1/4 (PMC, profiles/traffic.json: 793.6 B per
+# column measured with the benchmark's uniform parameters against 728 B of state and stores + 232 B of parameter loads x 1/4 = 786)
+UNIFORM_READ_FRACTION = 1.0 / 4.0
 
 
 def kernel_bytes_per_cell(model, variant, param_stats=None):
