@@ -135,8 +135,7 @@ struct StepCtx {
     int cond_time;
     int64_t dt_secs_prelim;
     int64_t itt_day;
-    int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 2: from the per-cell aggregate planes; 3: from the
-                          // column's own aggregates, formed in the kernel (cell_forcing_value); 0: k_select did
+    int apply_sel;        // 1: the fused kernel applies the prec/ta selection itself (summary path); 2: from the per-cell aggregates; 0: k_select did
     int forc_exhausted;   // the device-side set_forcing hook found midnight beyond the end of the resident series
     // rh_set_time_limit (RogerSetup.run(): `while vs.time - start_time < runlen`, roger/roger.py:548-556, decided on the device):
     int halt;             // the time limit was reached before this step: the launch does nothing

@@ -658,38 +658,6 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_agg(Arena a, DevState *D, int
         for (int k = 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
 }
 RH_DEV double cell_agg(const DevState *D, int64_t n, int64_t i, int k) { return D->agg_cell[(size_t)k * n + i]; }
-// ONE aggregate of a column's day, formed where it is needed (round 4): cls 0 the daily sum (a plane: formed once a day), 1 the hourly
-// window, 2 the current ten-minute slot; var 0 prec, 1 ta, 2 pet -- the very operations of forcing_aggregates_of (numpy's pairwise
-// order over the window, nanmean's divisor), so the same bits as the nine planes k_cell_agg writes.  A step needs the aggregates of the
-// class the day's predicates select (prec / ta: sel_p) and of the step's own class (pet / ta: sel_w) only: the selection kernel and the
-// fused kernel evaluate those themselves instead of every column storing six values per step for them to load two or four.  cls and
-// var are uniform over the grid.  lds: the shared series of the day staged by stage_day (weighted station forcing).
-template <class Get>
-RH_DEV double window_or_slot(Get get, int cls, bool is_ta, int64_t itd) {
-    if (cls == 1) {
-        if (!is_ta) return np_sum144_window(get, itd);
-        int cnt = 0;
-        for (int w = 0; w < 6; ++w) {
-            const int64_t k = itd + w;
-            cnt += (k >= 0 && k < 144) && !isnan(get((int)k));
-        }
-        return np_sum144_window([&](int k) { const double v = get(k); return isnan(v) ? 0.0 : v; }, itd) / (double)cnt;
-    }
-    int64_t k = itd < 0 ? itd + 144 : itd;
-    k = k > 143 ? 143 : k;
-    return get((int)k);
-}
-RH_DEV double cell_forcing_value(const DevState *D, const DaySeries &lds, int64_t n, int64_t i, int cls, int var, int64_t itd) {
-    if (cls == 0) return D->agg_cell[(size_t)var * n + i];
-    if (D->weights[0]) {
-        const DayView F = day_view(D, lds, i);
-        const double w = D->weights[var][i];
-        if (var == 1) return window_or_slot([&](int k) { return F(1, k) + w; }, cls, true, itd);
-        return window_or_slot([&](int k) { return F(var, k) * w; }, cls, false, itd);
-    }
-    const double *p = D->forc_cell[var] + i;
-    return window_or_slot([&](int k) { return p[(size_t)k * n]; }, cls, var == 1, itd);
-}
 
 
 // mode: RH_SELECT_M1_PENDING = the tau -> taum1 copies of the last fused step are still pending (lazy rotation): prec_m1 / swe_m1 are
@@ -697,15 +665,11 @@ RH_DEV double cell_forcing_value(const DevState *D, const DaySeries &lds, int64_
 // (StepCtx.apply_sel = 2) -- the planes stay untouched between two fused steps, so the rotation can stay pending
 #define RH_SELECT_M1_PENDING 1
 #define RH_SELECT_DEFER 2
-#define RH_SELECT_COMPUTE 4   // the column's selected aggregates are formed here (cell_forcing_value), not read from the aggregate planes
 __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D, int mode) {
     const Consts K = D->K;
     const StepCtx X = D->X;
     const bool per_cell = D->per_cell != 0;
     unsigned long long b = 0;
-    __shared__ DaySeries day;
-    const bool compute = per_cell && (mode & RH_SELECT_COMPUTE) && X.sel_p >= 0;
-    if (compute && D->weights[0] != nullptr) stage_day(D, day);
     for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * RH_BLOCK) {
         Col c;
         rh_ld(a, RH_P_prec, i, c.prec);
@@ -721,9 +685,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_select(Arena a, DevState *D, int m
             rh_ld(a, RH_P_swe_m1, i, swe_m1);
         }
         if (X.sel_p >= 0) {
-            if (compute)
-                rt_select_prec_ta(c, X, cell_forcing_value(D, day, a.n, i, X.sel_p, 0, X.itt_day), cell_forcing_value(D, day, a.n, i, X.sel_p, 1, X.itt_day));
-            else if (per_cell)
+            if (per_cell)
                 rt_select_prec_ta(c, X, cell_agg(D, a.n, i, 3 * X.sel_p), cell_agg(D, a.n, i, 3 * X.sel_p + 1));
             else
                 rt_select_prec_ta(c, X, X.prec_sel, X.ta_sel);
@@ -1174,7 +1136,7 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due) {
     w1 |= bit(cells, FC_COMMON + 1) ? BIT(PC_SWE_NOT_LE0) : 0;
     w1 |= bit(cells, FC_COMMON + 2) ? BIT(PC_PM1_NE0) : 0;
     w1 |= bit(cells, FC_COMMON + 3) ? BIT(PC_PM1_EQ0) : 0;
-    const int64_t dts = scalars_update(S, X, w1, 1, 3, true, D->K.end_event);   // (apply_sel 3: the fused kernel forms the selected aggregates itself)
+    const int64_t dts = scalars_update(S, X, w1, 1, 2, true, D->K.end_event);
     D->words[0] = 0;
     D->words[1] = 0;
     D->words[2] = 0;
@@ -1244,6 +1206,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
         if (with_daily && daily_due)
             for (int k = 0; k < 3; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
         if (!daily_only) {
+            for (int k = 3; k < 9; ++k) D->agg_cell[(size_t)k * a.n + i] = agg[k];
             if (!(with_daily && daily_due)) {
                 agg[0] = day0;
                 agg[1] = day1;
@@ -1634,33 +1597,21 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
 // KEEP (with SPARSE): an accumulator was given planes the sparse kernel does not store -- those are stored after all (DevState::keep)
 template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE, bool KEEP = false, bool MK1 = false>
-RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep, unsigned long long um,
-                        const DaySeries &day) {
+RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep, unsigned long long um) {
     {
     const Consts K = D->K;
     const StepCtx X = *Xp;
     Col c;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     double prec_s = X.prec_sel, ta_s = X.ta_sel;   // the column's own when the per-cell selection was deferred to this kernel
-#ifndef RH_CENSUS   // (tools/isa_census.py counts the step with shared forcing: the per-cell path's loads and arithmetic are left out)
-    if (D->per_cell && X.apply_sel == 3) {   // the column forms the aggregates it needs itself (cell_forcing_value; `day` staged by k_step)
-        if (X.sel_w >= 0) {
-            pet_v = cell_forcing_value(D, day, a.n, i, X.sel_w, 2, X.itt_day);
-            ta_v = cell_forcing_value(D, day, a.n, i, X.sel_w, 1, X.itt_day);
-        }
-        if (X.sel_p >= 0) {
-            prec_s = cell_forcing_value(D, day, a.n, i, X.sel_p, 0, X.itt_day);
-            ta_s = cell_forcing_value(D, day, a.n, i, X.sel_p, 1, X.itt_day);
-        }
-    } else if (D->per_cell) {
-        if (X.sel_w >= 0) {
-            pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
-            ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
-        }
-        if (X.apply_sel == 2 && X.sel_p >= 0) {
-            prec_s = cell_agg(D, a.n, i, 3 * X.sel_p);
-            ta_s = cell_agg(D, a.n, i, 3 * X.sel_p + 1);
-        }
+#ifndef RH_CENSUS   // (tools/isa_census.py counts the step with shared forcing: these four loads belong to the per-cell path only)
+    if (D->per_cell && X.sel_w >= 0) {
+        pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
+        ta_v = cell_agg(D, a.n, i, 3 * X.sel_w + 1);
+    }
+    if (X.apply_sel == 2 && D->per_cell && X.sel_p >= 0) {
+        prec_s = cell_agg(D, a.n, i, 3 * X.sel_p);
+        ta_s = cell_agg(D, a.n, i, 3 * X.sel_p + 1);
     }
 #endif
     if (MONTHLY && LATERAL) {
@@ -1714,13 +1665,6 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     if (halted) return;
 #endif
     if (threadIdx.x == 0) wg_done = 0;
-#ifndef RH_CENSUS
-    __shared__ DaySeries day_s;       // per-cell forcing with in-kernel aggregates (apply_sel == 3): the shared series of the day
-    if (D->per_cell && Xp->apply_sel == 3 && D->weights[0] != nullptr)
-        for (int k = threadIdx.x; k < 3 * RH_SLOTS_PER_DAY; k += RH_BLOCK) day_s.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
-#else
-    DaySeries day_s;
-#endif
     __syncthreads();                  // (at the start, where all waves are in step; the kernel has no closing barrier)
     unsigned long long q = 0;
     bool bad = false;
@@ -1747,13 +1691,13 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #else
         if (SPARSE && !Xp->last) {
 #endif
-            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um, day_s);
-            else if (mk1) step_column<false, LATERAL, LAZY, SPARSE, KEEP, LAZY>(a, D, Xp, i, q, bad, dep, um, day_s);
-            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um, day_s);
+            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
+            else if (mk1) step_column<false, LATERAL, LAZY, SPARSE, KEEP, LAZY>(a, D, Xp, i, q, bad, dep, um);
+            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
         } else {
             // (the full-store pipeline keeps the generic code: with a third copy the full-store kernels spill registers)
-            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um, day_s);
-            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um, day_s);
+            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
+            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
         }
     } else {
         post_summary(D, 0ull, dep);
@@ -3251,23 +3195,15 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
     ctx->pred_daily_stale = false;
     LAUNCH_WG(ctx, k_agg, ctx->dev, hooks, 1);
-    const bool defer = ctx->per_cell && ctx->defer_select_ok;   // (shared forcing on this path, e.g. before the series is resident: k_select stores)
-    // round 4: with the deferred selection the columns' hourly and ten-minute aggregates are formed where they are used -- the selection
-    // kernel and the fused kernel each evaluate the one class they need (cell_forcing_value) --, so only the DAILY sums are formed
-    // ahead, once a day (k_cell_agg<2>, which returns at once unless they are due); RH_PER_CELL_AGG_PLANES=1: the nine planes of round 3
-    static const bool agg_planes = std::getenv("RH_PER_CELL_AGG_PLANES") != nullptr;
-    const bool inline_agg = defer && !agg_planes;
     if (ctx->per_cell) {
-        if (inline_agg)
-            hipLaunchKernelGGL(k_cell_agg<2>, dim3(grid_for(ctx->n)), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->agg_daily_stale ? 1 : 0);
-        else
-            launch_cell_agg(ctx);
+        launch_cell_agg(ctx);
         ctx->agg_daily_stale = false;
     }
+    const bool defer = ctx->per_cell && ctx->defer_select_ok;   // (shared forcing on this path, e.g. before the series is resident: k_select stores)
     if (!defer) planes_touched(ctx);
     hipLaunchKernelGGL(k_select, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev,
-                       (ctx->m1_stale ? RH_SELECT_M1_PENDING : 0) | (defer ? RH_SELECT_DEFER : 0) | (inline_agg ? RH_SELECT_COMPUTE : 0));
-    LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1, inline_agg ? 3 : (defer ? 2 : 0));
+                       (ctx->m1_stale ? RH_SELECT_M1_PENDING : 0) | (defer ? RH_SELECT_DEFER : 0));
+    LAUNCH_WG(ctx, k_scalars, ctx->dev, 1, 1, defer ? 2 : 0);
     int rc = launch_fused_kernel(ctx, monthly);
     if (rc) return rc;
     CHECK_LAUNCH(ctx);
