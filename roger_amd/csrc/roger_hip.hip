@@ -2630,6 +2630,11 @@ int rh_download(rh_ctx *ctx, int plane, void *host, size_t bytes) {
 
 void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
     if (!ctx || plane < 0 || plane >= ctx->planes_held) return nullptr;
+    if (ctx->outputs_stale && pure_output_planes()[ctx->cfg.enable_routing_1D ? 2 : (ctx->cfg.enable_lateral_flow ? 1 : 0)][plane]) {
+        // (as rh_download: only after a stepping call that ended before its final, full-store step -- ADVICE r3)
+        fail(ctx, RH_ERR_STATE, "rh_plane_device_ptr: the last rh_run_steps call ended before its final step; this plane holds an earlier step's values");
+        return nullptr;
+    }
     planes_touched(ctx);  // the caller may write through the pointer
 #if RH_TILED
     return ctx->arena.base + (size_t)plane * RH_SLOT_BYTES;   // cell i: + (i / 64) * tile_bytes + (i % 64) * element size
