@@ -112,3 +112,19 @@ def test_a_terminated_launcher_takes_its_ranks_with_it():
         except ProcessLookupError:
             alive = False
         assert not alive, f"rank process {pid} survived its launcher"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepping,on_device", [("script", True), ("hooks", False)])
+def test_bench_as_a_setup_script(stepping, on_device):
+    """`bench.py --stepping script`: the benchmark as a RogerSetup script with its OWN set_forcing / set_parameters / after_timestep (the
+    reference's bodies, benchmarks/SVAT_benchmark.py:105-110, 152-181) is recognised hook by hook and run() stays on the device;
+    `--stepping hooks`: a hook that does something of its own keeps the loop on the host behind one native call per step."""
+    r = subprocess.run([sys.executable, BENCH, "--stepping", stepping, "--size", "80", "53", "--days", "4", "--warmup-days", "1"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    hooks = rec["config"]["hooks_on_device"]
+    assert all(hooks[h] for h in ("set_forcing", "set_parameters", "after_timestep"))
+    assert hooks["read_data"] is on_device
+    assert rec["steps"] >= 4 and rec["value"] > 0
