@@ -81,10 +81,6 @@ class Probe:
         self.calls = []
 
 
-def probing(state):
-    return state is not None and state._variables is not None and state._variables._probe is not None
-
-
 def record_kernel_call(state, name, native_entry):
     """Called by the @roger_kernel wrapper / run_native while a probe is active: the kernel is logged, not run."""
     state._variables._probe.calls.append(native_entry or ("host:" + name))
