@@ -96,7 +96,7 @@ def test_a_terminated_launcher_takes_its_ranks_with_it():
     env = _env(RH_BENCH_TEST_HANG="1")
     p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     pids = []
-    t_end = time.monotonic() + 120
+    t_end = time.monotonic() + 400   # (the ranks announce themselves after `import torch`, which can take minutes in a fresh container)
     while len(pids) < 2 and time.monotonic() < t_end:   # the ranks announce themselves, then wait
         line = p.stdout.readline()
         if line.startswith("rank-pid "):
