@@ -93,14 +93,24 @@ def test_a_terminated_launcher_takes_its_ranks_with_it():
     import signal
     import time
 
+    import threading
+
     env = _env(RH_BENCH_TEST_HANG="1")
     p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     pids = []
-    t_end = time.monotonic() + 400   # (the ranks announce themselves after `import torch`, which can take minutes in a fresh container)
-    while len(pids) < 2 and time.monotonic() < t_end:   # the ranks announce themselves, then wait
-        line = p.stdout.readline()
-        if line.startswith("rank-pid "):
-            pids.append(int(line.split()[1]))
+
+    def reader():   # (a thread: a launcher that never prints must fail the test, not hang it)
+        for line in p.stdout:
+            if line.startswith("rank-pid "):
+                pids.append(int(line.split()[1]))
+                if len(pids) == 2:
+                    return
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    th.join(timeout=400)   # (the ranks announce themselves after `import torch`, which can take minutes in a fresh container)
+    if len(pids) != 2:
+        p.kill()
     assert len(pids) == 2
     p.send_signal(signal.SIGTERM)
     assert p.wait(timeout=60) == 128 + signal.SIGTERM
