@@ -1513,38 +1513,49 @@ __global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, u
 #else
 #define RH_PIN
 #endif
+#ifdef RH_STEP_PHASES   // measurement builds (tools/step_phases.sh): wave cycles per stage of the step, by class of step length
+__device__ unsigned long long g_step_phases[256 * 64];   // 256 copies (one address would serialise the chip's atomics)
+#define RH_PH(k)                                                                          \
+    if ((threadIdx.x & 63) == 0) {                                                        \
+        const unsigned long long t_ = clock64();                                          \
+        atomicAdd(&g_step_phases[(blockIdx.x & 255) * 64 + ph_cls * 20 + (k)], t_ - ph_t);                          \
+        ph_t = t_;                                                                        \
+    }
+#else
+#define RH_PH(k)
+#endif
 #define RH_STEP_BODY(seq, mon_rt, MON_LOADS, MON_RUN, sub_rt, sub_call, ne_rt, ne_call, at_rt, at_call) \
     RH_LOADS(seq, rt_select_prec) RH_LOADS(seq, rt_select_pet) MON_LOADS RH_LOADS(seq, rt_interception) RH_PIN  \
     rt_select_prec(c, X, prec_s, ta_s); RH_STORES(seq, rt_select_prec)                                                \
-    rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet)                                      \
+    rt_select_pet(c, X, pet_v, ta_v); RH_STORES(seq, rt_select_pet) RH_PH(1)                                      \
     q = summary_bits_pt(c.prec, c.ta, K);                                                                \
     MON_RUN                                                                                              \
     RH_LOADS(seq, rt_evapotranspiration) RH_PIN                                                                 \
-    rt_interception(c, K); RH_STORES(seq, rt_interception)                                               \
+    rt_interception(c, K); RH_STORES(seq, rt_interception) RH_PH(2)                                               \
     RH_LOADS(seq, rt_snow) RH_PIN                                                                               \
-    RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration)  \
+    RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration) RH_PH(3)  \
     RH_LOADS(seq, rt_inf_events) RH_PIN                                                                         \
-    rt_snow(c, K, X); RH_STORES(seq, rt_snow)                                                            \
+    rt_snow(c, K, X); RH_STORES(seq, rt_snow) RH_PH(4)                                                            \
     q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
     RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                         \
-    rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events)                                                \
+    rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events) RH_PH(5)                                                \
     RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                                     \
-    RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix)                       \
+    RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X); RH_STORES(seq, rt_inf_matrix) RH_PH(6)                       \
     RH_LOADS(seq, rt_inf_cracks) RH_PIN                                                                         \
-    RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores)           \
+    RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X); RH_STORES(seq, rt_inf_macropores) RH_PH(7)           \
     RH_LOADS(seq, rt_inf_finish) RH_PIN                                                                         \
-    rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks)                                                \
+    rt_inf_cracks(c, K, X); RH_STORES(seq, rt_inf_cracks) RH_PH(8)                                                \
     RH_LOADS(seq, sub_rt) RH_PIN                                                                                \
-    rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish)                                                \
+    rt_inf_finish(c, K, X); RH_STORES(seq, rt_inf_finish) RH_PH(9)                                                \
     RH_LOADS(seq, rt_capillary_rise) RH_PIN                                                                     \
-    RH_DERIVE(sub_rt) sub_call; RH_STORES(seq, sub_rt)                                                   \
+    RH_DERIVE(sub_rt) sub_call; RH_STORES(seq, sub_rt) RH_PH(10)                                                   \
     RH_LOADS(seq, rt_storage) RH_PIN                                                                            \
-    rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise)                                           \
+    rt_capillary_rise(c, X); RH_STORES(seq, rt_capillary_rise) RH_PH(11)                                           \
     RH_LOADS(seq, ne_rt) RH_PIN                                                                                 \
-    RH_DERIVE(rt_storage) rt_storage(c, X); RH_STORES(seq, rt_storage)                                   \
+    RH_DERIVE(rt_storage) rt_storage(c, X); RH_STORES(seq, rt_storage) RH_PH(12)                                   \
     RH_LOADS(seq, at_rt) RH_PIN                                                                                 \
-    bad = ne_call; RH_STORES(seq, ne_rt)                                                                 \
-    at_call; RH_STORES(seq, at_rt)
+    bad = ne_call; RH_STORES(seq, ne_rt) RH_PH(13)                                                                 \
+    at_call; RH_STORES(seq, at_rt) RH_PH(14)
 #else
 #define RH_STAGE(seq, rt, call) RH_LOADS(seq, rt) call; RH_STORES(seq, rt)
 #ifdef RH_NO_SELSTAGE  // timing experiments only
@@ -1604,6 +1615,11 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
     Col c;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     double prec_s = X.prec_sel, ta_s = X.ta_sel;   // the column's own when the per-cell selection was deferred to this kernel
+#ifdef RH_STEP_PHASES
+    const int ph_cls = X.dt < 0.5 ? 0 : (X.dt < 12 ? 1 : 2);
+    unsigned long long ph_t = clock64();
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_step_phases[(blockIdx.x & 255) * 64 + ph_cls * 20 + 19], 1ull);
+#endif
 #ifndef RH_CENSUS   // (tools/isa_census.py counts the step with shared forcing: these four loads belong to the per-cell path only)
     if (D->per_cell && X.sel_w >= 0) {
         pet_v = cell_agg(D, a.n, i, 3 * X.sel_w + 2);
@@ -2530,6 +2546,25 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
 void rh_destroy(rh_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+#ifdef RH_STEP_PHASES
+    {
+        static unsigned long long all[256 * 64];
+        unsigned long long h[60] = {0};
+        if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_step_phases), sizeof(all)) == hipSuccess) {
+            for (int b = 0; b < 256; ++b)
+                for (int k = 0; k < 60; ++k) h[k] += all[b * 64 + k];
+            static const char *cls[3] = {"10min", "hourly", "daily"};
+            for (int c = 0; c < 3; ++c) {
+                if (!h[c * 20 + 19]) continue;
+                double tot = 0;
+                for (int k = 0; k < 19; ++k) tot += (double)h[c * 20 + k];
+                std::fprintf(stderr, "step phases %s: %llu waves, cycles per wave %.0f:", cls[c], h[c * 20 + 19], tot / (double)h[c * 20 + 19]);
+                for (int k = 1; k <= 14; ++k) std::fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)h[c * 20 + k] / tot);
+                std::fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     for (auto &ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->dt_log_buf) (void)hipFree(ctx->dt_log_buf);
     for (auto &b : ctx->forc_cell_buf)
