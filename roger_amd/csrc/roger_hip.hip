@@ -37,13 +37,17 @@
 #define RH_STRIDE_PAD 0
 #endif
 #define RH_PRED_BLOCKS 1024  // grid of the grid-stride predicate kernels
-#define RH_DONE_GROUPS 1024  // completion counters of the fused kernel (two levels: workgroup -> group -> grid)
+#define RH_DONE_GROUPS 256   // completion counters of the fused kernel (two levels: workgroup -> group -> grid), a cache line each
+#define RH_DONE_STRIDE 32   // (unsigned ints: 128 bytes)
 #define RH_DEVERR_FORCING 1u // a step began a day beyond the end of the resident forcing series
 // flags of k_step / sources of k_ctrl
 #define RH_TAIL_USE_NEXT 1   // this step runs on S_next / X_next (the previous kernel's tail formed them); its tail commits them
 #define RH_TAIL_CTRL 2       // the tail forms the next step's S_next / X_next
 #define RH_TAIL_HOOKS 4      // ... including the device-side set_forcing / set_parameters hooks
 #define RH_SRC_WORD3 0       // the summary word sits in words[3] (a fused kernel ran last)
+#ifndef RH_WSTRIDE
+#define RH_WSTRIDE 16       // words between two slots of the device-wide OR words (sumw, frontw, dayw): 128 bytes -- a slot per cache line
+#endif
 #define RH_SRC_SUMW 1        // ... in sumw[] (k_summary rebuilt it from the arena)
 #ifndef RH_STEP_PREFETCH
 // 0: a stage's planes are requested right in front of it.  1: the NEXT stage's planes are requested before the current stage computes
@@ -74,8 +78,8 @@ struct DevState {
     // summary path: the QB_* bits of every column at the end of a step, OR-ed by the fused kernel's wavefronts into 64 words
     // (device-scope atomics, word = workgroup mod 64: ~250 atomics per address and step at 10^6 columns); the last wavefront
     // to finish folds them into words[3] and runs the control part of the NEXT step on S_next / X_next (step_tail)
-    unsigned long long sumw[64];
-    unsigned int done_grp[RH_DONE_GROUPS];   // workgroups finished per group of 2^grp_shift workgroups
+    unsigned long long sumw[64 * RH_WSTRIDE];   // 64 slots, one per cache line (RH_WSTRIDE)
+    unsigned int done_grp[RH_DONE_GROUPS * RH_DONE_STRIDE];   // workgroups finished per completion group (workgroup b belongs to group b mod n_groups)
     unsigned int done_top;                   // groups finished
     unsigned long long sanity_last;          // words[2] of the last fused step (the tail clears words[2] for the next one)
     unsigned int err_flags;                  // RH_DEVERR_*
@@ -102,7 +106,7 @@ struct DevState {
     // per-cell forcing, one launch in front of the fused kernel (k_cell_front): frontw = the waves' column bits of the step (word 0's
     // snow bits, word 1's terms for each candidate selection), dayw = the forcing bits of the DAY over all columns and slots (formed
     // once a day, folded into day_word by the front kernel's last wavefront)
-    unsigned long long frontw[64], dayw[64], day_word;
+    unsigned long long frontw[64 * RH_WSTRIDE], dayw[64 * RH_WSTRIDE], day_word;
     int per_cell;
     // whole forcing series resident on the device (rh_set_forcing_series): 10-minute PREC/TA/PET
     // and the calendar vectors, as the benchmark's set_forcing_setup holds them in vs.PREC, ...
@@ -171,7 +175,7 @@ struct rh_ctx {
     bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
     int pending_hooks;    // ... formed with / without the device-side hooks
     bool tail_ok;         // RH_NO_TAIL_CTRL unset
-    int grp_shift;        // fused kernel: 2^grp_shift workgroups per completion group
+    int n_groups;         // fused kernel: completion groups (about 64 workgroups each, at most RH_DONE_GROUPS)
     // lazy tau -> taum1 rotation (k_step<.,.,LAZY>): rot_consistent = the last thing that touched the planes was a complete
     // fused step, i.e. X_m1 == X logically for every rotation pair; m1_stale = the X_m1 PLANES do not hold that yet
     bool rot_consistent, m1_stale, lazy_ok, diag_reads_m1;
@@ -185,10 +189,12 @@ struct rh_ctx {
     bool pred_daily_stale;  // the same for the day's forcing bits kept by k_pred1
     bool front_daily_stale = true;   // ... and for the one-launch front (k_cell_front: daily sums + DevState::day_word)
     bool cell_front_ok = true;       // RH_PER_CELL_OLD_FRONT unset: per-cell forcing takes k_cell_front instead of the five predicate-generation launches
-    int64_t cell_front_max = 131072; // ... on grids up to this many columns (RH_CELL_FRONT_MAX).  Measured, round 4 (profiles/r04_per_cell_front.txt):
-                                     // 80 x 53 columns 0.055 -> 0.046 ms per step (launch-bound: two launches instead of six in front of the fused
-                                     // kernel), 10^6 columns 0.280 -> 0.320 ms -- one thread doing a column's aggregates, plane reads and bits in
-                                     // sequence is latency-bound (108 us against 85 us for the five kernels, two of which are grid-stride)
+    int64_t cell_front_max = 2097152; // ... on grids up to this many columns (RH_CELL_FRONT_MAX).  Measured, round 4 (profiles/r04_per_cell_front.txt), ms
+                                     // per step with the predicate kernels / with the front: 80 x 53 columns 0.055 / 0.039 (launch-bound: one
+                                     // launch in front of the fused kernel instead of six -- the set_forcing hook rides along), 10^6 columns
+                                     // 0.261 / 0.252, 10^7 columns 2.15 / 2.23 (one thread doing a column's aggregates, plane reads and bits in
+                                     // sequence is latency-bound; two of the five predicate kernels are grid-stride).  Before the slots of the
+                                     // device-wide words and the completion counters had a cache line each, the front took 0.320 ms at 10^6.
     int last_front = 0;              // which of the two formed the day's cached parts last (1 old, 2 new): the other re-forms them when it takes over
     double *diag_buf;
     long long *diag_steps_buf;
@@ -321,8 +327,28 @@ RH_DEV double np_sum144(Get get) {
 // consecutive slots fall into six different lanes of the two 72-blocks (lane = slot mod 8), every lane also receives
 // zeros (v + 0.0: a negative zero becomes positive, as in the full sum), and the lanes are combined as np_sum72 does.
 // itd is uniform over the grid, so the lane selection is scalar work.
+// A window that lies inside one 72-block (every hourly step's: itd a multiple of 6) with a start that is the same over the wavefront
+// takes the short way: the six values sit in six of the eight lanes of ONE block in rotated order, r = itd mod 8 says where, and each of
+// the eight rotations is the tree ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)) with its two zero lanes written out of it (x + 0.0 = x
+// for everything but a negative zero, which `+ 0.0` on the way in has removed; the other block's 0.0 and the leading 0.0 + likewise):
+// five additions behind a scalar branch instead of 96 selects per sum (k_cell_agg<1> at 10^6 columns: 39 -> 17 us).
 template <class Get>
 RH_DEV double np_sum144_window(Get get, int64_t itd) {
+    const int iu = __builtin_amdgcn_readfirstlane((int)itd);
+    if (__all((int64_t)iu == itd) && iu >= 0 && iu + 6 <= RH_SLOTS_PER_DAY && !(iu < 72 && iu + 6 > 72)) {
+        const double v0 = get(iu) + 0.0, v1 = get(iu + 1) + 0.0, v2 = get(iu + 2) + 0.0, v3 = get(iu + 3) + 0.0, v4 = get(iu + 4) + 0.0,
+                     v5 = get(iu + 5) + 0.0;
+        switch (iu & 7) {
+        case 0: return ((v0 + v1) + (v2 + v3)) + (v4 + v5);
+        case 1: return (v0 + (v1 + v2)) + ((v3 + v4) + v5);
+        case 2: return (v0 + v1) + ((v2 + v3) + (v4 + v5));
+        case 3: return (v5 + v0) + ((v1 + v2) + (v3 + v4));
+        case 4: return (v4 + v5) + ((v0 + v1) + (v2 + v3));
+        case 5: return ((v3 + v4) + v5) + (v0 + (v1 + v2));
+        case 6: return ((v2 + v3) + (v4 + v5)) + (v0 + v1);
+        default: return ((v1 + v2) + (v3 + v4)) + (v5 + v0);
+        }
+    }
     double lane[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -437,27 +463,55 @@ __global__ __launch_bounds__(RH_BLOCK) void k_set_forcing(DevState *D) { hooks_s
 struct DaySeries {
     double f[3][RH_SLOTS_PER_DAY];
 };
-RH_DEV void stage_day(const DevState *D, DaySeries &s) {
-    for (int k = threadIdx.x; k < 3 * RH_SLOTS_PER_DAY; k += RH_BLOCK) s.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
+// The day a kernel in front of the fused step works on when the set_forcing hook rides along (k_cell_front): at midnight, with a day left
+// in the resident series, that is the NEXT day -- read straight from the series; the kernel's last wavefront then does what the hook does to
+// the state (front_ctrl), and nothing has to run in front of the kernel.
+struct FreshDay {
+    bool fresh;     // the hook finds midnight and a day left: the new day
+    bool missing;   // midnight, but the series is exhausted (the step runs on yesterday's forcing and the error is reported)
+    int64_t i0;     // first slot of the new day in the series
+    int64_t itd;    // itt_day as the hook leaves it
+};
+RH_DEV FreshDay fresh_day(const DevState *D, int hooks) {
+    FreshDay f;
+    const bool midnight = hooks && (D->S.time % 86400 == 0);
+    f.i0 = D->S.itt_forc;
+    f.fresh = midnight && (f.i0 + RH_SLOTS_PER_DAY <= D->nitt_forc);
+    f.missing = midnight && !f.fresh;
+    f.itd = f.fresh ? 0 : D->S.itt_day;
+    return f;
+}
+RH_DEV void stage_day(const DevState *D, DaySeries &s, const FreshDay *fd = nullptr) {
+    const bool fresh = fd && fd->fresh;
+    for (int k = threadIdx.x; k < 3 * RH_SLOTS_PER_DAY; k += RH_BLOCK) {
+        const int v = k / RH_SLOTS_PER_DAY, j = k % RH_SLOTS_PER_DAY;
+        s.f[v][j] = fresh ? D->series[v][fd->i0 + j] : D->forc[v][j];
+    }
     __syncthreads();
 }
 // The day's series as a column sees it: the one shared series staged in LDS, or -- with several stations -- its station's rows of
-// forc_multi (a table of 3 x n_stations x 144 values: cache-resident); a column without a station reads zeros.
+// forc_multi (a table of 3 x n_stations x 144 values: cache-resident; on a fresh day the rows of the series themselves); a column without
+// a station reads zeros.
 struct DayView {
     const DaySeries *lds;
-    const double *multi;
-    int S, st;
+    const double *sv[3];   // several stations: slot 0 of station 0, per variable
+    size_t ststride;       // ... and the distance between two stations
+    bool multi;
+    int st;
     RH_DEV double operator()(int v, int k) const {
         if (!multi) return lds->f[v][k];
-        return st < 0 ? 0.0 : multi[((size_t)v * S + st) * RH_SLOTS_PER_DAY + k];
+        return st < 0 ? 0.0 : sv[v][(size_t)st * ststride + k];
     }
 };
-RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i) {
+RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i, const FreshDay *fd = nullptr) {
     DayView d;
     d.lds = &lds;
-    d.multi = D->n_stations > 0 ? D->forc_multi : nullptr;
-    d.S = D->n_stations;
-    d.st = D->n_stations > 0 ? D->station_idx[i] : 0;
+    d.multi = D->n_stations > 0;
+    d.st = d.multi ? D->station_idx[i] : 0;
+    const bool fresh = fd && fd->fresh;
+    for (int v = 0; v < 3; ++v)
+        d.sv[v] = !d.multi ? nullptr : (fresh ? D->series[v] + fd->i0 : D->forc_multi + (size_t)v * D->n_stations * RH_SLOTS_PER_DAY);
+    d.ststride = fresh ? (size_t)D->nitt_forc : (size_t)RH_SLOTS_PER_DAY;
     return d;
 }
 // start-of-step predicates over the columns (adaptive_time_stepping.py:38-81), grid-stride
@@ -1007,8 +1061,8 @@ __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src,
     if (src64) {
         cells = wave_or(src64[lane] ? (1ull << lane) : 0ull);
     } else if (src == RH_SRC_SUMW) {
-        cells = wave_or(dev_load(&D->sumw[lane]));
-        dev_store(&D->sumw[lane], 0ull);
+        cells = wave_or(dev_load(&D->sumw[lane * RH_WSTRIDE]));
+        dev_store(&D->sumw[lane * RH_WSTRIDE], 0ull);
     } else {
         cells = D->words[3];
     }
@@ -1026,10 +1080,26 @@ __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src,
 // The tail of the fused kernel, run by the wavefront that finishes last: folds the summary words into words[3] (and, for the
 // exchange between ranks, spreads them over 64 int32), latches the sanity word, commits S_next / X_next if the step ran on them,
 // and forms the next step's S_next / X_next (the control part of the next step: no control kernel between two fused kernels).
+// A workgroup reports itself done; true for the one that is the last of the grid.  Two levels of counters -- workgroup b counts into
+// group b mod n_groups, a full group into the top counter --, every counter in a cache line of its own and neighbouring workgroups in
+// different groups: device-scope atomics on ONE line are served one after the other (~ 25 ns each; 3 907 workgroups counting into the two
+// lines of 62 packed counters kept a 50 us kernel waiting for them, and the fused kernel's waves for their slot).  The counters reset
+// themselves.  Called by one lane, after everything the workgroup posted through device-scope atomics has returned.
+RH_DEV bool grid_completion(DevState *D, int n_groups) {
+    const unsigned nblk = gridDim.x, ng = (unsigned)n_groups < nblk ? (unsigned)n_groups : nblk;
+    const unsigned g = blockIdx.x % ng, cnt = nblk / ng + (g < nblk % ng ? 1u : 0u);
+    unsigned int *c = &D->done_grp[g * RH_DONE_STRIDE];
+    if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cnt - 1) return false;
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ng == 1) return true;   // (small grids: one level -- a round trip less in a launch-bound step)
+    if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ng - 1) return false;
+    __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     const int lane = threadIdx.x & 63;
-    const unsigned long long cells = wave_or(dev_load(&D->sumw[lane]));
-    dev_store(&D->sumw[lane], 0ull);
+    const unsigned long long cells = wave_or(dev_load(&D->sumw[lane * RH_WSTRIDE]));
+    dev_store(&D->sumw[lane * RH_WSTRIDE], 0ull);
     const unsigned long long bad = dev_load(&D->words[2]);
     rh_scalars S;
     StepCtx X;
@@ -1087,17 +1157,38 @@ RH_DEV unsigned long long front_daily(P p, T t, E e, double *agg, const Consts &
     return b;
 }
 // the control part by the last wavefront: S / X as k_agg's thread 0 and k_scalars form them
-RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due) {
+// fd: the set_forcing hook rode along with the kernel (fresh_day) -- what it does to the state happens here, once
+RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, const FreshDay &fd, int hooks) {
     const int lane = threadIdx.x & 63;
     unsigned long long day = D->day_word;
     if (daily_due) {
-        day = wave_or(dev_load(&D->dayw[lane]));
-        dev_store(&D->dayw[lane], 0ull);
+        day = wave_or(dev_load(&D->dayw[lane * RH_WSTRIDE]));
+        dev_store(&D->dayw[lane * RH_WSTRIDE], 0ull);
+    }
+    if (fd.fresh) {   // hooks_set_forcing: the day of the resident series becomes the current one for everybody behind this kernel
+        for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->series[k / RH_SLOTS_PER_DAY][fd.i0 + k % RH_SLOTS_PER_DAY];
+        const int ns = D->n_stations;
+        for (int q = lane; q < 3 * ns * RH_SLOTS_PER_DAY; q += 64) {
+            const int v = q / (ns * RH_SLOTS_PER_DAY), r = q % (ns * RH_SLOTS_PER_DAY), st = r / RH_SLOTS_PER_DAY, j = r % RH_SLOTS_PER_DAY;
+            D->forc_multi[q] = D->series[v][(size_t)st * D->nitt_forc + fd.i0 + j];
+        }
     }
     if (lane != 0) return;
     D->day_word = day;
     rh_scalars S = D->S;
     StepCtx X = D->X;
+    if (hooks) {
+        if (fd.fresh) {
+            S.itt_day = 0;
+            S.year[1] = D->calendar[0][fd.i0];
+            S.month[1] = D->calendar[1][fd.i0];
+            S.doy[1] = D->calendar[2][fd.i0];
+            S.itt_forc = fd.i0 + RH_SLOTS_PER_DAY;
+            D->per_cell = D->weights[0] ? 1 : 0;
+        }
+        D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
+        if (fd.missing) D->err_flags |= RH_DEVERR_FORCING;
+    }
     const unsigned long long w = ((cells >> (FC_COMMON + 4)) & 0xFull) | day;   // word 0: bits 0..3 are the columns' snow bits
     {
         const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
@@ -1149,11 +1240,14 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due) {
 // SIMD).  m1_pending as k_select's RH_SELECT_M1_PENDING.  The column's planes, weights and daily sums are requested FIRST, so that their
 // round trips to HBM run under the staging of the day and the window sums.
 template <int PART>
-__global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, int force_daily, int m1_pending, int grp_shift) {
+__global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, int force_daily, int m1_pending, int n_groups, int hooks) {
     constexpr bool daily_only = PART == 2, with_daily = PART != 0;
     const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
     const bool weighted = D->weights[0] != nullptr;
-    const bool daily_due = !weighted || force_daily || D->S.itt_day == 0;   // (uniform over the grid; k_cell_agg's rule)
+    // hooks: the device-side set_forcing hook rides along -- at midnight the kernel works on the day the hook is about to bring, the last
+    // wavefront does the hook's bookkeeping (the state is read, not written, until then: PART 2 in front of PART 0 decides the same)
+    const FreshDay fd = fresh_day(D, hooks);
+    const bool daily_due = !weighted || force_daily || fd.itd == 0;   // (uniform over the grid; k_cell_agg's rule)
     __shared__ unsigned wg_done;
     __shared__ DaySeries day;
     if (daily_only && !daily_due) return;
@@ -1180,15 +1274,15 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
         ew = D->weights[2][ii];
     }
     if (threadIdx.x == 0) wg_done = 0;
-    if (weighted) stage_day(D, day);
+    if (weighted) stage_day(D, day, &fd);
     else __syncthreads();
     const Consts K = D->K;
-    const int64_t itd = D->S.itt_day;
+    const int64_t itd = fd.itd;
     unsigned long long b = 0, db = 0;
     if (in) {
         double agg[9];
         if (weighted) {
-            const DayView F = day_view(D, day, i);
+            const DayView F = day_view(D, day, i, &fd);
             auto p = [&](int k) { return F(0, k) * pw; };
             auto t = [&](int k) { return F(1, k) + toff; };
             auto e = [&](int k) { return F(2, k) * ew; };
@@ -1235,30 +1329,22 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
     b = wave_or(b);
     db = wave_or(db);
     if ((threadIdx.x & 63) == 0) {
-        if (db) dep |= (unsigned)(__hip_atomic_fetch_or(&D->dayw[blockIdx.x & 63], db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
-        if (b) dep |= (unsigned)(__hip_atomic_fetch_or(&D->frontw[blockIdx.x & 63], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
+        if (db) dep |= (unsigned)(__hip_atomic_fetch_or(&D->dayw[(blockIdx.x & 63) * RH_WSTRIDE], db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
+        if (b) dep |= (unsigned)(__hip_atomic_fetch_or(&D->frontw[(blockIdx.x & 63) * RH_WSTRIDE], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
     }
     if (daily_only) return;   // (the front kernel behind this launch folds dayw)
     bool last = false;
     if ((threadIdx.x & 63) == 0) {
         const unsigned o = atomicAdd(&wg_done, dep);   // LDS; dep == 1 (bit 63 of the words is never set)
         if (o == (RH_BLOCK / 64) - 1) {
-            const unsigned nblk = gridDim.x, g = blockIdx.x >> grp_shift, ng = ((nblk - 1) >> grp_shift) + 1;
-            const unsigned cnt = (g == ng - 1) ? nblk - (g << grp_shift) : (1u << grp_shift);
-            if (__hip_atomic_fetch_add(&D->done_grp[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1) {
-                __hip_atomic_store(&D->done_grp[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {
-                    __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = true;
-                }
-            }
+            last = grid_completion(D, n_groups);
         }
     }
     if (__shfl((int)last, 0)) {
         const int lane = threadIdx.x & 63;
-        const unsigned long long cells = wave_or(dev_load(&D->frontw[lane]));
-        dev_store(&D->frontw[lane], 0ull);
-        front_ctrl(D, cells, daily_due);
+        const unsigned long long cells = wave_or(dev_load(&D->frontw[lane * RH_WSTRIDE]));
+        dev_store(&D->frontw[lane * RH_WSTRIDE], 0ull);
+        front_ctrl(D, cells, daily_due, fd, hooks);
     }
 }
 
@@ -1275,7 +1361,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary(Arena a, DevState *D) {
         b = summary_bits(swe, swe_top, prec, ta, D->K);
     }
     b = wave_or(b);
-    if ((threadIdx.x & 63) == 0 && b) __hip_atomic_fetch_or(&D->sumw[blockIdx.x & 63], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && b) __hip_atomic_fetch_or(&D->sumw[(blockIdx.x & 63) * RH_WSTRIDE], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Output accumulators: after a step that covered (t0, t1], day = t0 / 86400, slot = day mod diag_slots; the first
 // step of a day (t0 on midnight) overwrites.  Rate planes add this step's value (Rate.diagnose, roger/diagnostics/
@@ -1312,8 +1398,8 @@ __global__ __launch_bounds__(RH_BLOCK) void k_summary_reduce(DevState *D, int do
     if (threadIdx.x < 64) {
         unsigned long long w;
         if (src == RH_SRC_SUMW) {
-            w = wave_or(dev_load(&D->sumw[threadIdx.x]));
-            dev_store(&D->sumw[threadIdx.x], 0ull);
+            w = wave_or(dev_load(&D->sumw[threadIdx.x * RH_WSTRIDE]));
+            dev_store(&D->sumw[threadIdx.x * RH_WSTRIDE], 0ull);
         } else {
             w = D->words[3];
         }
@@ -1600,7 +1686,7 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 #pragma unroll
     for (int b = 0; b <= QB_P_NE0; ++b) qq |= __ballot((q >> b) & 1ull) ? (1ull << b) : 0ull;
     if ((threadIdx.x & 63) == 0 && qq) {
-        const unsigned long long old = __hip_atomic_fetch_or(&D->sumw[blockIdx.x & 63], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_or(&D->sumw[(blockIdx.x & 63) * RH_WSTRIDE], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dep |= (unsigned)(old >> 63);   // (bit 63 is never set: dep stays as it is, but depends on the atomic's return)
     }
 }
@@ -1651,10 +1737,10 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
 
 // MODE: 0 = the plain step, 1 = with the monthly surface parameters (calc_parameters_surface_kernel first), 2 = decided
 // by the device-side month-change flag (rh_run_steps, rh_step_finish: one launch whatever the month does)
-// flags: RH_TAIL_*; grp_shift: 2^grp_shift workgroups per completion group; dst64: the summary word for the exchange between
+// flags: RH_TAIL_*; n_groups: completion groups (grid_completion); dst64: the summary word for the exchange between
 // ranks, written by the tail (or null)
 template <int MODE, bool LATERAL, bool LAZY, bool SPARSE = false, bool KEEP = false>
-__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int flags, int grp_shift, int *dst64) {
+__global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevState *D, int flags, int n_groups, int *dst64) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2 and address-translation cache).  Mapping
     // workgroup b to the column block  (b mod 8) * blocks_per_xcd + b / 8  lets every XCD walk ONE contiguous eighth of
     // the arena instead of every XCD touching every page.  Never slower; on one box 6 - 11 % faster at 10^7 columns (21 GB
@@ -1726,15 +1812,7 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
         if (any_bad) dep |= (unsigned)(__hip_atomic_fetch_or(&D->words[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
         const unsigned o = atomicAdd(&wg_done, dep);   // LDS; dep == 1
         if (o == (RH_BLOCK / 64) - 1) {                // the last wave of the workgroup reports the workgroup
-            const unsigned nblk = gridDim.x, g = blockIdx.x >> grp_shift, ng = ((nblk - 1) >> grp_shift) + 1;
-            const unsigned cnt = (g == ng - 1) ? nblk - (g << grp_shift) : (1u << grp_shift);
-            if (__hip_atomic_fetch_add(&D->done_grp[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1) {
-                __hip_atomic_store(&D->done_grp[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {
-                    __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = true;
-                }
-            }
+            last = grid_completion(D, n_groups);
         }
     }
 #ifndef RH_CENSUS   // tools/isa_census.py counts the per-column memory instructions of the kernel without its tail
@@ -2528,8 +2606,9 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     ctx->cell_front_ok = std::getenv("RH_PER_CELL_OLD_FRONT") == nullptr && ctx->defer_select_ok;
     if (const char *v = std::getenv("RH_CELL_FRONT_MAX")) ctx->cell_front_max = std::atoll(v);
     if (const char *v = std::getenv("RH_CELL_AGG_SPLIT_MIN")) ctx->cell_agg_split_min = std::atoll(v);
-    ctx->grp_shift = 6;
-    while ((grid_for(ctx->n) >> ctx->grp_shift) >= RH_DONE_GROUPS) ++ctx->grp_shift;
+    ctx->n_groups = (int)((grid_for(ctx->n) + 63) / 64);
+    if (ctx->n_groups > RH_DONE_GROUPS) ctx->n_groups = RH_DONE_GROUPS;
+    if (ctx->n_groups < 1) ctx->n_groups = 1;
     ctx->summary_valid = false;
     ctx->pred_blocks = (int)(grid_for(ctx->n) < RH_PRED_BLOCKS ? grid_for(ctx->n) : RH_PRED_BLOCKS);
     if ((e = hipMemcpyAsync(&ctx->dev->pred_blocks, &ctx->pred_blocks, sizeof(int), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
@@ -3068,9 +3147,9 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
     const bool lat = ctx->cfg.enable_lateral_flow != 0;
 #ifdef RH_EVENT_RECORD
-#define RH_LAUNCH_K(K) hipLaunchKernelGGL(K, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, flags, ctx->grp_shift, dst64)
+#define RH_LAUNCH_K(K) hipLaunchKernelGGL(K, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, flags, ctx->n_groups, dst64)
 #else
-#define RH_LAUNCH_K(K) hipExtLaunchKernelGGL(K, grid, block, 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev, flags, ctx->grp_shift, dst64)
+#define RH_LAUNCH_K(K) hipExtLaunchKernelGGL(K, grid, block, 0, ctx->stream, ev0, ev1, 0, ctx->arena, ctx->dev, flags, ctx->n_groups, dst64)
 #endif
     // lazy rotation: the planes were last touched by a complete fused step (X_m1 == X) and nobody who reads X_m1 planes
     // follows inside this call (the accumulator kernel may, if it was given an X_m1 plane)
@@ -3198,11 +3277,13 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         const int flags = (use_next ? RH_TAIL_USE_NEXT : 0) | (ctx->tail_ok ? RH_TAIL_CTRL | (hooks ? RH_TAIL_HOOKS : 0) : 0);
         return launch_fused_kernel(ctx, monthly, flags);
     }
-    if (hooks) {  // per-cell forcing from the resident series: the hooks must have formed it before k_pred1 reads it
+    const bool front = ctx->cell_front_ok && ctx->n <= ctx->cell_front_max;
+    if (hooks && !front) {  // per-cell forcing from the resident series: the hooks must have formed it before k_pred1 reads it
         launch_hooks(ctx);
         hooks = 0;
     }
-    if (ctx->cell_front_ok && ctx->n <= ctx->cell_front_max) {
+    if (front) {
+        // (the set_forcing hook rides along with the front kernel: fresh_day / front_ctrl)
         // ONE per-column launch in front of the fused kernel (k_cell_front; a second one, returning at once unless a new day began, for the
         // daily sums of large grids).  Nothing in front of the fused kernel writes a plane: its lazy rotation stays.
         ctx->summary_valid = false;
@@ -3211,10 +3292,10 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
         const int force = (ctx->front_daily_stale || ctx->last_front != 2) ? 1 : 0, m1 = ctx->m1_stale ? 1 : 0;
         if (ctx->n >= ctx->cell_agg_split_min) {
-            hipLaunchKernelGGL(k_cell_front<2>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
-            hipLaunchKernelGGL(k_cell_front<0>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
+            hipLaunchKernelGGL(k_cell_front<2>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->n_groups, hooks);
+            hipLaunchKernelGGL(k_cell_front<0>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->n_groups, hooks);
         } else {
-            hipLaunchKernelGGL(k_cell_front<1>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->grp_shift);
+            hipLaunchKernelGGL(k_cell_front<1>, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, force, m1, ctx->n_groups, hooks);
         }
         CHECK_LAUNCH(ctx);
         ctx->front_daily_stale = false;
