@@ -44,6 +44,8 @@
 #define RH_TAIL_USE_NEXT 1   // this step runs on S_next / X_next (the previous kernel's tail formed them); its tail commits them
 #define RH_TAIL_CTRL 2       // the tail forms the next step's S_next / X_next
 #define RH_TAIL_HOOKS 4      // ... including the device-side set_forcing / set_parameters hooks
+#define RH_TAIL_SKIP 8       // nobody reads this step's summary word (per-cell forcing behind k_cell_front, which looks at the planes): no summary
+                             // bits posted, no completion counting, no tail -- three round trips less at the end of a launch-bound step
 #define RH_SRC_WORD3 0       // the summary word sits in words[3] (a fused kernel ran last)
 #ifndef RH_WSTRIDE
 #define RH_WSTRIDE 16       // words between two slots of the device-wide OR words (sumw, frontw, dayw): 128 bytes -- a slot per cache line
@@ -1231,6 +1233,7 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, co
     D->words[0] = 0;
     D->words[1] = 0;
     D->words[2] = 0;
+    D->sanity_last = 0;   // (the fused kernel behind this front has no tail: words[2] is the whole record of its step)
     D->S = S;
     D->X = X;
     log_dt(D, dts);
@@ -1622,7 +1625,7 @@ __device__ unsigned long long g_step_phases[256 * 64];   // 256 copies (one addr
     RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K); RH_STORES(seq, rt_evapotranspiration) RH_PH(3)  \
     RH_LOADS(seq, rt_inf_events) RH_PIN                                                                         \
     rt_snow(c, K, X); RH_STORES(seq, rt_snow) RH_PH(4)                                                            \
-    q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);                                   \
+    q = summary_bits_sw(q, c.swe, c.swe_top); if (post) post_summary(D, q, dep);                         \
     RH_LOADS(seq, rt_inf_matrix) RH_PIN                                                                         \
     rt_inf_events(c, K, X); RH_STORES(seq, rt_inf_events) RH_PH(5)                                                \
     RH_LOADS(seq, rt_inf_macropores) RH_PIN                                                                     \
@@ -1664,7 +1667,7 @@ __device__ unsigned long long g_step_phases[256 * 64];   // 256 copies (one addr
     RH_STAGE(seq, rt_interception, rt_interception(c, K))                                                \
     RH_STAGE(seq, rt_evapotranspiration, RH_DERIVE(rt_evapotranspiration) rt_evapotranspiration(c, K))   \
     RH_STAGE(seq, rt_snow, rt_snow(c, K, X))                                                             \
-    RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top); post_summary(D, q, dep);)                       \
+    RH_DBG_SUM(q = summary_bits_sw(q, c.swe, c.swe_top); if (post) post_summary(D, q, dep);)             \
     RH_STAGE(seq, rt_inf_events, rt_inf_events(c, K, X))                                                 \
     RH_STAGE(seq, rt_inf_matrix, RH_DERIVE(rt_inf_matrix) rt_inf_matrix(c, K, X))                        \
     RH_STAGE(seq, rt_inf_macropores, RH_DERIVE(rt_inf_macropores) rt_inf_macropores(c, K, X))            \
@@ -1694,7 +1697,8 @@ RH_DEV void post_summary(DevState *D, unsigned long long q, unsigned &dep) {
 // the step of one column: loads, the staged pipeline, stores; q = summary bits of the column for the next step's predicates
 // KEEP (with SPARSE): an accumulator was given planes the sparse kernel does not store -- those are stored after all (DevState::keep)
 template <bool MONTHLY, bool LATERAL, bool LAZY, bool SPARSE, bool KEEP = false, bool MK1 = false>
-RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep, unsigned long long um) {
+RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t i, unsigned long long &q, bool &bad, unsigned &dep, unsigned long long um,
+                        bool post) {
     {
     const Consts K = D->K;
     const StepCtx X = *Xp;
@@ -1771,6 +1775,7 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     unsigned long long q = 0;
     bool bad = false;
     unsigned dep = 1;
+    const bool post = !(flags & RH_TAIL_SKIP);
     if (i < a.n) {
         const bool monthly = MODE == 1 || (MODE == 2 && D->monthly != 0);
         // the wave's word of the parameter planes (uniform / derivable / all in the catchment; zero: plain loads) -- wave-uniform, in
@@ -1793,18 +1798,22 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
 #else
         if (SPARSE && !Xp->last) {
 #endif
-            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
-            else if (mk1) step_column<false, LATERAL, LAZY, SPARSE, KEEP, LAZY>(a, D, Xp, i, q, bad, dep, um);
-            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um);
+            if (monthly) step_column<true, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um, post);
+            else if (mk1) step_column<false, LATERAL, LAZY, SPARSE, KEEP, LAZY>(a, D, Xp, i, q, bad, dep, um, post);
+            else step_column<false, LATERAL, LAZY, SPARSE, KEEP>(a, D, Xp, i, q, bad, dep, um, post);
         } else {
             // (the full-store pipeline keeps the generic code: with a third copy the full-store kernels spill registers)
-            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
-            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um);
+            if (monthly) step_column<true, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um, post);
+            else step_column<false, LATERAL, LAZY, false>(a, D, Xp, i, q, bad, dep, um, post);
         }
-    } else {
+    } else if (post) {
         post_summary(D, 0ull, dep);
     }
     const bool any_bad = __any(bad);
+    if (!post) {   // RH_TAIL_SKIP: the sanity word is all anybody reads of this launch
+        if (any_bad && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(&D->words[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // Completion, without a barrier and without fences (a release fence at device scope writes the XCD's L2 back): everything the
     // tail reads from other waves went through device-scope atomics that have RETURNED before the wave counts itself done.
     bool last = false;
@@ -3198,7 +3207,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
 #endif
         ctx->ev_used += 2;
     }
-    ctx->summary_valid = true;  // the fused kernel's tail leaves the summary word of the state it wrote (words[3])
+    ctx->summary_valid = !(flags & RH_TAIL_SKIP);  // the fused kernel's tail leaves the summary word of the state it wrote (words[3])
     ctx->pending_valid = (flags & RH_TAIL_CTRL) != 0;
     ctx->pending_hooks = (flags & RH_TAIL_HOOKS) != 0;
     ctx->exch_valid = dst64 != nullptr;
@@ -3300,7 +3309,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         CHECK_LAUNCH(ctx);
         ctx->front_daily_stale = false;
         ctx->last_front = 2;
-        int rc = launch_fused_kernel(ctx, monthly);
+        int rc = launch_fused_kernel(ctx, monthly, RH_TAIL_SKIP);   // (the next front reads the planes, not the summary word)
         if (rc) return rc;
         CHECK_LAUNCH(ctx);
         return RH_OK;
