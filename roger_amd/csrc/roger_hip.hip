@@ -934,7 +934,21 @@ struct CtrlLds {
 // [Device-side hooks,] predicate word 0, forcing aggregates in numpy's order, dt and event bookkeeping -- what k_agg + k_select +
 // k_scalars do for the predicate-kernel generation -- on the copies S / X every lane holds (uniform); `cells` = OR of the
 // summary bits of all columns (of all ranks).  The caller stores S / X.  Shared forcing only (the summary path).
+#ifdef RH_STEP_PHASES   // measurement builds: cycles of the tail's parts (one wavefront per launch)
+__device__ unsigned long long g_tail_phases[8];
+#define RH_TPH(k)                                                  \
+    if ((threadIdx.x & 63) == 0) {                                 \
+        const unsigned long long t_ = clock64();                   \
+        atomicAdd(&g_tail_phases[k], t_ - tph);                    \
+        tph = t_;                                                  \
+    }
+#else
+#define RH_TPH(k)
+#endif
 RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks) {
+#ifdef RH_STEP_PHASES
+    unsigned long long tph = clock64();
+#endif
     const int lane = threadIdx.x & 63;
     const double ta_fm = D->K.ta_fm;
     const int64_t hpi_i = D->K.hpi, end_event = D->K.end_event;
@@ -972,6 +986,7 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
     if (!fresh_day)
         for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) L.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
     wave_sync();
+    RH_TPH(1)
     // word 0: the columns' bits 0..3 and the predicates of the day's series (adaptive_time_stepping.py:38-81)
     unsigned long long fb = 0;
     int cnt_d = 0, cnt_h = 0;
@@ -1001,6 +1016,7 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         L.part[sum_id][l16] = r;
     }
     wave_sync();
+    RH_TPH(2)
     {   // uniform from here on (every lane computes the same)
         const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
         const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
@@ -1042,14 +1058,17 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
             X.ta_sel = agg_pick(X, X.sel_p, 1);
         }
     }
+    RH_TPH(3)
     const int64_t dts = scalars_update(S, X, derive_word1(cells, X, Kf), 1, 1, false, end_event);
     X.last = (t_end >= 0 && S.time >= t_end) ? 1 : 0;   // (S.time is the END of the step that is being formed)
+    RH_TPH(4)
     if (lane == 0) {
         D->words[0] = 0;
         D->words[1] = 0;
         D->words[2] = 0;
         log_dt(D, dts);
     }
+    RH_TPH(5)
 }
 RH_DEV unsigned long long dev_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RH_DEV void dev_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1100,6 +1119,9 @@ RH_DEV bool grid_completion(DevState *D, int n_groups) {
 }
 RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     const int lane = threadIdx.x & 63;
+#ifdef RH_STEP_PHASES
+    const unsigned long long tph0 = clock64();
+#endif
     const unsigned long long cells = wave_or(dev_load(&D->sumw[lane * RH_WSTRIDE]));
     dev_store(&D->sumw[lane * RH_WSTRIDE], 0ull);
     const unsigned long long bad = dev_load(&D->words[2]);
@@ -1123,11 +1145,21 @@ RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     }
     if (dst64) dst64[lane] = (int)((cells >> lane) & 1ull);
     if (!(flags & RH_TAIL_CTRL)) return;
+#ifdef RH_STEP_PHASES
+    if (lane == 0) {
+        atomicAdd(&g_tail_phases[0], clock64() - tph0 + (S.time & 0) + (unsigned long long)(X.halt & 0));   // (loads of S / X used)
+        atomicAdd(&g_tail_phases[7], 1ull);
+    }
+#endif
     ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0);
     if (lane == 0) {
         D->S_next = S;
         D->X_next = X;
     }
+#ifdef RH_STEP_PHASES
+    __threadfence();
+    if (lane == 0) atomicAdd(&g_tail_phases[6], clock64() - tph0);
+#endif
 }
 // ---- per-cell forcing: ONE per-column launch in front of the fused kernel (round 4) --------------------------------
 // What k_pred1 -> k_agg -> k_cell_agg<1> -> k_select -> k_scalars did in five launches (four of them passes over the columns or
@@ -1821,9 +1853,14 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
         if (any_bad) dep |= (unsigned)(__hip_atomic_fetch_or(&D->words[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63);
         const unsigned o = atomicAdd(&wg_done, dep);   // LDS; dep == 1
         if (o == (RH_BLOCK / 64) - 1) {                // the last wave of the workgroup reports the workgroup
+#ifndef RH_X_NOCOMPLETION
             last = grid_completion(D, n_groups);
+#endif
         }
     }
+#ifdef RH_X_NOTAIL
+    last = false;
+#endif
 #ifndef RH_CENSUS   // tools/isa_census.py counts the per-column memory instructions of the kernel without its tail
     if (__shfl((int)last, 0)) step_tail(D, tail_lds, flags, dst64);
 #endif
@@ -2636,6 +2673,11 @@ void rh_destroy(rh_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 #ifdef RH_STEP_PHASES
     {
+        unsigned long long tp[8];
+        if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_tail_phases), sizeof(tp)) == hipSuccess && tp[7])
+            std::fprintf(stderr, "tail phases: %llu tails, cycles per tail: loads %.0f, hooks+staging %.0f, bits+sums %.0f, decisions %.0f, scalars %.0f, log %.0f; whole tail %.0f\n",
+                         tp[7], (double)tp[0] / tp[7], (double)tp[1] / tp[7], (double)tp[2] / tp[7], (double)tp[3] / tp[7], (double)tp[4] / tp[7],
+                         (double)tp[5] / tp[7], (double)tp[6] / tp[7]);
         static unsigned long long all[256 * 64];
         unsigned long long h[60] = {0};
         if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_step_phases), sizeof(all)) == hipSuccess) {
