@@ -84,6 +84,12 @@ struct DevState {
     unsigned int done_grp[RH_DONE_GROUPS * RH_DONE_STRIDE];   // workgroups finished per completion group (workgroup b belongs to group b mod n_groups)
     unsigned int done_top;                   // groups finished
     unsigned long long sanity_last;          // words[2] of the last fused step (the tail clears words[2] for the next one)
+    // what the control part keeps of the DAY's shared series between two midnights (ctrl_wave): the OR of the slots' forcing bits and the
+    // three daily aggregates -- a step inside the day then needs the six slots of its hourly window only.  Everything that writes forc
+    // clears day_cache_ok.
+    int day_cache_ok, day_cache_pad;
+    unsigned long long day_fb;
+    double day_agg[3];
     unsigned int err_flags;                  // RH_DEVERR_*
     rh_scalars S_next;                       // scalars / step context of the next step, formed by the tail of the last fused kernel;
     StepCtx X_next;                          // committed to S / X by the tail of the kernel that runs that step
@@ -436,6 +442,7 @@ RH_DEV void hooks_set_forcing(DevState *D) {
     __syncthreads();  // everybody has read S before thread 0 changes it
     if (have && threadIdx.x < RH_SLOTS_PER_DAY)
         for (int k = 0; k < 3; ++k) D->forc[k][threadIdx.x] = D->series[k][i0 + threadIdx.x];
+    if (have && threadIdx.x == 0) D->day_cache_ok = 0;
     if (have && D->n_stations > 0) {   // the series are (n_stations, nitt_forc): the day of every station
         const int S = D->n_stations;
         for (int q = threadIdx.x; q < 3 * S * RH_SLOTS_PER_DAY; q += RH_BLOCK) {
@@ -945,18 +952,59 @@ __device__ unsigned long long g_tail_phases[8];
 #else
 #define RH_TPH(k)
 #endif
-RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks) {
+// The day's shared series spread over the wavefront's registers (lane l holds slots l, l + 64, l + 128 of each variable) and the scalars
+// the control part needs besides S / X: requested by the caller BEFORE it waits for anything else, so that the tail of the fused kernel
+// makes ONE round trip to memory for all its inputs (it made three in sequence: the summary words and S / X, then the constants, then the
+// series into LDS -- 19 600 cycles per tail, a tenth of a 10^6-column step and a third of an 80 x 53 one; profiles/r04_tail_phases.txt).
+struct CtrlIn {
+    double f[3][3];            // f[v][r]: slot lane + 64 r of variable v (slots >= 144: 0)
+    double ta_fm;
+    int64_t hpi, end_event, nitt_forc;
+    long long t_end;
+    int cache_ok;
+    unsigned long long day_fb;
+    double day_agg[3];
+};
+RH_DEV CtrlIn ctrl_inputs(const DevState *D) {
+    CtrlIn in;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = lane + 64 * r;
+            in.f[v][r] = k < RH_SLOTS_PER_DAY ? D->forc[v][k] : 0.0;
+        }
+    in.ta_fm = D->K.ta_fm;
+    in.hpi = D->K.hpi;
+    in.end_event = D->K.end_event;
+    in.nitt_forc = D->nitt_forc;
+    in.t_end = D->t_end;
+    in.cache_ok = D->day_cache_ok;
+    in.day_fb = D->day_fb;
+    in.day_agg[0] = D->day_agg[0]; in.day_agg[1] = D->day_agg[1]; in.day_agg[2] = D->day_agg[2];
+    return in;
+}
+// slot k (uniform) of a variable from the registers of ctrl_inputs (x0, x1, x2: the lane's slots lane, lane + 64, lane + 128)
+RH_DEV double ctrl_slot(double x0, double x1, double x2, int k) {
+    const int r = k >> 6, l = k & 63;
+    const double x = r == 0 ? x0 : (r == 1 ? x1 : x2);
+    const long long bits = __double_as_longlong(x);   // (v_readlane: the lane is uniform -- no trip through the LDS crossbar)
+    const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks, const CtrlIn &in) {
 #ifdef RH_STEP_PHASES
     unsigned long long tph = clock64();
 #endif
     const int lane = threadIdx.x & 63;
-    const double ta_fm = D->K.ta_fm;
-    const int64_t hpi_i = D->K.hpi, end_event = D->K.end_event;
+    const double ta_fm = in.ta_fm;
+    const int64_t hpi_i = in.hpi, end_event = in.end_event;
     Consts Kf;   // forcing_bits / derive_word1 read hpi and ta_fm only
     Kf.hpi = hpi_i;
     Kf.ta_fm = ta_fm;
     bool fresh_day = false;
-    const long long t_end = D->t_end;
+    const long long t_end = in.t_end;
     X.halt = (t_end >= 0 && S.time >= t_end) ? 1 : 0;   // the run is over (roger/roger.py:548): nothing is formed, S stays as it is
     X.last = 0;
     if (X.halt) return;
@@ -964,7 +1012,7 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
     if (do_hooks) {   // hooks_set_forcing: benchmarks/SVAT_benchmark.py:105-110, 151-171
         const bool midnight = (S.time % 86400 == 0);
         const int64_t i0 = S.itt_forc;
-        const bool have = midnight && (i0 + RH_SLOTS_PER_DAY <= D->nitt_forc);
+        const bool have = midnight && (i0 + RH_SLOTS_PER_DAY <= in.nitt_forc);
         X.forc_exhausted = (midnight && !have) ? 1 : 0;
         if (have) {
             for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) {
@@ -983,40 +1031,82 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         }
         if (lane == 0) D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
     }
-    if (!fresh_day)
-        for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) L.f[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY];
-    wave_sync();
-    RH_TPH(1)
-    // word 0: the columns' bits 0..3 and the predicates of the day's series (adaptive_time_stepping.py:38-81)
-    unsigned long long fb = 0;
-    int cnt_d = 0, cnt_h = 0;
     const int64_t itd = S.itt_day;
-    for (int k = lane; k < RH_SLOTS_PER_DAY; k += 64) fb |= forcing_bits(L.f[0][k], L.f[1][k], Kf);
-    for (int k0 = 0; k0 < RH_SLOTS_PER_DAY; k0 += 64) {   // nanmean's divisors
-        const int k = k0 + lane;
-        const bool ok = k < RH_SLOTS_PER_DAY && !isnan(L.f[1][k < RH_SLOTS_PER_DAY ? k : 0]);
-        cnt_d += __popcll(__ballot(ok));
-        cnt_h += __popcll(__ballot(ok && (k >= itd) && (k < itd + 6)));
-    }
-    const unsigned long long w = (cells & 0xFull) | wave_or(fb);
-    // numpy's partial sums (agg_body): six sums x 16 (half, lane-of-eight) pairs
-    for (int item = lane; item < 96; item += 64) {
-        const int sum_id = item >> 4, l16 = item & 15, half = l16 >> 3, j = l16 & 7;
-        const int var = sum_id % 3;          // 0 prec, 1 ta, 2 pet
-        const bool hourly = sum_id >= 3;     // sums 0..2 daily, 3..5 hourly window
-        double r = 0.0;
-        for (int q = 0; q < 9; ++q) {
-            const int k = half * 72 + j + 8 * q;
-            double v = L.f[var][k];
-            const bool in = !hourly || ((k >= itd) && (k < itd + 6));
-            if (var == 1) v = (in && !isnan(v)) ? v : 0.0;  // nanmean: NaN (and masked) slots count as 0
-            else v = in ? v : 0.0;
-            r = (q == 0) ? v : r + v;
+    unsigned long long w;
+    if (!fresh_day && in.cache_ok) {
+        // inside a day whose bits and daily aggregates an earlier control part has formed: the six slots of the hourly window, out of the
+        // registers (forcing_aggregates_of: the sums in numpy's order, as the full path forms them)
+        RH_TPH(1)
+        w = (cells & 0xFull) | in.day_fb;
+        double agg[9];
+        // (copies by value: a closure holding a reference to `in` keeps the whole struct in scratch memory)
+        const double p0 = in.f[0][0], p1 = in.f[0][1], p2 = in.f[0][2], t0 = in.f[1][0], t1 = in.f[1][1], t2 = in.f[1][2];
+        const double e0 = in.f[2][0], e1 = in.f[2][1], e2 = in.f[2][2];
+        forcing_aggregates_of([=](int k) { return ctrl_slot(p0, p1, p2, k); }, [=](int k) { return ctrl_slot(t0, t1, t2, k); },
+                              [=](int k) { return ctrl_slot(e0, e1, e2, k); }, itd, agg, false, true);
+        X.agg[0] = in.day_agg[0]; X.agg[1] = in.day_agg[1]; X.agg[2] = in.day_agg[2];
+        X.agg[3] = agg[3]; X.agg[4] = agg[4]; X.agg[5] = agg[5];
+        X.agg[6] = agg[6]; X.agg[7] = agg[7]; X.agg[8] = agg[8];
+        RH_TPH(2)
+    } else {
+        if (!fresh_day) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (lane + 64 * r < RH_SLOTS_PER_DAY) L.f[v][lane + 64 * r] = in.f[v][r];
         }
-        L.part[sum_id][l16] = r;
+        wave_sync();
+        RH_TPH(1)
+        // word 0: the columns' bits 0..3 and the predicates of the day's series (adaptive_time_stepping.py:38-81)
+        unsigned long long fb = 0;
+        int cnt_d = 0, cnt_h = 0;
+        for (int k = lane; k < RH_SLOTS_PER_DAY; k += 64) fb |= forcing_bits(L.f[0][k], L.f[1][k], Kf);
+        for (int k0 = 0; k0 < RH_SLOTS_PER_DAY; k0 += 64) {   // nanmean's divisors
+            const int k = k0 + lane;
+            const bool ok = k < RH_SLOTS_PER_DAY && !isnan(L.f[1][k < RH_SLOTS_PER_DAY ? k : 0]);
+            cnt_d += __popcll(__ballot(ok));
+            cnt_h += __popcll(__ballot(ok && (k >= itd) && (k < itd + 6)));
+        }
+        fb = wave_or(fb);
+        w = (cells & 0xFull) | fb;
+        // numpy's partial sums (agg_body): six sums x 16 (half, lane-of-eight) pairs
+        for (int item = lane; item < 96; item += 64) {
+            const int sum_id = item >> 4, l16 = item & 15, half = l16 >> 3, j = l16 & 7;
+            const int var = sum_id % 3;          // 0 prec, 1 ta, 2 pet
+            const bool hourly = sum_id >= 3;     // sums 0..2 daily, 3..5 hourly window
+            double r = 0.0;
+            for (int q = 0; q < 9; ++q) {
+                const int k = half * 72 + j + 8 * q;
+                double v = L.f[var][k];
+                const bool inw = !hourly || ((k >= itd) && (k < itd + 6));
+                if (var == 1) v = (inw && !isnan(v)) ? v : 0.0;  // nanmean: NaN (and masked) slots count as 0
+                else v = inw ? v : 0.0;
+                r = (q == 0) ? v : r + v;
+            }
+            L.part[sum_id][l16] = r;
+        }
+        wave_sync();
+        RH_TPH(2)
+#define RH_SUM6(q) (0.0 + (np_tree8(&L.part[q][0]) + np_tree8(&L.part[q][8])))
+        X.agg[0] = RH_SUM6(0);
+        X.agg[1] = RH_SUM6(1) / (double)cnt_d;
+        X.agg[2] = RH_SUM6(2);
+        X.agg[3] = RH_SUM6(3);
+        X.agg[4] = RH_SUM6(4) / (double)cnt_h;
+        X.agg[5] = RH_SUM6(5);
+#undef RH_SUM6
+        int64_t k = itd < 0 ? itd + RH_SLOTS_PER_DAY : itd;
+        k = k > RH_SLOTS_PER_DAY - 1 ? RH_SLOTS_PER_DAY - 1 : k;
+        X.agg[6] = L.f[0][k];
+        X.agg[7] = L.f[1][k];
+        X.agg[8] = L.f[2][k];
+        if (lane == 0) {   // the day's part, for the steps until somebody writes forc again
+            D->day_fb = fb;
+            D->day_agg[0] = X.agg[0]; D->day_agg[1] = X.agg[1]; D->day_agg[2] = X.agg[2];
+            D->day_cache_ok = 1;
+        }
     }
-    wave_sync();
-    RH_TPH(2)
     {   // uniform from here on (every lane computes the same)
         const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
         const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
@@ -1040,19 +1130,6 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         X.dt_secs_prelim = dts;
         X.itt_day = itd;
         X.sel_p = X.sel_10min ? 2 : (X.sel_hourly ? 1 : (X.sel_daily ? 0 : -1));
-#define RH_SUM6(q) (0.0 + (np_tree8(&L.part[q][0]) + np_tree8(&L.part[q][8])))
-        X.agg[0] = RH_SUM6(0);
-        X.agg[1] = RH_SUM6(1) / (double)cnt_d;
-        X.agg[2] = RH_SUM6(2);
-        X.agg[3] = RH_SUM6(3);
-        X.agg[4] = RH_SUM6(4) / (double)cnt_h;
-        X.agg[5] = RH_SUM6(5);
-#undef RH_SUM6
-        int64_t k = itd < 0 ? itd + RH_SLOTS_PER_DAY : itd;
-        k = k > RH_SLOTS_PER_DAY - 1 ? RH_SLOTS_PER_DAY - 1 : k;
-        X.agg[6] = L.f[0][k];
-        X.agg[7] = L.f[1][k];
-        X.agg[8] = L.f[2][k];
         if (X.sel_p >= 0) {
             X.prec_sel = agg_pick(X, X.sel_p, 0);
             X.ta_sel = agg_pick(X, X.sel_p, 1);
@@ -1078,6 +1155,7 @@ RH_DEV void dev_store(unsigned long long *p, unsigned long long v) { __hip_atomi
 __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src, const int *src64) {
     __shared__ CtrlLds L;
     const int lane = threadIdx.x & 63;
+    const CtrlIn in = ctrl_inputs(D);
     unsigned long long cells;
     if (src64) {
         cells = wave_or(src64[lane] ? (1ull << lane) : 0ull);
@@ -1089,7 +1167,7 @@ __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src,
     }
     rh_scalars S = D->S;
     StepCtx X = D->X;
-    ctrl_wave(D, L, S, X, cells, do_hooks);
+    ctrl_wave(D, L, S, X, cells, do_hooks, in);
     if (lane == 0) {
         D->words[3] = cells;
         if (!X.halt) D->sanity_last = 0;
@@ -1119,6 +1197,7 @@ RH_DEV bool grid_completion(DevState *D, int n_groups) {
 }
 RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     const int lane = threadIdx.x & 63;
+    const CtrlIn in = ctrl_inputs(D);   // (requested first: one round trip for everything the tail reads)
 #ifdef RH_STEP_PHASES
     const unsigned long long tph0 = clock64();
 #endif
@@ -1151,7 +1230,7 @@ RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
         atomicAdd(&g_tail_phases[7], 1ull);
     }
 #endif
-    ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0);
+    ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0, in);
     if (lane == 0) {
         D->S_next = S;
         D->X_next = X;
@@ -1201,6 +1280,7 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, co
     }
     if (fd.fresh) {   // hooks_set_forcing: the day of the resident series becomes the current one for everybody behind this kernel
         for (int k = lane; k < 3 * RH_SLOTS_PER_DAY; k += 64) D->forc[k / RH_SLOTS_PER_DAY][k % RH_SLOTS_PER_DAY] = D->series[k / RH_SLOTS_PER_DAY][fd.i0 + k % RH_SLOTS_PER_DAY];
+        if (lane == 0) D->day_cache_ok = 0;
         const int ns = D->n_stations;
         for (int q = lane; q < 3 * ns * RH_SLOTS_PER_DAY; q += 64) {
             const int v = q / (ns * RH_SLOTS_PER_DAY), r = q % (ns * RH_SLOTS_PER_DAY), st = r / RH_SLOTS_PER_DAY, j = r % RH_SLOTS_PER_DAY;
@@ -2890,6 +2970,7 @@ int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day
     if (!pc) {
         for (int k = 0; k < 3; ++k)
             HIPCHK(ctx, hipMemcpyAsync(ctx->dev->forc[k], src[k], sizeof(double) * RH_SLOTS_PER_DAY, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(&ctx->dev->day_cache_ok, 0, sizeof(int), ctx->stream));   // (ctrl_wave's cache of the day)
     } else {
         const size_t bytes = sizeof(double) * RH_SLOTS_PER_DAY * (size_t)ctx->n;
         if (!ctx->transpose_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->transpose_buf, bytes));
