@@ -24,6 +24,7 @@
 #include <new>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rh_physics.h"
@@ -44,6 +45,8 @@
 #define RH_TAIL_USE_NEXT 1   // this step runs on S_next / X_next (the previous kernel's tail formed them); its tail commits them
 #define RH_TAIL_CTRL 2       // the tail forms the next step's S_next / X_next
 #define RH_TAIL_HOOKS 4      // ... including the device-side set_forcing / set_parameters hooks
+#define RH_TAIL_PRE 16      // (with RH_TAIL_CTRL) the launch has one workgroup more than the columns need: its first wavefront forms the half of the
+                             // next step's control part that does not depend on the columns WHILE they are stepped (pre_tail); the tail does the rest
 #define RH_TAIL_SKIP 8       // nobody reads this step's summary word (per-cell forcing behind k_cell_front, which looks at the planes): no summary
                              // bits posted, no completion counting, no tail -- three round trips less at the end of a launch-bound step
 #define RH_SRC_WORD3 0       // the summary word sits in words[3] (a fused kernel ran last)
@@ -87,6 +90,7 @@ struct DevState {
     // what the control part keeps of the DAY's shared series between two midnights (ctrl_wave): the OR of the slots' forcing bits and the
     // three daily aggregates -- a step inside the day then needs the six slots of its hourly window only.  Everything that writes forc
     // clears day_cache_ok.
+    unsigned long long pre_words[64];        // pre_tail -> tail of one fused launch (TailPre, a word per lane)
     int day_cache_ok, day_cache_pad;
     unsigned long long day_fb;
     double day_agg[3];
@@ -964,6 +968,8 @@ struct CtrlIn {
     int cache_ok;
     unsigned long long day_fb;
     double day_agg[3];
+    int *dt_log;               // log_dt's three loads, with the others
+    int dt_log_n, dt_log_cap;
 };
 RH_DEV CtrlIn ctrl_inputs(const DevState *D) {
     CtrlIn in;
@@ -983,6 +989,9 @@ RH_DEV CtrlIn ctrl_inputs(const DevState *D) {
     in.cache_ok = D->day_cache_ok;
     in.day_fb = D->day_fb;
     in.day_agg[0] = D->day_agg[0]; in.day_agg[1] = D->day_agg[1]; in.day_agg[2] = D->day_agg[2];
+    in.dt_log = D->dt_log;
+    in.dt_log_n = D->dt_log_n;
+    in.dt_log_cap = D->dt_log_cap;
     return in;
 }
 // slot k (uniform) of a variable from the registers of ctrl_inputs (x0, x1, x2: the lane's slots lane, lane + 64, lane + 128)
@@ -993,17 +1002,30 @@ RH_DEV double ctrl_slot(double x0, double x1, double x2, int k) {
     const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
-RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks, const CtrlIn &in) {
+// The control part in two halves.  ctrl_pre: everything that does not depend on the columns -- the time limit, the set_forcing hook, the
+// day's forcing bits (fb) and the aggregates of the day and of the hourly window; it may run while the columns are still being stepped
+// (the extra workgroup of a fused launch, pre_tail), so what running wavefronts read (D->monthly, D->per_cell) is NOT written here but
+// handed on in `side` (RH_SIDE_*).  ctrl_post: the decisions on word 0 and word 1 (`cells` = OR of the columns' summary bits), dt and the
+// event bookkeeping.
+#define RH_SIDE_MONTHLY_SET 1   // D->monthly = bit RH_SIDE_MONTHLY
+#define RH_SIDE_MONTHLY 2
+#define RH_SIDE_PER_CELL_SET 4  // D->per_cell = bit RH_SIDE_PER_CELL
+#define RH_SIDE_PER_CELL 8
+RH_DEV void ctrl_side_effects(DevState *D, int side) {   // (one lane)
+    if (side & RH_SIDE_PER_CELL_SET) D->per_cell = (side & RH_SIDE_PER_CELL) ? 1 : 0;
+    if (side & RH_SIDE_MONTHLY_SET) D->monthly = (side & RH_SIDE_MONTHLY) ? 1 : 0;
+}
+RH_DEV void ctrl_pre(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, int do_hooks, const CtrlIn &in, unsigned long long &fb_out, int &side) {
 #ifdef RH_STEP_PHASES
     unsigned long long tph = clock64();
 #endif
     const int lane = threadIdx.x & 63;
-    const double ta_fm = in.ta_fm;
-    const int64_t hpi_i = in.hpi, end_event = in.end_event;
-    Consts Kf;   // forcing_bits / derive_word1 read hpi and ta_fm only
-    Kf.hpi = hpi_i;
-    Kf.ta_fm = ta_fm;
+    Consts Kf;   // forcing_bits reads hpi and ta_fm only
+    Kf.hpi = in.hpi;
+    Kf.ta_fm = in.ta_fm;
     bool fresh_day = false;
+    side = 0;
+    fb_out = 0;
     const long long t_end = in.t_end;
     X.halt = (t_end >= 0 && S.time >= t_end) ? 1 : 0;   // the run is over (roger/roger.py:548): nothing is formed, S stays as it is
     X.last = 0;
@@ -1026,18 +1048,17 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
             S.month[1] = D->calendar[1][i0];
             S.doy[1] = D->calendar[2][i0];
             S.itt_forc = i0 + RH_SLOTS_PER_DAY;
-            if (lane == 0) D->per_cell = D->weights[0] ? 1 : 0;
+            side |= RH_SIDE_PER_CELL_SET | (D->weights[0] ? RH_SIDE_PER_CELL : 0);
             fresh_day = true;
         }
-        if (lane == 0) D->monthly = (S.month[1] != S.month[0]) && (S.itt > 1);
+        side |= RH_SIDE_MONTHLY_SET | (((S.month[1] != S.month[0]) && (S.itt > 1)) ? RH_SIDE_MONTHLY : 0);
     }
     const int64_t itd = S.itt_day;
-    unsigned long long w;
     if (!fresh_day && in.cache_ok) {
         // inside a day whose bits and daily aggregates an earlier control part has formed: the six slots of the hourly window, out of the
         // registers (forcing_aggregates_of: the sums in numpy's order, as the full path forms them)
         RH_TPH(1)
-        w = (cells & 0xFull) | in.day_fb;
+        fb_out = in.day_fb;
         double agg[9];
         // (copies by value: a closure holding a reference to `in` keeps the whole struct in scratch memory)
         const double p0 = in.f[0][0], p1 = in.f[0][1], p2 = in.f[0][2], t0 = in.f[1][0], t1 = in.f[1][1], t2 = in.f[1][2];
@@ -1069,7 +1090,7 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
             cnt_h += __popcll(__ballot(ok && (k >= itd) && (k < itd + 6)));
         }
         fb = wave_or(fb);
-        w = (cells & 0xFull) | fb;
+        fb_out = fb;
         // numpy's partial sums (agg_body): six sums x 16 (half, lane-of-eight) pairs
         for (int item = lane; item < 96; item += 64) {
             const int sum_id = item >> 4, l16 = item & 15, half = l16 >> 3, j = l16 & 7;
@@ -1107,6 +1128,20 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
             D->day_cache_ok = 1;
         }
     }
+    X.cond_time = (S.time % 86400 == 0);
+    X.itt_day = itd;
+}
+RH_DEV void ctrl_post(DevState *D, rh_scalars &S, StepCtx &X, unsigned long long cells, unsigned long long fb, double ta_fm, int64_t hpi_i, int64_t end_event,
+                      long long t_end, int *dt_log, int dt_log_n, int dt_log_cap) {
+#ifdef RH_STEP_PHASES
+    unsigned long long tph = clock64();
+#endif
+    const int lane = threadIdx.x & 63;
+    if (X.halt) return;
+    Consts Kf;   // derive_word1 reads hpi and ta_fm only
+    Kf.hpi = hpi_i;
+    Kf.ta_fm = ta_fm;
+    const unsigned long long w = (cells & 0xFull) | fb;
     {   // uniform from here on (every lane computes the same)
         const bool all_p_le0 = !bit(w, PB_P_NOT_LE0), any_p_gt0 = bit(w, PB_P_GT0), any_p_gthpi = bit(w, PB_P_GT_HPI);
         const bool all_p_lehpi = !bit(w, PB_P_NOT_LE_HPI), all_ta_gt = !bit(w, PB_TA_NOT_GT), any_ta_gt = bit(w, PB_TA_GT);
@@ -1120,7 +1155,6 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         const bool cond3 = any_p_gthpi && any_p_gt0 && snow_any;
         const bool cond4 = all_p_lehpi && any_p_gt0 && snow_any;
         const bool cond5 = all_p_le0 && snow_any;
-        X.cond_time = (S.time % 86400 == 0);
         X.sel_daily = cond0 || cond00;
         X.sel_hourly = (cond2 || cond4 || cond5) && !cond1 && !cond3;
         X.sel_10min = (cond1 || cond3) && !cond2 && !cond4 && !cond5;
@@ -1128,7 +1162,6 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         if (X.sel_hourly) dts = 3600;
         if (X.sel_10min) dts = 600;
         X.dt_secs_prelim = dts;
-        X.itt_day = itd;
         X.sel_p = X.sel_10min ? 2 : (X.sel_hourly ? 1 : (X.sel_daily ? 0 : -1));
         if (X.sel_p >= 0) {
             X.prec_sel = agg_pick(X, X.sel_p, 0);
@@ -1143,9 +1176,20 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
         D->words[0] = 0;
         D->words[1] = 0;
         D->words[2] = 0;
-        log_dt(D, dts);
+        if (dt_log) {   // log_dt on values requested with the tail's other loads
+            if (dt_log_n < dt_log_cap) dt_log[dt_log_n] = (int)dts;
+            D->dt_log_n = dt_log_n + 1;
+        }
     }
     RH_TPH(5)
+}
+// both halves in one wavefront (the control kernel; a fused launch without the extra workgroup)
+RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsigned long long cells, int do_hooks, const CtrlIn &in) {
+    unsigned long long fb;
+    int side;
+    ctrl_pre(D, L, S, X, do_hooks, in, fb, side);
+    if ((threadIdx.x & 63) == 0) ctrl_side_effects(D, side);
+    ctrl_post(D, S, X, cells, fb, in.ta_fm, in.hpi, in.end_event, in.t_end, in.dt_log, in.dt_log_n, in.dt_log_cap);
 }
 RH_DEV unsigned long long dev_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RH_DEV void dev_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1195,28 +1239,98 @@ RH_DEV bool grid_completion(DevState *D, int n_groups) {
     __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
+// What pre_tail hands to the tail: S after the hook, X with the aggregates, the day's forcing bits, the deferred writes (RH_SIDE_*) -- one
+// 8-byte word per lane (WI: integer fields, WF: doubles), packed by a select chain and taken apart by v_readlane with constant lanes:
+// the structs never exist in memory on either side (as aggregates through LDS they cost both kernels a scratch frame).
+#define RH_PRE_FIELDS(WI, WF)                                                                                                        \
+    WI(S.itt) WI(S.time) WI(S.dt_secs) WI(S.itt_day) WI(S.itt_forc) WI(S.time_event0) WI(S.event_id_counter)                         \
+    WI(S.event_id[0]) WI(S.event_id[1]) WI(S.year[0]) WI(S.year[1]) WI(S.month[0]) WI(S.month[1]) WI(S.doy[0]) WI(S.doy[1])          \
+    WF(S.dt) WI(S.sanity_ok)                                                                                                         \
+    WF(X.dt) WF(X.agg[0]) WF(X.agg[1]) WF(X.agg[2]) WF(X.agg[3]) WF(X.agg[4]) WF(X.agg[5]) WF(X.agg[6]) WF(X.agg[7]) WF(X.agg[8])    \
+    WI(X.month_tau) WI(X.sel_daily) WI(X.sel_hourly) WI(X.sel_10min) WI(X.sel_p) WF(X.prec_sel) WF(X.ta_sel) WI(X.sel_w)             \
+    WF(X.pet_sel_w) WF(X.ta_sel_w) WI(X.cond1) WI(X.cond2) WI(X.cond3) WI(X.cond4) WI(X.cond5) WI(X.cond_time)                       \
+    WI(X.dt_secs_prelim) WI(X.itt_day) WI(X.apply_sel) WI(X.forc_exhausted) WI(X.halt) WI(X.last)                                    \
+    WI(fb) WI(side)
+static_assert(sizeof(rh_scalars) == 17 * 8, "RH_PRE_FIELDS lists every field of rh_scalars");
+static_assert(sizeof(StepCtx) == 200, "RH_PRE_FIELDS lists every field of StepCtx");
+RH_DEV unsigned long long lane_word(unsigned long long w, int l) {   // (l: a constant)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)w, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(w >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// The first wavefront of a fused launch's extra workgroup (RH_TAIL_PRE), at the START of the launch: commits the running step's S / X
+// (nothing of the launch reads D->S / D->X: the columns work from X_next), forms the columns-independent half of the next control part
+// and publishes it through returning device-scope atomics (the tail reads it with device-scope loads: sumw's scheme).  `dep`: the wave's
+// completion count, made to depend on the atomics' return.
+RH_DEV void pre_tail(DevState *D, CtrlLds &L, int flags, unsigned &dep) {
+    const int lane = threadIdx.x & 63;
+    const CtrlIn in = ctrl_inputs(D);
+    const bool use_next = (flags & RH_TAIL_USE_NEXT) != 0;
+    rh_scalars S = *(use_next ? &D->S_next : &D->S);   // (one load site: two would leave a copy of the structs in scratch memory)
+    StepCtx X = *(use_next ? &D->X_next : &D->X);
+    if (use_next && lane == 0) {
+        D->S = S;
+        D->X = X;
+        if (X.forc_exhausted) D->err_flags |= RH_DEVERR_FORCING;
+    }
+    unsigned long long fb;
+    int side;
+    ctrl_pre(D, L, S, X, (flags & RH_TAIL_HOOKS) != 0, in, fb, side);
+    unsigned long long mine = 0;
+    {
+        int k = 0;
+#define RH_WI(f) if (lane == k) mine = (unsigned long long)(long long)(f); ++k;
+#define RH_WF(f) if (lane == k) mine = (unsigned long long)__double_as_longlong(f); ++k;
+        RH_PRE_FIELDS(RH_WI, RH_WF)
+#undef RH_WI
+#undef RH_WF
+    }
+    const unsigned long long old = __hip_atomic_exchange(&D->pre_words[lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(dep) : "v"((unsigned)old));   // (dep is used only after the exchange has returned -- for every lane: one instruction)
+}
 RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     const int lane = threadIdx.x & 63;
-    const CtrlIn in = ctrl_inputs(D);   // (requested first: one round trip for everything the tail reads)
+    const bool pre = (flags & RH_TAIL_PRE) != 0;
+    CtrlIn in;
+    if (!pre) in = ctrl_inputs(D);   // (requested first: one round trip for everything the tail reads)
 #ifdef RH_STEP_PHASES
     const unsigned long long tph0 = clock64();
 #endif
-    const unsigned long long cells = wave_or(dev_load(&D->sumw[lane * RH_WSTRIDE]));
-    dev_store(&D->sumw[lane * RH_WSTRIDE], 0ull);
+    // every load of the tail is requested before the first result is used (one round trip)
+    const unsigned long long sw = dev_load(&D->sumw[lane * RH_WSTRIDE]);
     const unsigned long long bad = dev_load(&D->words[2]);
+    const unsigned long long pw = pre ? dev_load(&D->pre_words[lane]) : 0ull;
+    const double ta_fm = D->K.ta_fm;
+    const int64_t hpi = D->K.hpi, end_event = D->K.end_event;
+    const long long t_end = D->t_end;
+    int *const dt_log = D->dt_log;
+    const int dt_log_n = D->dt_log_n, dt_log_cap = D->dt_log_cap;
     rh_scalars S;
     StepCtx X;
-    if (flags & RH_TAIL_USE_NEXT) {
-        S = D->S_next;
-        X = D->X_next;
-    } else {
-        S = D->S;
-        X = D->X;
+    unsigned long long fb = 0;
+    int side = 0;
+    if (!pre) {
+        if (flags & RH_TAIL_USE_NEXT) {
+            S = D->S_next;
+            X = D->X_next;
+        } else {
+            S = D->S;
+            X = D->X;
+        }
+    }
+    const unsigned long long cells = wave_or(sw);
+    dev_store(&D->sumw[lane * RH_WSTRIDE], 0ull);
+    if (pre) {   // pre_tail has done the commit and its half of the control part
+        int k = 0;
+#define RH_WI(f) f = (std::remove_reference_t<decltype((f))>)(long long)lane_word(pw, k); ++k;
+#define RH_WF(f) f = __longlong_as_double((long long)lane_word(pw, k)); ++k;
+        RH_PRE_FIELDS(RH_WI, RH_WF)
+#undef RH_WI
+#undef RH_WF
     }
     if (lane == 0) {
         D->words[3] = cells;
         D->sanity_last = bad;
-        if (flags & RH_TAIL_USE_NEXT) {
+        if (!pre && (flags & RH_TAIL_USE_NEXT)) {
             D->S = S;
             D->X = X;
             if (X.forc_exhausted) D->err_flags |= RH_DEVERR_FORCING;
@@ -1230,7 +1344,12 @@ RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
         atomicAdd(&g_tail_phases[7], 1ull);
     }
 #endif
-    ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0, in);
+    if (pre) {
+        if (lane == 0) ctrl_side_effects(D, side);
+        ctrl_post(D, S, X, cells, fb, ta_fm, hpi, end_event, t_end, dt_log, dt_log_n, dt_log_cap);
+    } else {
+        ctrl_wave(D, L, S, X, cells, (flags & RH_TAIL_HOOKS) != 0, in);
+    }
     if (lane == 0) {
         D->S_next = S;
         D->X_next = X;
@@ -1862,15 +1981,18 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     // the arena instead of every XCD touching every page.  Never slower; on one box 6 - 11 % faster at 10^7 columns (21 GB
     // arena: 3.87 -> 3.44 .. 3.64 ms per step; oneD 4.38 -> 4.12 ms), on another box and up to 4 x 10^6 columns the same
     // (DESIGN.md section 5 on the speed levels of this kernel).  -DRH_XCD_ROUND_ROBIN: the plain mapping.
+    // RH_TAIL_PRE: the last workgroup of the grid has no columns -- its first wavefront is pre_tail
+    const unsigned nb = gridDim.x - ((flags & RH_TAIL_PRE) ? 1u : 0u);
+    const bool extra = blockIdx.x >= nb;
 #ifndef RH_XCD_ROUND_ROBIN
-    const unsigned nb = gridDim.x, x = blockIdx.x & 7u, base_cnt = nb >> 3, rem = nb & 7u;
+    const unsigned x = blockIdx.x & 7u, base_cnt = nb >> 3, rem = nb & 7u;
     const unsigned blk = x * base_cnt + (x < rem ? x : rem) + (blockIdx.x >> 3);
-    const int64_t i = (int64_t)blk * RH_BLOCK + threadIdx.x;
+    const int64_t i = extra ? a.n : (int64_t)blk * RH_BLOCK + threadIdx.x;
 #else
-    const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+    const int64_t i = extra ? a.n : (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
 #endif
     __shared__ unsigned wg_done;      // wavefronts of this workgroup that are through
-    __shared__ CtrlLds tail_lds;      // scratch of the tail (one wavefront of the whole grid uses it)
+    __shared__ CtrlLds tail_lds;      // scratch of the tail and of pre_tail (one wavefront each of the whole grid)
     const StepCtx *Xp = (flags & RH_TAIL_USE_NEXT) ? &D->X_next : &D->X;
     // rh_set_time_limit: the control part found the run over before this step (uniform over the grid).  Nothing runs, the tail
     // included: S_next / X_next keep saying so to every launch that follows.
@@ -1921,6 +2043,9 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     } else if (post) {
         post_summary(D, 0ull, dep);
     }
+#if !defined(RH_CENSUS) && !defined(RH_X_NOPRE)
+    if (__builtin_expect(extra && threadIdx.x < 64, 0)) pre_tail(D, tail_lds, flags, dep);
+#endif
     const bool any_bad = __any(bad);
     if (!post) {   // RH_TAIL_SKIP: the sanity word is all anybody reads of this launch
         if (any_bad && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(&D->words[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3276,7 +3401,10 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
         HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
 #endif
     }
-    const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
+    // a launch whose tail forms the next step's control part gets one workgroup more: pre_tail (RH_NO_PRE_TAIL=1: the tail does it all)
+    static const bool pre_ok = std::getenv("RH_NO_PRE_TAIL") == nullptr;
+    if ((flags & RH_TAIL_CTRL) && pre_ok) flags |= RH_TAIL_PRE;
+    const dim3 grid(grid_for(ctx->n) + ((flags & RH_TAIL_PRE) ? 1u : 0u)), block(RH_BLOCK);
     const bool lat = ctx->cfg.enable_lateral_flow != 0;
 #ifdef RH_EVENT_RECORD
 #define RH_LAUNCH_K(K) hipLaunchKernelGGL(K, grid, block, 0, ctx->stream, ctx->arena, ctx->dev, flags, ctx->n_groups, dst64)
