@@ -506,24 +506,25 @@ RH_DEV void stage_day(const DevState *D, DaySeries &s, const FreshDay *fd = null
 // forc_multi (a table of 3 x n_stations x 144 values: cache-resident; on a fresh day the rows of the series themselves); a column without
 // a station reads zeros.
 struct DayView {
-    const DaySeries *lds;
-    const double *sv[3];   // several stations: slot 0 of station 0, per variable
+    const DaySeries *lds;  // null: the one series is read where it lies (DevState::forc) -- a step that needs six slots of it does not stage the day
+    const double *sv[3];   // several stations: slot 0 of station 0, per variable; one series without staging: DevState::forc[v]
     size_t ststride;       // ... and the distance between two stations
     bool multi;
     int st;
     RH_DEV double operator()(int v, int k) const {
-        if (!multi) return lds->f[v][k];
+        if (!multi) return lds ? lds->f[v][k] : sv[v][k];
         return st < 0 ? 0.0 : sv[v][(size_t)st * ststride + k];
     }
 };
-RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i, const FreshDay *fd = nullptr) {
+RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i, const FreshDay *fd = nullptr, bool staged = true) {
     DayView d;
-    d.lds = &lds;
+    d.lds = staged ? &lds : nullptr;
     d.multi = D->n_stations > 0;
     d.st = d.multi ? D->station_idx[i] : 0;
     const bool fresh = fd && fd->fresh;
     for (int v = 0; v < 3; ++v)
-        d.sv[v] = !d.multi ? nullptr : (fresh ? D->series[v] + fd->i0 : D->forc_multi + (size_t)v * D->n_stations * RH_SLOTS_PER_DAY);
+        d.sv[v] = !d.multi ? (staged ? nullptr : (fresh ? D->series[v] + fd->i0 : &D->forc[v][0]))   // (fresh: the day the hook is about to bring)
+                           : (fresh ? D->series[v] + fd->i0 : D->forc_multi + (size_t)v * D->n_stations * RH_SLOTS_PER_DAY);
     d.ststride = fresh ? (size_t)D->nitt_forc : (size_t)RH_SLOTS_PER_DAY;
     return d;
 }
@@ -1242,15 +1243,15 @@ RH_DEV bool grid_completion(DevState *D, int n_groups) {
 // What pre_tail hands to the tail: S after the hook, X with the aggregates, the day's forcing bits, the deferred writes (RH_SIDE_*) -- one
 // 8-byte word per lane (WI: integer fields, WF: doubles), packed by a select chain and taken apart by v_readlane with constant lanes:
 // the structs never exist in memory on either side (as aggregates through LDS they cost both kernels a scratch frame).
-#define RH_PRE_FIELDS(WI, WF)                                                                                                        \
+#define RH_SX_FIELDS(WI, WF)                                                                                                         \
     WI(S.itt) WI(S.time) WI(S.dt_secs) WI(S.itt_day) WI(S.itt_forc) WI(S.time_event0) WI(S.event_id_counter)                         \
     WI(S.event_id[0]) WI(S.event_id[1]) WI(S.year[0]) WI(S.year[1]) WI(S.month[0]) WI(S.month[1]) WI(S.doy[0]) WI(S.doy[1])          \
     WF(S.dt) WI(S.sanity_ok)                                                                                                         \
     WF(X.dt) WF(X.agg[0]) WF(X.agg[1]) WF(X.agg[2]) WF(X.agg[3]) WF(X.agg[4]) WF(X.agg[5]) WF(X.agg[6]) WF(X.agg[7]) WF(X.agg[8])    \
     WI(X.month_tau) WI(X.sel_daily) WI(X.sel_hourly) WI(X.sel_10min) WI(X.sel_p) WF(X.prec_sel) WF(X.ta_sel) WI(X.sel_w)             \
     WF(X.pet_sel_w) WF(X.ta_sel_w) WI(X.cond1) WI(X.cond2) WI(X.cond3) WI(X.cond4) WI(X.cond5) WI(X.cond_time)                       \
-    WI(X.dt_secs_prelim) WI(X.itt_day) WI(X.apply_sel) WI(X.forc_exhausted) WI(X.halt) WI(X.last)                                    \
-    WI(fb) WI(side)
+    WI(X.dt_secs_prelim) WI(X.itt_day) WI(X.apply_sel) WI(X.forc_exhausted) WI(X.halt) WI(X.last)
+#define RH_PRE_FIELDS(WI, WF) RH_SX_FIELDS(WI, WF) WI(fb) WI(side)
 static_assert(sizeof(rh_scalars) == 17 * 8, "RH_PRE_FIELDS lists every field of rh_scalars");
 static_assert(sizeof(StepCtx) == 200, "RH_PRE_FIELDS lists every field of StepCtx");
 RH_DEV unsigned long long lane_word(unsigned long long w, int l) {   // (l: a constant)
@@ -1390,11 +1391,19 @@ RH_DEV unsigned long long front_daily(P p, T t, E e, double *agg, const Consts &
 }
 // the control part by the last wavefront: S / X as k_agg's thread 0 and k_scalars form them
 // fd: the set_forcing hook rode along with the kernel (fresh_day) -- what it does to the state happens here, once
-RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, const FreshDay &fd, int hooks) {
+RH_DEV void front_ctrl(DevState *D, bool daily_due, const FreshDay &fd, int hooks) {
     const int lane = threadIdx.x & 63;
+    // everything this wavefront reads is requested before the first result is used (one round trip, as in the fused kernel's tail)
+    const unsigned long long fw = dev_load(&D->frontw[lane * RH_WSTRIDE]);
+    const unsigned long long dw = daily_due ? dev_load(&D->dayw[lane * RH_WSTRIDE]) : 0ull;
     unsigned long long day = D->day_word;
+    const int64_t end_event = D->K.end_event;
+    int *const dt_log = D->dt_log;
+    const int dt_log_n = D->dt_log_n, dt_log_cap = D->dt_log_cap;
+    const unsigned long long cells = wave_or(fw);
+    dev_store(&D->frontw[lane * RH_WSTRIDE], 0ull);
     if (daily_due) {
-        day = wave_or(dev_load(&D->dayw[lane * RH_WSTRIDE]));
+        day = wave_or(dw);
         dev_store(&D->dayw[lane * RH_WSTRIDE], 0ull);
     }
     if (fd.fresh) {   // hooks_set_forcing: the day of the resident series becomes the current one for everybody behind this kernel
@@ -1408,7 +1417,7 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, co
     }
     if (lane != 0) return;
     D->day_word = day;
-    rh_scalars S = D->S;
+    rh_scalars S = D->S;   // (hoisted above the folds these two structs end up in scratch memory)
     StepCtx X = D->X;
     if (hooks) {
         if (fd.fresh) {
@@ -1460,14 +1469,17 @@ RH_DEV void front_ctrl(DevState *D, unsigned long long cells, bool daily_due, co
     w1 |= bit(cells, FC_COMMON + 1) ? BIT(PC_SWE_NOT_LE0) : 0;
     w1 |= bit(cells, FC_COMMON + 2) ? BIT(PC_PM1_NE0) : 0;
     w1 |= bit(cells, FC_COMMON + 3) ? BIT(PC_PM1_EQ0) : 0;
-    const int64_t dts = scalars_update(S, X, w1, 1, 2, true, D->K.end_event);
+    const int64_t dts = scalars_update(S, X, w1, 1, 2, true, end_event);
     D->words[0] = 0;
     D->words[1] = 0;
     D->words[2] = 0;
     D->sanity_last = 0;   // (the fused kernel behind this front has no tail: words[2] is the whole record of its step)
     D->S = S;
     D->X = X;
-    log_dt(D, dts);
+    if (dt_log) {   // log_dt
+        if (dt_log_n < dt_log_cap) dt_log[dt_log_n] = (int)dts;
+        D->dt_log_n = dt_log_n + 1;
+    }
 }
 // PART 0: every step's part; 1: with the daily part inline (small grids: one launch); 2: the daily part alone (in front of PART 0 on large
 // grids, returning at once unless it is due: the daily sums' code needs > 200 registers, which would leave every step's part two waves per
@@ -1508,7 +1520,9 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
         ew = D->weights[2][ii];
     }
     if (threadIdx.x == 0) wg_done = 0;
-    if (weighted) stage_day(D, day, &fd);
+    // the whole day in LDS only where all of it is walked (the daily part); every step's part reads its window's six slots where they lie
+    const bool staged = weighted && with_daily && daily_due;
+    if (staged) stage_day(D, day, &fd);
     else __syncthreads();
     const Consts K = D->K;
     const int64_t itd = fd.itd;
@@ -1516,7 +1530,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
     if (in) {
         double agg[9];
         if (weighted) {
-            const DayView F = day_view(D, day, i, &fd);
+            const DayView F = day_view(D, day, i, &fd, staged);
             auto p = [&](int k) { return F(0, k) * pw; };
             auto t = [&](int k) { return F(1, k) + toff; };
             auto e = [&](int k) { return F(2, k) * ew; };
@@ -1575,10 +1589,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_cell_front(Arena a, DevState *D, i
         }
     }
     if (__shfl((int)last, 0)) {
-        const int lane = threadIdx.x & 63;
-        const unsigned long long cells = wave_or(dev_load(&D->frontw[lane * RH_WSTRIDE]));
-        dev_store(&D->frontw[lane * RH_WSTRIDE], 0ull);
-        front_ctrl(D, cells, daily_due, fd, hooks);
+        front_ctrl(D, daily_due, fd, hooks);
     }
 }
 
