@@ -65,7 +65,14 @@ if [ "$what" = all ] || [ "$what" = svat ]; then
     python3 bench.py --stepping $st --size 80 53 --days 60 --warmup-days 2 > $scratch/svat_80x53_$st.out 2> $scratch/svat_80x53_$st.err && last $scratch/svat_80x53_$st.out > $out/${tag}_bench_svat_80x53_run_$st.json
   done
   # the parameter fast paths of the fused step, alternating in this very call
-  tools/ab_params.sh "--steps 200 --warmup 10" 2 ${tag}_u1e6 > $out/${tag}_ab_param_paths.txt 2>&1
+  {
+    echo "# The parameter fast paths of the fused step switched off one at a time (tools/ab_params.sh: RH_NO_PARAM_UNIFORM / RH_NO_PARAM_DERIVE /"
+    echo "# RH_NO_MASK_CONSTANT), alternating inside this one call; bytes/col = what the variant must move (census x rh_param_stats)."
+    echo "# Blocks: 10^6 columns uniform parameters (two rounds), 10^6 columns parameters drawn per column, 10^7 columns uniform."
+    echo "# Earlier in round 4 (removed from the source): the loads of stage k + 2 requested before stage k -- everywhere: + 5 % and spills;"
+    echo "# through the three short early stages only: +- 1 %."
+  } > $out/${tag}_ab_param_paths.txt
+  tools/ab_params.sh "--steps 200 --warmup 10" 2 ${tag}_u1e6 >> $out/${tag}_ab_param_paths.txt 2>&1
   tools/ab_params.sh "--steps 200 --warmup 10 --params hetero" 1 ${tag}_h1e6 >> $out/${tag}_ab_param_paths.txt 2>&1
   tools/ab_params.sh "--steps 60 --warmup 5 --size 3200 3125" 1 ${tag}_u1e7 >> $out/${tag}_ab_param_paths.txt 2>&1
   # BASELINE configs[4] as written: the Eberbaechle shape over the station's full 2019-2022 series
