@@ -185,6 +185,7 @@ struct rh_ctx {
     bool defer_select_ok = true;     // RH_NO_DEFERRED_SELECT: k_select stores the per-cell prec / ta itself (A/B, tests)
     int64_t cell_agg_split_min = 65536;   // columns from which the per-cell aggregates run as two kernels (RH_CELL_AGG_SPLIT_MIN: tests)
     bool pending_valid;   // S_next / X_next hold the control part of the next step (formed by the last fused kernel's tail)
+    bool pre_valid = false;   // ... or, multi-GPU step: pre_words hold its columns-independent half (pre_tail of the last fused launch), for k_ctrl behind the exchange
     int pending_hooks;    // ... formed with / without the device-side hooks
     bool tail_ok;         // RH_NO_TAIL_CTRL unset
     int n_groups;         // fused kernel: completion groups (about 64 workgroups each, at most RH_DONE_GROUPS)
@@ -1194,13 +1195,32 @@ RH_DEV void ctrl_wave(DevState *D, CtrlLds &L, rh_scalars &S, StepCtx &X, unsign
 }
 RH_DEV unsigned long long dev_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RH_DEV void dev_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// What pre_tail hands to the tail: S after the hook, X with the aggregates, the day's forcing bits, the deferred writes (RH_SIDE_*) -- one
+// 8-byte word per lane (WI: integer fields, WF: doubles), packed by a select chain and taken apart by v_readlane with constant lanes:
+// the structs never exist in memory on either side (as aggregates through LDS they cost both kernels a scratch frame).
+#define RH_SX_FIELDS(WI, WF)                                                                                                         \
+    WI(S.itt) WI(S.time) WI(S.dt_secs) WI(S.itt_day) WI(S.itt_forc) WI(S.time_event0) WI(S.event_id_counter)                         \
+    WI(S.event_id[0]) WI(S.event_id[1]) WI(S.year[0]) WI(S.year[1]) WI(S.month[0]) WI(S.month[1]) WI(S.doy[0]) WI(S.doy[1])          \
+    WF(S.dt) WI(S.sanity_ok)                                                                                                         \
+    WF(X.dt) WF(X.agg[0]) WF(X.agg[1]) WF(X.agg[2]) WF(X.agg[3]) WF(X.agg[4]) WF(X.agg[5]) WF(X.agg[6]) WF(X.agg[7]) WF(X.agg[8])    \
+    WI(X.month_tau) WI(X.sel_daily) WI(X.sel_hourly) WI(X.sel_10min) WI(X.sel_p) WF(X.prec_sel) WF(X.ta_sel) WI(X.sel_w)             \
+    WF(X.pet_sel_w) WF(X.ta_sel_w) WI(X.cond1) WI(X.cond2) WI(X.cond3) WI(X.cond4) WI(X.cond5) WI(X.cond_time)                       \
+    WI(X.dt_secs_prelim) WI(X.itt_day) WI(X.apply_sel) WI(X.forc_exhausted) WI(X.halt) WI(X.last)
+#define RH_PRE_FIELDS(WI, WF) RH_SX_FIELDS(WI, WF) WI(fb) WI(side)
+static_assert(sizeof(rh_scalars) == 17 * 8, "RH_PRE_FIELDS lists every field of rh_scalars");
+static_assert(sizeof(StepCtx) == 200, "RH_PRE_FIELDS lists every field of StepCtx");
+RH_DEV unsigned long long lane_word(unsigned long long w, int l) {   // (l: a constant)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)w, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(w >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
 // The control kernel of a step that does not find S_next / X_next ready (first step, after the host touched planes or
 // scalars, multi-GPU after the exchange): one wavefront.  src: where the columns' summary word is (RH_SRC_*); src64 != null:
 // it arrives as 64 int32 (0 / 1) from the exchange between the ranks and is folded here.
-__global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src, const int *src64) {
+__global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src, const int *src64, int use_pre = 0) {
     __shared__ CtrlLds L;
     const int lane = threadIdx.x & 63;
     const CtrlIn in = ctrl_inputs(D);
+    const unsigned long long pw = use_pre ? D->pre_words[lane] : 0ull;   // (written by the launch in front: a plain load)
     unsigned long long cells;
     if (src64) {
         cells = wave_or(src64[lane] ? (1ull << lane) : 0ull);
@@ -1210,9 +1230,26 @@ __global__ __launch_bounds__(64) void k_ctrl(DevState *D, int do_hooks, int src,
     } else {
         cells = D->words[3];
     }
-    rh_scalars S = D->S;
-    StepCtx X = D->X;
-    ctrl_wave(D, L, S, X, cells, do_hooks, in);
+    rh_scalars S;
+    StepCtx X;
+    if (use_pre) {
+        // the columns-independent half was formed by pre_tail of the fused launch in front of the exchange (from the S / X this kernel
+        // would read): the decisions on the exchanged word are left
+        unsigned long long fb = 0;
+        int side = 0;
+        int k = 0;
+#define RH_WI(f) f = (std::remove_reference_t<decltype((f))>)(long long)lane_word(pw, k); ++k;
+#define RH_WF(f) f = __longlong_as_double((long long)lane_word(pw, k)); ++k;
+        RH_PRE_FIELDS(RH_WI, RH_WF)
+#undef RH_WI
+#undef RH_WF
+        if (lane == 0) ctrl_side_effects(D, side);
+        ctrl_post(D, S, X, cells, fb, in.ta_fm, in.hpi, in.end_event, in.t_end, in.dt_log, in.dt_log_n, in.dt_log_cap);
+    } else {
+        S = D->S;
+        X = D->X;
+        ctrl_wave(D, L, S, X, cells, do_hooks, in);
+    }
     if (lane == 0) {
         D->words[3] = cells;
         if (!X.halt) D->sanity_last = 0;
@@ -1239,24 +1276,6 @@ RH_DEV bool grid_completion(DevState *D, int n_groups) {
     if (__hip_atomic_fetch_add(&D->done_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ng - 1) return false;
     __hip_atomic_store(&D->done_top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
-}
-// What pre_tail hands to the tail: S after the hook, X with the aggregates, the day's forcing bits, the deferred writes (RH_SIDE_*) -- one
-// 8-byte word per lane (WI: integer fields, WF: doubles), packed by a select chain and taken apart by v_readlane with constant lanes:
-// the structs never exist in memory on either side (as aggregates through LDS they cost both kernels a scratch frame).
-#define RH_SX_FIELDS(WI, WF)                                                                                                         \
-    WI(S.itt) WI(S.time) WI(S.dt_secs) WI(S.itt_day) WI(S.itt_forc) WI(S.time_event0) WI(S.event_id_counter)                         \
-    WI(S.event_id[0]) WI(S.event_id[1]) WI(S.year[0]) WI(S.year[1]) WI(S.month[0]) WI(S.month[1]) WI(S.doy[0]) WI(S.doy[1])          \
-    WF(S.dt) WI(S.sanity_ok)                                                                                                         \
-    WF(X.dt) WF(X.agg[0]) WF(X.agg[1]) WF(X.agg[2]) WF(X.agg[3]) WF(X.agg[4]) WF(X.agg[5]) WF(X.agg[6]) WF(X.agg[7]) WF(X.agg[8])    \
-    WI(X.month_tau) WI(X.sel_daily) WI(X.sel_hourly) WI(X.sel_10min) WI(X.sel_p) WF(X.prec_sel) WF(X.ta_sel) WI(X.sel_w)             \
-    WF(X.pet_sel_w) WF(X.ta_sel_w) WI(X.cond1) WI(X.cond2) WI(X.cond3) WI(X.cond4) WI(X.cond5) WI(X.cond_time)                       \
-    WI(X.dt_secs_prelim) WI(X.itt_day) WI(X.apply_sel) WI(X.forc_exhausted) WI(X.halt) WI(X.last)
-#define RH_PRE_FIELDS(WI, WF) RH_SX_FIELDS(WI, WF) WI(fb) WI(side)
-static_assert(sizeof(rh_scalars) == 17 * 8, "RH_PRE_FIELDS lists every field of rh_scalars");
-static_assert(sizeof(StepCtx) == 200, "RH_PRE_FIELDS lists every field of StepCtx");
-RH_DEV unsigned long long lane_word(unsigned long long w, int l) {   // (l: a constant)
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)w, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(w >> 32), l);
-    return ((unsigned long long)hi << 32) | lo;
 }
 // The first wavefront of a fused launch's extra workgroup (RH_TAIL_PRE), at the START of the launch: commits the running step's S / X
 // (nothing of the launch reads D->S / D->X: the columns work from X_next), forms the columns-independent half of the next control part
@@ -1290,7 +1309,7 @@ RH_DEV void pre_tail(DevState *D, CtrlLds &L, int flags, unsigned &dep) {
 }
 RH_DEV void step_tail(DevState *D, CtrlLds &L, int flags, int *dst64) {
     const int lane = threadIdx.x & 63;
-    const bool pre = (flags & RH_TAIL_PRE) != 0;
+    const bool pre = (flags & RH_TAIL_PRE) && (flags & RH_TAIL_CTRL);   // (RH_TAIL_PRE alone: the control kernel behind the exchange takes the hand-over)
     CtrlIn in;
     if (!pre) in = ctrl_inputs(D);   // (requested first: one round trip for everything the tail reads)
 #ifdef RH_STEP_PHASES
@@ -2544,7 +2563,7 @@ static void planes_touched(rh_ctx *ctx) {
     ctx->rot_consistent = false;
     ctx->summary_valid = false;
     ctx->routed_summary = false;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->exch_valid = false;
 }
 #define LAUNCH_CELLS(ctx, kern)                                                                                          \
@@ -2860,7 +2879,7 @@ int rh_create(const rh_config *cfg, rh_ctx **out) {
     if ((e = hipMemcpyAsync(&ctx->dev->S, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(scalars)");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");  // K, S are stack locals
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->pending_hooks = 0;
     ctx->tail_ok = std::getenv("RH_NO_TAIL_CTRL") == nullptr;
     ctx->routed_device_ok = std::getenv("RH_ROUTED_BY_ROUTINE") == nullptr;
@@ -3026,7 +3045,7 @@ void *rh_plane_device_ptr(rh_ctx *ctx, int plane) {
 
 int rh_set_scalars(rh_ctx *ctx, const rh_scalars *s) {
     if (!ctx || !s) return RH_ERR_ARG;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->S, s, sizeof(*s), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -3124,7 +3143,7 @@ int rh_set_forcing_day(rh_ctx *ctx, const double *prec_day, const double *ta_day
         }
     }
     ctx->per_cell = pc != 0;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->per_cell, &pc, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
@@ -3471,6 +3490,7 @@ static int launch_fused_kernel(rh_ctx *ctx, int monthly, int flags = 0, int *dst
     }
     ctx->summary_valid = !(flags & RH_TAIL_SKIP);  // the fused kernel's tail leaves the summary word of the state it wrote (words[3])
     ctx->pending_valid = (flags & RH_TAIL_CTRL) != 0;
+    ctx->pre_valid = (flags & RH_TAIL_PRE) && !(flags & RH_TAIL_CTRL);
     ctx->pending_hooks = (flags & RH_TAIL_HOOKS) != 0;
     ctx->exch_valid = dst64 != nullptr;
     if (ctx->diag_n) {
@@ -3558,7 +3578,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
         // ONE per-column launch in front of the fused kernel (k_cell_front; a second one, returning at once unless a new day began, for the
         // daily sums of large grids).  Nothing in front of the fused kernel writes a plane: its lazy rotation stays.
         ctx->summary_valid = false;
-        ctx->pending_valid = false;
+        ctx->pending_valid = ctx->pre_valid = false;
         ctx->exch_valid = false;
         const dim3 grid(grid_for(ctx->n)), block(RH_BLOCK);
         const int force = (ctx->front_daily_stale || ctx->last_front != 2) ? 1 : 0, m1 = ctx->m1_stale ? 1 : 0;
@@ -3582,7 +3602,7 @@ static int step_fused_launches(rh_ctx *ctx, int monthly, int hooks) {
     // (apply_sel = 2, from the per-cell aggregates), the predicate kernels read tau planes only -- with the rotation pending, prec_m1 /
     // swe_m1 are the tau planes themselves.  So the fused kernel keeps its lazy rotation in the per-cell path too.
     ctx->summary_valid = false;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->exch_valid = false;
     hipLaunchKernelGGL(k_pred1, dim3(ctx->pred_blocks), dim3(RH_BLOCK), 0, ctx->stream, ctx->arena, ctx->dev, ctx->pred_daily_stale ? 1 : 0);
     ctx->pred_daily_stale = false;
@@ -3612,7 +3632,7 @@ static int step_summary(rh_ctx *ctx, int32_t *dev_dst64) {
         ctx->summary_valid = true;
         src = RH_SRC_SUMW;
     }
-    ctx->pending_valid = false;   // the ranks decide together: the control kernel follows the exchange
+    ctx->pending_valid = ctx->pre_valid = false;   // the ranks decide together: the control kernel follows the exchange
     LAUNCH_WG(ctx, k_summary_reduce, ctx->dev, ctx->series_buf ? 1 : 0, (int *)dev_dst64, src);
     CHECK_LAUNCH(ctx);
     return RH_OK;
@@ -3687,7 +3707,7 @@ int rh_set_forcing_series(rh_ctx *ctx, const double *prec, const double *ta, con
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->n_stations, 0, sizeof(int), ctx->stream));   // one series for all columns
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->per_cell = false;
     return RH_OK;
 }
@@ -3723,7 +3743,7 @@ int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, c
     HIPCHK(ctx, hipMemsetAsync(&ctx->dev->err_flags, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->forcing_set = true;
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     // the station series reach the columns through the per-cell (weighted) path: neutral weights unless the caller sets some
     if (!ctx->weight_buf[0]) {
         std::vector<double> one((size_t)ctx->n, 1.0), zero((size_t)ctx->n, 0.0);
@@ -3740,7 +3760,7 @@ int rh_set_forcing_stations(rh_ctx *ctx, const double *prec, const double *ta, c
 static void launch_hooks(rh_ctx *ctx) {
     // the hook rewrites D->S (itt_forc, itt_day, the calendar), D->forc and D->monthly: a control part the previous fused kernel's
     // tail formed for the next step (S_next / X_next) was formed BEFORE this hook ran and must not be used
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->exch_valid = false;
     hipLaunchKernelGGL(k_set_forcing, dim3(1), dim3(RH_BLOCK), 0, ctx->stream, ctx->dev);
 }
@@ -3906,7 +3926,7 @@ int rh_set_forcing_weights(rh_ctx *ctx, const double *prec_weight, const double 
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->dev->weights, dptr, sizeof(dptr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pending_valid = false;
+    ctx->pending_valid = ctx->pre_valid = false;
     ctx->per_cell = !clear;   // from the next midnight on; rh_set_forcing_weights is a setup-time call
     ctx->agg_daily_stale = true;
     ctx->pred_daily_stale = true;
@@ -3920,7 +3940,7 @@ int rh_set_time_limit(rh_ctx *ctx, int64_t t_end) {
     HIPCHK(ctx, hipMemcpyAsync(&ctx->dev->t_end, &v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (v is a stack local)
     ctx->t_end = v;
-    ctx->pending_valid = false;   // a control part formed under the old limit (possibly "halt") is not the next step's
+    ctx->pending_valid = ctx->pre_valid = false;   // a control part formed under the old limit (possibly "halt") is not the next step's
     return RH_OK;
 }
 // with a time limit: 1 if the limit is reached already (nothing to enqueue), 0 if the first launch of the call will run a step --
@@ -4063,10 +4083,13 @@ int rh_run_steps_dist(rh_ctx *ctx, int64_t nsteps) {
             HIPCHK(ctx, hipMemcpyAsync(recv, send, 64 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         else
             NCCLCHK(ctx, api->AllReduce(send, recv, 64, ncclInt32, ncclMax, ctx->comm, ctx->stream));
-        LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv);
+        // the fused launch in front of the exchange formed the columns-independent half of this control part (pre_tail): the kernel behind
+        // the exchange keeps the decisions
+        LAUNCH_ONE(ctx, k_ctrl, ctx->dev, 1, RH_SRC_WORD3, (const int *)recv, ctx->pre_valid ? 1 : 0);
         CHECK_LAUNCH(ctx);
         ctx->sparse_next = ctx->sparse_ok && k + 1 < nsteps;
-        int rc = launch_fused_kernel(ctx, -1, 0, send);   // the tail spreads the next step's summary word into `send`
+        static const bool pre_ok = std::getenv("RH_NO_PRE_TAIL") == nullptr;
+        int rc = launch_fused_kernel(ctx, -1, pre_ok ? (RH_TAIL_PRE | RH_TAIL_HOOKS) : 0, send);   // the tail spreads the next step's summary word into `send`
         if (rc) return rc;
     }
     return RH_OK;
@@ -4337,7 +4360,7 @@ int rh_enable_timing(rh_ctx *ctx, int on) {
     if (!ctx) return RH_ERR_ARG;
     ctx->timing = on != 0;
     ctx->ev_used = 0;
-    ctx->pending_valid = false;   // the step log restarts: the next step's entry must be written after this call
+    ctx->pending_valid = ctx->pre_valid = false;   // the step log restarts: the next step's entry must be written after this call
     if (on && !ctx->dt_log_buf) HIPCHK(ctx, hipMalloc((void **)&ctx->dt_log_buf, sizeof(int) * RH_DT_LOG_CAP));
     int *log = on ? ctx->dt_log_buf : nullptr;
     const int cap = RH_DT_LOG_CAP, zero = 0;
