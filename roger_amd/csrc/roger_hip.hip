@@ -2073,6 +2073,8 @@ __global__ __launch_bounds__(RH_BLOCK, RH_STEP_WAVES) void k_step(Arena a, DevSt
     } else if (post) {
         post_summary(D, 0ull, dep);
     }
+    // (behind the column pipeline in the kernel's text: in front of it, the allocator spilled 36 - 63 of the pipeline's registers.
+    //  RH_X_NOPRE / RH_X_NOCOMPLETION / RH_X_NOTAIL: timing-only builds whose results are NOT valid -- profiles/r04_tail_phases.txt)
 #if !defined(RH_CENSUS) && !defined(RH_X_NOPRE)
     if (__builtin_expect(extra && threadIdx.x < 64, 0)) pre_tail(D, tail_lds, flags, dep);
 #endif
