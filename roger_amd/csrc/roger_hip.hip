@@ -503,6 +503,21 @@ RH_DEV void stage_day(const DevState *D, DaySeries &s, const FreshDay *fd = null
     }
     __syncthreads();
 }
+// slot k (uniform) of a variable from a wavefront's registers (ctrl_inputs, k_cell_front) (x0, x1, x2: the lane's slots lane, lane + 64, lane + 128)
+RH_DEV double lane_double(double x, int l) {   // lane l's x (l uniform): v_readlane, no trip through the LDS crossbar
+    const long long bits = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+RH_DEV double ctrl_slot(double x0, double x1, double x2, int k) {
+    // The register is chosen by a UNIFORM branch, not by a select in front of the read: under a divergent mask a select leaves the
+    // switched-off lanes' copy unwritten, and v_readlane reads whatever lane it is told to (the registers themselves were loaded with
+    // every lane on).
+    const int r = __builtin_amdgcn_readfirstlane(k >> 6), l = k & 63;
+    if (r == 0) return lane_double(x0, l);
+    if (r == 1) return lane_double(x1, l);
+    return lane_double(x2, l);
+}
 // The day's series as a column sees it: the one shared series staged in LDS, or -- with several stations -- its station's rows of
 // forc_multi (a table of 3 x n_stations x 144 values: cache-resident; on a fresh day the rows of the series themselves); a column without
 // a station reads zeros.
@@ -523,6 +538,7 @@ RH_DEV DayView day_view(const DevState *D, const DaySeries &lds, int64_t i, cons
     d.multi = D->n_stations > 0;
     d.st = d.multi ? D->station_idx[i] : 0;
     const bool fresh = fd && fd->fresh;
+
     for (int v = 0; v < 3; ++v)
         d.sv[v] = !d.multi ? (staged ? nullptr : (fresh ? D->series[v] + fd->i0 : &D->forc[v][0]))   // (fresh: the day the hook is about to bring)
                            : (fresh ? D->series[v] + fd->i0 : D->forc_multi + (size_t)v * D->n_stations * RH_SLOTS_PER_DAY);
@@ -995,14 +1011,6 @@ RH_DEV CtrlIn ctrl_inputs(const DevState *D) {
     in.dt_log_n = D->dt_log_n;
     in.dt_log_cap = D->dt_log_cap;
     return in;
-}
-// slot k (uniform) of a variable from the registers of ctrl_inputs (x0, x1, x2: the lane's slots lane, lane + 64, lane + 128)
-RH_DEV double ctrl_slot(double x0, double x1, double x2, int k) {
-    const int r = k >> 6, l = k & 63;
-    const double x = r == 0 ? x0 : (r == 1 ? x1 : x2);
-    const long long bits = __double_as_longlong(x);   // (v_readlane: the lane is uniform -- no trip through the LDS crossbar)
-    const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 // The control part in two halves.  ctrl_pre: everything that does not depend on the columns -- the time limit, the set_forcing hook, the
 // day's forcing bits (fb) and the aggregates of the day and of the hourly window; it may run while the columns are still being stepped
