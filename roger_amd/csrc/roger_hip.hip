@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(RH_BLOCK) void k_param_mask(Arena a, DevState *D, u
 #define STK(name)
 #else
 #define STK(name) \
-    if ((D->keep[RH_P_##name >> 6] >> (RH_P_##name & 63)) & 1ull) rh_st(a, RH_P_##name, i, c.name);
+    if ((keepw[RH_P_##name >> 6] >> (RH_P_##name & 63)) & 1ull) rh_st(a, RH_P_##name, i, c.name);
 #endif
 #define RH_STORES(seq, rt)                                               \
     if constexpr (LAZY && SPARSE) {                                      \
@@ -1974,6 +1974,12 @@ RH_DEV void step_column(const Arena &a, DevState *D, const StepCtx *Xp, int64_t 
     Col c;
     double pet_v = X.pet_sel_w, ta_v = X.ta_sel_w;
     double prec_s = X.prec_sel, ta_s = X.ta_sel;   // the column's own when the per-cell selection was deferred to this kernel
+    // KEEP: the words that say which pure-output planes an accumulator reads, read ONCE -- tested at the store sites out of D they were
+    // loaded again behind every store (the stores may alias them, for all the compiler knows): 72 dependent trips per wavefront,
+    // + 65 us per step at 10^6 columns (k_step<..., KEEP> 244 against 179 us; tools/experiments/diag_prof.sh)
+    unsigned long long keepw[(RH_NPLANES + 63) / 64];
+#pragma unroll
+    for (int k = 0; k < (RH_NPLANES + 63) / 64; ++k) keepw[k] = KEEP ? D->keep[k] : 0ull;
 #ifdef RH_STEP_PHASES
     const int ph_cls = X.dt < 0.5 ? 0 : (X.dt < 12 ? 1 : 2);
     unsigned long long ph_t = clock64();
