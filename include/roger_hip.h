@@ -372,6 +372,10 @@ int rh_calibrate_copy(rh_ctx *ctx, int src_plane0, int dst_plane0, int nplanes);
 /* x[i] ** y[i] by the power function the kernels use (roger_amd/csrc/rh_pow.h), evaluated on the device: tests compare it bit for bit
  * with the host's compilation of the same header, whose accuracy is established against the C library's pow. */
 int rh_selftest_pow(const double *x, const double *y, double *out, int64_t n);
+/* The sum over a 144-slot series masked to the hourly window [itd, itd + 6) (adaptive_time_stepping.py:400-420) as the kernels form it, for
+ * n window starts over one series: out[2 j] by the kernels' function (a rotation of numpy's pairwise tree where the window lies inside one
+ * 72-block), out[2 j + 1] by its general path.  Tests compare both with numpy's own sum over the masked vector, bit for bit. */
+int rh_selftest_window_sum(const double *v144, const int64_t *itd, int64_t n, double *out2n);
 /* Measurement aid: two contexts of the same shape and state exchange their arenas (does a speed level belong to the allocation?). */
 int rh_debug_swap_arenas(rh_ctx *a, rh_ctx *b);
 

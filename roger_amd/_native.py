@@ -163,6 +163,7 @@ def load():
     lib.rh_predicates_compress.argtypes = [vp, i32, vp]
     lib.rh_calibrate_copy.argtypes = [vp, i32, i32, i32]
     lib.rh_selftest_pow.argtypes = [vp, vp, vp, i64]
+    lib.rh_selftest_window_sum.argtypes = [vp, vp, i64, vp]
     lib.rh_debug_swap_arenas.argtypes = [vp, vp]
     lib.rh_predicate_words.argtypes = [vp]
     lib.rh_predicate_words.restype = vp
@@ -399,11 +400,25 @@ DECLARED_SYMBOLS = (
     "rh_evapotranspiration", "rh_snow", "rh_infiltration", "rh_subsurface_runoff", "rh_capillary_rise",
     "rh_storage", "rh_num_error", "rh_after_timestep", "rh_step_phase1", "rh_step_phase2", "rh_step_phase3",
     "rh_svat_step", "rh_svat_step_scalars", "rh_param_stats", "rh_predicate_words", "rh_timing_summary", "rh_timing_detail", "rh_enable_timing", "rh_set_forcing_series",
-    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_selftest_pow", "rh_set_lut_mlms", "rh_params_lateral",
+    "rh_hooks_phase", "rh_run_steps", "rh_predicates_expand", "rh_predicates_compress", "rh_step_core", "rh_calibrate_copy", "rh_debug_swap_arenas", "rh_selftest_pow", "rh_selftest_window_sum", "rh_set_lut_mlms", "rh_params_lateral",
     "rh_step_summary", "rh_step_finish", "rh_diag_set_interval", "rh_diag_slot_times", "rh_placement_report", "rh_step_summary_expand", "rh_step_finish_compress", "rh_diag_configure", "rh_diag_download", "rh_diag_device_ptr", "rh_diag_steps",
     "rh_set_forcing_weights", "rh_adaptive_dt_finish", "rh_diag_upload", "rh_diag_set_slot_state", "rh_set_forcing_stations", "rh_step_mode", "rh_comm_unique_id", "rh_comm_init", "rh_set_comm", "rh_comm_info", "rh_plane_is_pure_output", "rh_sparse_steps", "rh_set_time_limit", "rh_run_steps_dist",
     "rh_surface_routing", "rh_subsurface_routing", "rh_step_routed", "rh_planes_held", "rh_route_out", "rh_route_in", "rh_route_get_edges", "rh_route_get_static_edges", "rh_route_set_halo",
 )
+
+
+def selftest_window_sum(v144, itd):
+    """np.sum over the series masked to [itd, itd + 6) as the kernels form it: (by their function, by its general path) per window start."""
+    lib = load()
+    v = np.ascontiguousarray(v144, dtype=np.float64)
+    t = np.ascontiguousarray(itd, dtype=np.int64)
+    if v.size != 144:
+        raise ValueError("selftest_window_sum: a series of 144 slots")
+    out = np.empty(2 * t.size, dtype=np.float64)
+    rc = lib.rh_selftest_window_sum(v.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), t.size, out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise NativeError(f"rh_selftest_window_sum failed ({rc})")
+    return out[0::2], out[1::2]
 
 
 def selftest_pow(x, y):

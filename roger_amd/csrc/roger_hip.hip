@@ -346,22 +346,7 @@ RH_DEV double np_sum144(Get get) {
 // for everything but a negative zero, which `+ 0.0` on the way in has removed; the other block's 0.0 and the leading 0.0 + likewise):
 // five additions behind a scalar branch instead of 96 selects per sum (k_cell_agg<1> at 10^6 columns: 39 -> 17 us).
 template <class Get>
-RH_DEV double np_sum144_window(Get get, int64_t itd) {
-    const int iu = __builtin_amdgcn_readfirstlane((int)itd);
-    if (__all((int64_t)iu == itd) && iu >= 0 && iu + 6 <= RH_SLOTS_PER_DAY && !(iu < 72 && iu + 6 > 72)) {
-        const double v0 = get(iu) + 0.0, v1 = get(iu + 1) + 0.0, v2 = get(iu + 2) + 0.0, v3 = get(iu + 3) + 0.0, v4 = get(iu + 4) + 0.0,
-                     v5 = get(iu + 5) + 0.0;
-        switch (iu & 7) {
-        case 0: return ((v0 + v1) + (v2 + v3)) + (v4 + v5);
-        case 1: return (v0 + (v1 + v2)) + ((v3 + v4) + v5);
-        case 2: return (v0 + v1) + ((v2 + v3) + (v4 + v5));
-        case 3: return (v5 + v0) + ((v1 + v2) + (v3 + v4));
-        case 4: return (v4 + v5) + ((v0 + v1) + (v2 + v3));
-        case 5: return ((v3 + v4) + v5) + (v0 + (v1 + v2));
-        case 6: return ((v2 + v3) + (v4 + v5)) + (v0 + v1);
-        default: return ((v1 + v2) + (v3 + v4)) + (v5 + v0);
-        }
-    }
+RH_DEV double np_sum144_window_general(Get get, int64_t itd) {
     double lane[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -382,6 +367,25 @@ RH_DEV double np_sum144_window(Get get, int64_t itd) {
     const double h0 = ((lane[0][0] + lane[0][1]) + (lane[0][2] + lane[0][3])) + ((lane[0][4] + lane[0][5]) + (lane[0][6] + lane[0][7]));
     const double h1 = ((lane[1][0] + lane[1][1]) + (lane[1][2] + lane[1][3])) + ((lane[1][4] + lane[1][5]) + (lane[1][6] + lane[1][7]));
     return 0.0 + (h0 + h1);
+}
+template <class Get>
+RH_DEV double np_sum144_window(Get get, int64_t itd) {
+    const int iu = __builtin_amdgcn_readfirstlane((int)itd);
+    if (__all((int64_t)iu == itd) && iu >= 0 && iu + 6 <= RH_SLOTS_PER_DAY && !(iu < 72 && iu + 6 > 72)) {
+        const double v0 = get(iu) + 0.0, v1 = get(iu + 1) + 0.0, v2 = get(iu + 2) + 0.0, v3 = get(iu + 3) + 0.0, v4 = get(iu + 4) + 0.0,
+                     v5 = get(iu + 5) + 0.0;
+        switch (iu & 7) {
+        case 0: return ((v0 + v1) + (v2 + v3)) + (v4 + v5);
+        case 1: return (v0 + (v1 + v2)) + ((v3 + v4) + v5);
+        case 2: return (v0 + v1) + ((v2 + v3) + (v4 + v5));
+        case 3: return (v5 + v0) + ((v1 + v2) + (v3 + v4));
+        case 4: return (v4 + v5) + ((v0 + v1) + (v2 + v3));
+        case 5: return ((v3 + v4) + v5) + (v0 + (v1 + v2));
+        case 6: return ((v2 + v3) + (v4 + v5)) + (v0 + v1);
+        default: return ((v1 + v2) + (v3 + v4)) + (v5 + v0);
+        }
+    }
+    return np_sum144_window_general(get, itd);
 }
 
 // aggregates {prec, ta, pet} x {daily, hourly, 10 min} of one forcing series given by accessors (per-cell rows, or the
@@ -4304,6 +4308,34 @@ int rh_selftest_pow(const double *x, const double *y, double *out, int64_t n) {
         hipLaunchKernelGGL(k_selftest_rh_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * n, n);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(out, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = RH_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+// np_sum144_window for n window starts over one 144-vector, one wavefront per start: out[2 j] by the kernels' function (the rotation path
+// where it applies), out[2 j + 1] by the general path (tests: both are numpy's sum over the masked vector, bit for bit)
+__global__ void k_selftest_window(const double *v, const int64_t *itd, double *out) {
+    const int64_t t = itd[blockIdx.x];
+    auto get = [&](int k) { return v[k]; };
+    const double a = np_sum144_window(get, t), b = np_sum144_window_general(get, t);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = a;
+        out[2 * blockIdx.x + 1] = b;
+    }
+}
+int rh_selftest_window_sum(const double *v144, const int64_t *itd, int64_t n, double *out2n) {
+    if (!v144 || !itd || !out2n || n <= 0) return RH_ERR_ARG;
+    char *d = nullptr;
+    const size_t bv = RH_SLOTS_PER_DAY * sizeof(double), bi = (size_t)n * sizeof(int64_t), bo = (size_t)n * 2 * sizeof(double);
+    if (hipMalloc((void **)&d, bv + bi + bo) != hipSuccess) return RH_ERR_HIP;
+    int rc = RH_OK;
+    if (hipMemcpy(d, v144, bv, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + bv, itd, bi, hipMemcpyHostToDevice) != hipSuccess) rc = RH_ERR_HIP;
+    if (rc == RH_OK) {
+        hipLaunchKernelGGL(k_selftest_window, dim3((unsigned)n), dim3(64), 0, 0, (const double *)d, (const int64_t *)(d + bv), (double *)(d + bv + bi));
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out2n, d + bv + bi, bo, hipMemcpyDeviceToHost) != hipSuccess)
             rc = RH_ERR_HIP;
     }
     (void)hipFree(d);

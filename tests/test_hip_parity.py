@@ -842,3 +842,26 @@ def test_eberbaechle_full_series_80x53(native):
     print(f"EBERBAECHLE 80x53 full series: {nsteps} steps in {wall:.2f} s incl. 18 state downloads ({nsteps / wall:.0f} steps/s, "
           f"{nsteps * nx * ny / wall:.3e} cell-timesteps/s); fused kernel {ms.mean() * 1e3:.1f} us per step")
     ctx.close()
+
+
+def test_window_sums_are_numpys(native):
+    """The hourly window sums (np.sum over a 144-slot series masked to [itd, itd + 6), adaptive_time_stepping.py:400-420) as the kernels
+    form them -- one of eight rotations of numpy's pairwise tree where the window lies inside one 72-block, the general path otherwise --
+    against numpy's own sum over the masked vector, for EVERY window start incl. the ones that leave the day or straddle slot 72, on
+    values whose sums depend on the order of the additions."""
+    from roger_amd import _native as N
+
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        v = rng.uniform(-1.0, 1.0, 144) * 10.0 ** rng.integers(-12, 6, 144)
+        if trial == 1:
+            v[rng.integers(0, 144, 40)] = 0.0
+            v[rng.integers(0, 144, 10)] = -0.0
+        itd = np.arange(-7, 146, dtype=np.int64)
+        fast, general = N.selftest_window_sum(v, itd)
+        want = np.empty(itd.size)
+        k = np.arange(144)
+        for j, t in enumerate(itd):
+            want[j] = np.sum(np.where((k >= t) & (k < t + 6), v, 0.0))
+        assert np.array_equal(general.view(np.int64), want.view(np.int64))
+        assert np.array_equal(fast.view(np.int64), want.view(np.int64))
